@@ -1,0 +1,100 @@
+"""Deterministic synthetic XYZRGB frames.
+
+Generator = SplitMix64 seeded per configuration; frame f of a sequence uses
+seed + f.  All coordinates are produced as float32 and the point order is the
+generation order (it matters: the reference's adaptive bounding box and the
+per-voxel point lists are order dependent).  The frames are then passed through
+the same group normalisation the reference applies before encoding
+(normalize_pointclouds, impl.hpp:1871-1967, bb_expand_factor = 0.2).
+"""
+import numpy as np
+
+POINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("rgba", "<u4"), ("pad", "<u4", (3,))]
+)
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64(seed, n, stream=0):
+    """n outputs of SplitMix64 started at `seed` (vectorised; stream offsets the counter)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64) + np.uint64(stream) * np.uint64(n)
+        z = np.uint64(seed) + idx * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _u01(seed, n, stream):
+    return (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def normalize(points, bb_expand_factor=0.2):
+    """normalize_pointclouds for one cloud, float32 arithmetic as impl.hpp:1915-1946."""
+    mn = np.array([points[a].min() for a in "xyz"], dtype=np.float32)
+    mx = np.array([points[a].max() for a in "xyz"], dtype=np.float32)
+    ext = np.abs(mx - mn)  # float
+    bb_min = (mn.astype(np.float64) - bb_expand_factor * ext.astype(np.float64)).astype(np.float32)
+    bb_max = (mx.astype(np.float64) + bb_expand_factor * ext.astype(np.float64)).astype(np.float32)
+    dyn = bb_max - bb_min
+    for i, a in enumerate("xyz"):
+        points[a] = (points[a] - bb_min[i]) / dyn[i]
+    return bb_min, bb_max
+
+
+def _finish(xyz, seed, n, do_normalize):
+    pts = np.zeros(n, dtype=POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts["w"] = 1.0
+    if do_normalize:
+        normalize(pts)
+    # colour: r = 255 x, g = 255 y, b = 255 z (+ U{-8..8}), clamped
+    noise = (splitmix64(seed, 3 * n, 7) % np.uint64(17)).astype(np.int64).reshape(n, 3) - 8
+    col = np.stack([pts["x"], pts["y"], pts["z"]], 1).astype(np.float64) * 255.0
+    col = np.clip(np.floor(col).astype(np.int64) + noise, 0, 255).astype(np.uint32)
+    pts["rgba"] = col[:, 2] | (col[:, 1] << 8) | (col[:, 0] << 16) | np.uint32(0xFF000000)
+    return pts
+
+
+def sphere_shell(n, seed, centre=(0.5, 0.5, 0.5), radius=0.3, noise=0.002, do_normalize=True):
+    """Surface-like frame (cfg1 / cfg2-surface / cfg3 fallback / cfg5)."""
+    u = _u01(seed, n, 0)
+    v = _u01(seed, n, 1)
+    w = _u01(seed, n, 2)
+    ct = 2.0 * u - 1.0
+    st = np.sqrt(np.maximum(0.0, 1.0 - ct * ct))
+    ph = 2.0 * np.pi * v
+    r = radius + (2.0 * w - 1.0) * noise
+    xyz = np.stack([centre[0] + r * st * np.cos(ph), centre[1] + r * st * np.sin(ph), centre[2] + r * ct], 1)
+    return _finish(xyz.astype(np.float32), seed, n, do_normalize)
+
+
+def uniform_volume(n, seed, do_normalize=True):
+    """Dense frame: uniform random in the unit cube (cfg2-uniform / cfg4)."""
+    xyz = np.stack([_u01(seed, n, 0), _u01(seed, n, 1), _u01(seed, n, 2)], 1)
+    return _finish(xyz.astype(np.float32), seed, n, do_normalize)
+
+
+CONFIGS = {
+    # name: (generator, n, seed, codec settings)
+    "cfg1": dict(gen="sphere", n=100_000, seed=0xC1, octree_bits=8, color_bits=8, color_coding_type=1,
+                 jpeg_quality=85, keep_centroid=0),
+    "cfg2": dict(gen="sphere", n=1_000_000, seed=0xC2, octree_bits=10, color_bits=8, color_coding_type=1,
+                 jpeg_quality=85, keep_centroid=0),
+    "cfg2u": dict(gen="uniform", n=1_000_000, seed=0xC2, octree_bits=10, color_bits=8, color_coding_type=1,
+                  jpeg_quality=85, keep_centroid=0),
+    "cfg3": dict(gen="sphere", n=800_000, seed=0xC3, octree_bits=10, color_bits=8, color_coding_type=1,
+                 jpeg_quality=85, keep_centroid=0),
+    "cfg4": dict(gen="uniform", n=10_000_000, seed=0xC4, octree_bits=12, color_bits=0, color_coding_type=1,
+                 jpeg_quality=85, keep_centroid=0),
+}
+
+
+def make_frame(cfg, frame=0, n=None):
+    c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
+    n = c["n"] if n is None else n
+    seed = c["seed"] + frame
+    if c["gen"] == "sphere":
+        return sphere_shell(n, seed)
+    return uniform_volume(n, seed)

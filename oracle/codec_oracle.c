@@ -1,0 +1,375 @@
+/*
+ * codec_oracle.c -- CPU ORACLE (test infrastructure, not product code).
+ *
+ * Frame-level restatement of the reference codec:
+ *   C1 encodePointCloud          impl.hpp:80-213
+ *   C6 writeFrameHeader          impl.hpp:1472-1486 (+ PCL base header it calls at :1477)
+ *   C7 entropyEncoding           impl.hpp:1682-1760
+ *   C3 ColorCodingJPEG           jpegcc.h:115-139 (getAverageDataVector),
+ *                                jpegcc.h:187-226 (encodeJPEGSnake), :244-317 (encodeJPEGLines)
+ *   C8 decodePointCloud          impl.hpp:224-310, syncToHeader :1660-1676,
+ *      readFrameHeader :1489-1502, entropyDecoding :1766-1835,
+ *      deserializeTreeCallback :1584-1653, jpegcc.h:150-172, :228-242, :319-344
+ *   normalize_pointclouds        impl.hpp:1871-1967
+ *
+ * PCL-inherited pieces (base header layout, deserializeTree, ColorCoding::
+ * decodePoints, defineBoundingBox/getKeyBitSize) are "parity unpinned", see
+ * pcc_oracle.h.
+ */
+#include "oracle_util.h"
+#include "octree_oracle.h"
+#include <float.h>
+#include <math.h>
+
+static const char V2_ID[] = "<PCL-OCT-CODECV2-COMPRESSED>"; /* codec.h:371 */
+static const char V1_ID[] = "<PCL-OCT-COMPRESSED>";         /* PCL frame_header_identifier_ */
+
+void pcco_frame_free(pcco_frame *f) {
+  free(f->leaf_keys);
+  free(f->leaf_counts);
+  free(f->simplified);
+  pcco_buf_free(&f->occupancy);
+  pcco_buf_free(&f->bgr);
+  pcco_buf_free(&f->centroid_bytes);
+  pcco_buf_free(&f->color_payload);
+  pcco_buf_free(&f->snake_image);
+  pcco_buf_free(&f->bitstream);
+  memset(f, 0, sizeof(*f));
+}
+void pcco_cloud_free(pcco_cloud *c) {
+  free(c->points);
+  memset(c, 0, sizeof(*c));
+}
+
+/* C3: encodeJPEGSnake (jpegcc.h:187-226) */
+static void encode_jpeg_snake(pcco_frame *f, int quality) {
+  long pixel_count = (long)f->bgr.len / 3;
+  int W = 256;
+  int H = (int)(pixel_count / W + 1);
+  long padded = (long)W * H - pixel_count;
+  pcco_buf in = {0, 0, 0};
+  buf_write(&in, f->bgr.data, f->bgr.len);
+  uint8_t last[3] = {f->bgr.data[f->bgr.len - 3], f->bgr.data[f->bgr.len - 2], f->bgr.data[f->bgr.len - 1]};
+  for (long j = 0; j < padded; j++) buf_write(&in, last, 3);
+  int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)W * H);
+  pcco_snake_perm(W, H, perm);
+  buf_reserve(&f->snake_image, (size_t)3 * W * H);
+  f->snake_image.len = (size_t)3 * W * H;
+  for (long i = 0; i < (long)W * H; i++) { /* doMapping, snake.h:105-118 */
+    f->snake_image.data[3 * perm[i] + 0] = in.data[3 * i + 0];
+    f->snake_image.data[3 * perm[i] + 1] = in.data[3 * i + 1];
+    f->snake_image.data[3 * perm[i] + 2] = in.data[3 * i + 2];
+  }
+  f->image_w = (uint32_t)W;
+  f->image_h = (uint32_t)H;
+  pcco_jpeg_encode_rgb(f->snake_image.data, W, H, quality, &f->color_payload);
+  free(perm);
+  pcco_buf_free(&in);
+}
+
+/* C3: encodeJPEGLines (jpegcc.h:244-317) + JPEGLineData::serialize (:72-83) */
+static void encode_jpeg_lines(pcco_frame *f, int quality) {
+  long pixel_count = (long)f->bgr.len / 3;
+  int num_lines = (int)(pixel_count / 2048);
+  uint32_t line_count = num_lines ? (uint32_t)num_lines : 1u;
+  buf_write(&f->color_payload, &line_count, 4);
+  for (uint32_t i = 0; i < line_count; i++) {
+    long start = 2048L * i;
+    long width = (num_lines == 0) ? pixel_count : (i != line_count - 1 ? 2048 : pixel_count - start);
+    pcco_buf line = {0, 0, 0};
+    pcco_jpeg_encode_rgb(f->bgr.data + 3 * start, (int)width, 1, quality, &line);
+    uint32_t sz = (uint32_t)line.len;
+    buf_write(&f->color_payload, &sz, 4);
+    buf_write(&f->color_payload, line.data, line.len);
+    pcco_buf_free(&line);
+  }
+}
+
+int pcco_encode_intra(const pcco_point *pts, size_t n, const pcco_params *p, pcco_frame *f) {
+  memset(f, 0, sizeof(*f));
+  /* impl.hpp:89-99: fresh tree + bbox every frame, then insert all points */
+  pcco_octree *t = pcco_octree_new(p->octree_resolution);
+  pcco_octree_add_points(t, pts, n);
+  if (pcco_octree_leaf_count(t) == 0) { /* impl.hpp:206-212: frame dropped */
+    pcco_octree_free(t);
+    return 1;
+  }
+  int cloud_with_color = p->do_color_encoding ? 1 : 0; /* impl.hpp:105-120 (PointXYZRGB has "rgb") */
+  pcco_octree_serialize(t, pts, p, cloud_with_color, f); /* impl.hpp:166 */
+  pcco_octree_free(t);
+
+  pcco_buf *o = &f->bitstream;
+  /* C6 header, 140 bytes */
+  buf_write(o, V2_ID, 28);
+  buf_write(o, V1_ID, 20);
+  uint32_t frame_id = p->frame_id;
+  uint8_t u8;
+  buf_write(o, &frame_id, 4);
+  u8 = 1; buf_write(o, &u8, 1);                                /* i_frame_ */
+  u8 = 1; buf_write(o, &u8, 1);                                /* do_voxel_grid_enDecoding_ */
+  u8 = (uint8_t)cloud_with_color; buf_write(o, &u8, 1);
+  uint64_t point_count = f->n_leaves; buf_write(o, &point_count, 8);
+  double d = p->octree_resolution; buf_write(o, &d, 8);
+  u8 = (uint8_t)p->color_bit_resolution; buf_write(o, &u8, 1);  /* color_coder_.getBitDepth() */
+  d = (double)(float)p->point_resolution; buf_write(o, &d, 8);  /* point_coder_.getPrecision() is float */
+  buf_write(o, f->bbox, 48);
+  u8 = (uint8_t)(p->do_voxel_centroid != 0); buf_write(o, &u8, 1);
+  u8 = (uint8_t)(p->do_connectivity != 0); buf_write(o, &u8, 1);
+  u8 = (uint8_t)(p->create_scalable != 0); buf_write(o, &u8, 1);
+  uint32_t cct = (uint32_t)p->color_coding_type; buf_write(o, &cct, 4);
+  int32_t mbs = p->macroblock_size; buf_write(o, &mbs, 4);
+  u8 = (uint8_t)(p->do_icp_color_offset != 0); buf_write(o, &u8, 1);
+
+  /* C7 entropy stage */
+  uint64_t sz64 = f->occupancy.len;
+  buf_write(o, &sz64, 8);
+  uint64_t point_len = pcco_rc_encode(f->occupancy.data, f->occupancy.len, o);
+  f->perf[0] = point_len;
+  if (p->do_voxel_centroid) {
+    uint32_t sz32 = (uint32_t)f->centroid_bytes.len;
+    buf_write(o, &sz32, 4);
+    point_len += pcco_rc_encode(f->centroid_bytes.data, f->centroid_bytes.len, o);
+  }
+  f->perf[1] = point_len - f->perf[0];
+  uint64_t color_len = 0;
+  if (cloud_with_color) {
+    switch (p->color_coding_type) { /* jpegcc.h:115-139 */
+      case 1: encode_jpeg_snake(f, p->jpeg_quality); break;
+      case 2: encode_jpeg_lines(f, p->jpeg_quality); break;
+      default: buf_write(&f->color_payload, f->bgr.data, f->bgr.len); break;
+    }
+    sz64 = f->color_payload.len;
+    buf_write(o, &sz64, 8);
+    color_len = pcco_rc_encode(f->color_payload.data, f->color_payload.len, o);
+  }
+  f->perf[2] = color_len;
+  return 0;
+}
+
+/* ---------------- decoder ---------------- */
+
+typedef struct {
+  const uint8_t *p;
+  size_t len, pos;
+} rd;
+static int rd_get(rd *r, void *dst, size_t n) {
+  if (r->pos + n > r->len) return -1;
+  memcpy(dst, r->p + r->pos, n);
+  r->pos += n;
+  return 0;
+}
+static int sync_to(rd *r, const char *id) { /* impl.hpp:1660-1676 scanning loop */
+  size_t idlen = strlen(id), k = 0;
+  while (k < idlen) {
+    if (r->pos >= r->len) return -1;
+    char c = (char)r->p[r->pos++];
+    if (c != id[k++]) k = (id[0] == c) ? 1 : 0;
+  }
+  return 0;
+}
+
+typedef struct {
+  const pcco_cloud *c;
+  const uint8_t *occ;
+  size_t occ_len, occ_pos;
+  const uint8_t *cen;   /* centroid bytes or NULL */
+  const uint8_t *col;   /* per-voxel colour bytes or NULL */
+  size_t col_len;
+  size_t leaf_i;
+  pcco_point *out;
+  size_t out_cap;
+  double res;
+  unsigned color_shift;
+  int with_color;
+} des_ctx;
+
+/* C8: deserializeTreeCallback (impl.hpp:1584-1653), voxel-grid branch */
+static void des_leaf(des_ctx *s, const unsigned key[3]) {
+  pcco_point np;
+  memset(&np, 0, sizeof(np));
+  np.w = 1.0f;
+  np.rgba = 0xFF000000u; /* default PointXYZRGB */
+  const double *mn = s->c->bbox;
+  float xyz[3];
+  if (s->cen) {
+    for (int a = 0; a < 3; a++) {
+      double lc = (double)key[a] * s->res + mn[a];
+      unsigned char diff = s->cen[3 * s->leaf_i + a];
+      xyz[a] = (float)(lc + diff * 0.001f); /* ptv2.h:115-117: uchar * float precision */
+    }
+  } else {
+    for (int a = 0; a < 3; a++) xyz[a] = (float)(((double)key[a] + 0.5) * s->res + mn[a]); /* impl.hpp:1630-1632 */
+  }
+  np.x = xyz[0]; np.y = xyz[1]; np.z = xyz[2];
+  if (s->with_color) {
+    /* ColorCoding::decodePoints, pointCount == 1 */
+    size_t i3 = 3 * s->leaf_i;
+    unsigned a0 = 0, a1 = 0, a2 = 0;
+    if (i3 + 2 < s->col_len) { a0 = s->col[i3]; a1 = s->col[i3 + 1]; a2 = s->col[i3 + 2]; }
+    a0 = (unsigned char)(a0 << s->color_shift);
+    a1 = (unsigned char)(a1 << s->color_shift);
+    a2 = (unsigned char)(a2 << s->color_shift);
+    np.rgba = a0 | (a1 << 8) | (a2 << 16);
+  } else {
+    np.rgba = 0x00FFFFFFu; /* ColorCoding::setDefaultColor */
+  }
+  if (s->leaf_i < s->out_cap) s->out[s->leaf_i] = np;
+  s->leaf_i++;
+}
+
+/* Appendix B: Octree2BufBase::deserializeTreeRecursive */
+static void des_rec(des_ctx *s, unsigned depth_mask, unsigned key[3]) {
+  if (s->occ_pos >= s->occ_len) return;
+  uint8_t bits = s->occ[s->occ_pos++];
+  for (unsigned c = 0; c < 8; c++) {
+    if (!(bits & (1u << c))) continue;
+    key[0] = (key[0] << 1) | (!!(c & 4));
+    key[1] = (key[1] << 1) | (!!(c & 2));
+    key[2] = (key[2] << 1) | (!!(c & 1));
+    if (depth_mask > 1) des_rec(s, depth_mask / 2, key);
+    else des_leaf(s, key);
+    key[0] >>= 1; key[1] >>= 1; key[2] >>= 1;
+  }
+}
+
+int pcco_decode_intra(const uint8_t *bs, size_t len, pcco_cloud *out) {
+  memset(out, 0, sizeof(*out));
+  rd r = {bs, len, 0};
+  if (sync_to(&r, V2_ID)) return -1;
+  if (sync_to(&r, V1_ID)) return -1;
+  pcco_params *p = &out->params;
+  uint8_t i_frame, vg, with_color, u8;
+  uint64_t point_count;
+  double octree_res, point_res;
+  if (rd_get(&r, &p->frame_id, 4) || rd_get(&r, &i_frame, 1)) return -2;
+  if (!i_frame) return -3;
+  if (rd_get(&r, &vg, 1) || rd_get(&r, &with_color, 1) || rd_get(&r, &point_count, 8) ||
+      rd_get(&r, &octree_res, 8) || rd_get(&r, &u8, 1) || rd_get(&r, &point_res, 8) ||
+      rd_get(&r, out->bbox, 48))
+    return -2;
+  p->color_bit_resolution = u8;
+  p->octree_resolution = octree_res;
+  p->point_resolution = point_res;
+  p->do_color_encoding = with_color;
+  uint32_t cct; int32_t mbs;
+  if (rd_get(&r, &u8, 1)) return -2;
+  p->do_voxel_centroid = u8;
+  if (rd_get(&r, &u8, 1)) return -2;
+  p->do_connectivity = u8;
+  if (rd_get(&r, &u8, 1)) return -2;
+  p->create_scalable = u8;
+  if (rd_get(&r, &cct, 4) || rd_get(&r, &mbs, 4) || rd_get(&r, &u8, 1)) return -2;
+  p->color_coding_type = (int)cct; p->macroblock_size = mbs; p->do_icp_color_offset = u8;
+
+  /* defineBoundingBox -> getKeyBitSize (Appendix B) */
+  {
+    const float mv = FLT_EPSILON;
+    unsigned mk = 0;
+    for (int a = 0; a < 3; a++) {
+      unsigned k = (unsigned)ceil((out->bbox[3 + a] - out->bbox[a] - mv) / octree_res);
+      if (k > mk) mk = k;
+    }
+    if (mk < 2) mk = 2;
+    unsigned dd = (unsigned)ceil(log2((double)mk) - mv);
+    if (dd > 32) dd = 32;
+    out->depth = dd;
+    double side = (double)(1u << dd) * octree_res;
+    for (int a = 0; a < 3; a++) {
+      double over = (side - (out->bbox[3 + a] - out->bbox[a])) / 2.0;
+      if (over > mv) { out->bbox[a] -= over; out->bbox[3 + a] += over; }
+    }
+  }
+
+  /* entropyDecoding (impl.hpp:1766-1835) */
+  uint64_t occ_n;
+  if (rd_get(&r, &occ_n, 8)) return -2;
+  uint8_t *occ = (uint8_t *)malloc(occ_n ? occ_n : 1);
+  r.pos += pcco_rc_decode(r.p + r.pos, r.len - r.pos, occ, occ_n);
+  uint8_t *cen = NULL;
+  if (p->do_voxel_centroid) {
+    uint32_t cn;
+    if (rd_get(&r, &cn, 4)) { free(occ); return -2; }
+    cen = (uint8_t *)malloc(cn ? cn : 1);
+    r.pos += pcco_rc_decode(r.p + r.pos, r.len - r.pos, cen, cn);
+  }
+  uint8_t *col = NULL;
+  size_t col_len = 0;
+  if (with_color) {
+    uint64_t cn;
+    if (rd_get(&r, &cn, 8)) { free(occ); free(cen); return -2; }
+    uint8_t *payload = (uint8_t *)malloc(cn ? cn : 1);
+    r.pos += pcco_rc_decode(r.p + r.pos, r.len - r.pos, payload, cn);
+    if (cct == 1) { /* decodeJPEGSnake (jpegcc.h:228-242) */
+      uint8_t *img; int w, h;
+      if (pcco_jpeg_decode_rgb(payload, cn, &img, &w, &h) == 0) {
+        int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)w * h);
+        pcco_snake_perm(w, h, perm);
+        col_len = (size_t)3 * w * h;
+        col = (uint8_t *)malloc(col_len);
+        for (long i = 0; i < (long)w * h; i++) { /* undoSnakeGridMapping, snake.h:123-137 */
+          col[3 * i + 0] = img[3 * perm[i] + 0];
+          col[3 * i + 1] = img[3 * perm[i] + 1];
+          col[3 * i + 2] = img[3 * perm[i] + 2];
+        }
+        free(perm); free(img);
+      }
+      free(payload);
+    } else if (cct == 2) { /* decodeJPEGLines (jpegcc.h:319-344) */
+      rd lr = {payload, cn, 0};
+      uint32_t lc = 0;
+      rd_get(&lr, &lc, 4);
+      pcco_buf acc = {0, 0, 0};
+      for (uint32_t i = 0; i < lc; i++) {
+        uint32_t ls = 0;
+        if (rd_get(&lr, &ls, 4) || lr.pos + ls > lr.len) break;
+        uint8_t *img; int w, h;
+        if (pcco_jpeg_decode_rgb(lr.p + lr.pos, ls, &img, &w, &h) == 0) {
+          buf_write(&acc, img, (size_t)3 * w * h);
+          free(img);
+        }
+        lr.pos += ls;
+      }
+      col = acc.data; col_len = acc.len;
+      free(payload);
+    } else {
+      col = payload; col_len = cn;
+    }
+  }
+  out->consumed = r.pos;
+
+  out->n = point_count;
+  out->points = (pcco_point *)calloc(point_count ? point_count : 1, sizeof(pcco_point));
+  des_ctx s;
+  memset(&s, 0, sizeof(s));
+  s.c = out; s.occ = occ; s.occ_len = occ_n; s.cen = cen; s.col = col; s.col_len = col_len;
+  s.out = out->points; s.out_cap = point_count; s.res = octree_res; s.with_color = with_color;
+  s.color_shift = (cct == 0) ? (unsigned)(8 - p->color_bit_resolution) : 0u;
+  unsigned key[3] = {0, 0, 0};
+  des_rec(&s, 1u << (out->depth - 1), key);
+  int rc = (s.leaf_i == point_count) ? 0 : -20;
+  free(occ); free(cen); free(col);
+  return rc;
+}
+
+/* normalize_pointclouds (impl.hpp:1871-1967), one cloud, fresh box */
+void pcco_normalize_single(pcco_point *pts, size_t n, double f, float bb_min[3], float bb_max[3]) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (size_t i = 0; i < n; i++) { /* pcl::getMinMax3D (finite points only) */
+    float q[3] = {pts[i].x, pts[i].y, pts[i].z};
+    if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) continue;
+    for (int a = 0; a < 3; a++) {
+      if (q[a] < mn[a]) mn[a] = q[a];
+      if (q[a] > mx[a]) mx[a] = q[a];
+    }
+  }
+  float dyn[3];
+  for (int a = 0; a < 3; a++) { /* impl.hpp:1915-1921: double product stored to float */
+    bb_min[a] = (float)((double)mn[a] - f * (double)fabsf(mx[a] - mn[a]));
+    bb_max[a] = (float)((double)mx[a] + f * (double)fabsf(mx[a] - mn[a]));
+    dyn[a] = bb_max[a] - bb_min[a];
+  }
+  for (size_t i = 0; i < n; i++) { /* impl.hpp:1935-1946: two float ops per axis */
+    pts[i].x -= bb_min[0]; pts[i].y -= bb_min[1]; pts[i].z -= bb_min[2];
+    pts[i].x /= dyn[0]; pts[i].y /= dyn[1]; pts[i].z /= dyn[2];
+  }
+}

@@ -1,0 +1,21 @@
+/* octree_oracle.h -- CPU ORACLE (test infrastructure): pointer-octree internals. */
+#ifndef PCC_OCTREE_ORACLE_H
+#define PCC_OCTREE_ORACLE_H
+#include "pcc_oracle.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct pcco_octree pcco_octree;
+pcco_octree *pcco_octree_new(double resolution);
+void pcco_octree_free(pcco_octree *t);
+void pcco_octree_add_points(pcco_octree *t, const pcco_point *pts, size_t n);
+uint64_t pcco_octree_leaf_count(const pcco_octree *t);
+uint64_t pcco_octree_object_count(const pcco_octree *t);
+unsigned pcco_octree_depth(const pcco_octree *t);
+void pcco_octree_bbox(const pcco_octree *t, double bb[6]);
+void pcco_octree_serialize(const pcco_octree *t, const pcco_point *pts, const pcco_params *prm,
+                           int cloud_with_color, pcco_frame *f);
+#ifdef __cplusplus
+}
+#endif
+#endif

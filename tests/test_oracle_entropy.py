@@ -1,0 +1,142 @@
+"""Oracle checks: static range coder (P7), snake mapping (C3b), JPEG stage (C5/C8)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------- range coder ----------------
+
+def test_rc_empty_vector_kat(oracle):
+    """Empty input: table = 0,1,...,256 (every symbol forced to count 1) + 8 flush bytes of zero."""
+    enc = oracle.rc_encode(b"")
+    assert len(enc) == 1028 + 8
+    assert struct.unpack("<257I", enc[:1028]) == tuple(range(257))
+    assert enc[1028:] == bytes(8)
+
+
+def test_rc_single_symbol_table(oracle):
+    enc = oracle.rc_encode(bytes([7]))
+    freq = struct.unpack("<257I", enc[:1028])
+    # counts: 1 for every absent symbol (forced strictly increasing), 1 for symbol 7
+    assert freq[256] == 256 and all(freq[i + 1] - freq[i] == 1 for i in range(256))
+    dec, used = oracle.rc_decode(enc, 1)
+    assert dec == bytes([7]) and used == len(enc)
+
+
+@pytest.mark.parametrize("n,kind", [(1, "u"), (256, "all"), (5000, "u"), (200_000, "skew"), (50_000, "occ")])
+def test_rc_round_trip(oracle, n, kind):
+    rng = np.random.default_rng(n)
+    if kind == "all":
+        data = bytes(range(256))
+    elif kind == "skew":
+        data = bytes(np.minimum(rng.geometric(0.3, n), 255).astype(np.uint8))
+    elif kind == "occ":  # occupancy-like: few bits set
+        data = bytes((1 << rng.integers(0, 8, n) | 1 << rng.integers(0, 8, n)).astype(np.uint8))
+    else:
+        data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    enc = oracle.rc_encode(data)
+    dec, used = oracle.rc_decode(enc, len(data))
+    assert dec == data
+    assert used == len(enc)  # the decoder consumes exactly what the encoder wrote
+
+
+def test_rc_python_model_agrees(oracle):
+    """Independent pure-Python transcription of the P7 loop (small input)."""
+    rng = np.random.default_rng(11)
+    data = bytes(np.minimum(rng.geometric(0.2, 3000), 255).astype(np.uint8))
+    M = (1 << 64) - 1
+    hist = [0] * 257
+    for s in data:
+        hist[s + 1] += 1
+    freq = [0] * 257
+    for f in range(1, 257):
+        freq[f] = freq[f - 1] + hist[f]
+        if freq[f] <= freq[f - 1]:
+            freq[f] = freq[f - 1] + 1
+    out = bytearray(struct.pack("<257I", *freq))
+    low, rng_ = 0, M
+    top, bottom = 1 << 56, 1 << 48
+    for ch in data:
+        rng_ //= freq[256]
+        low = (low + freq[ch] * rng_) & M
+        rng_ = (rng_ * (freq[ch + 1] - freq[ch])) & M
+        while True:
+            if ((low ^ ((low + rng_) & M)) < top):
+                pass
+            elif rng_ < bottom:
+                rng_ = ((-low) & M) & (bottom - 1)
+            else:
+                break
+            out.append(low >> 56)
+            rng_ = (rng_ << 8) & M
+            low = (low << 8) & M
+    for _ in range(8):
+        out.append(low >> 56)
+        low = (low << 8) & M
+    assert bytes(out) == oracle.rc_encode(data)
+
+
+# ---------------- snake mapping ----------------
+
+SNAKE_SHAPES = [(256, 1), (256, 5), (256, 8), (256, 9), (256, 17), (16, 3), (8, 7), (64, 23), (256, 391)]
+
+
+def test_snake_appendix_f_16x3(oracle):
+    """Hand-derived order for a 16x3 image: odd row count quirk."""
+    want = list(range(0, 8)) + list(range(23, 15, -1)) + list(range(32, 40)) + \
+        list(range(15, 7, -1)) + list(range(24, 32)) + list(range(47, 39, -1))
+    assert oracle.snake_perm(16, 3).tolist() == want
+
+
+@pytest.mark.parametrize("w,h", SNAKE_SHAPES)
+def test_snake_matches_reference_header(oracle, w, h):
+    """PIN: the restatement equals the reference's own snake_grid_mapping.h (oracle/_ref)."""
+    ref = oracle.ref_snake_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref/libsnake_ref.so not built (needs /root/reference at build time)")
+    mine = oracle.snake_perm(w, h)
+    theirs = np.zeros(w * h, dtype=np.int32)
+    ref.ref_snake_perm(w, h, theirs.ctypes.data)
+    assert np.array_equal(mine, theirs)
+    assert sorted(mine.tolist()) == list(range(w * h))  # a permutation
+    # doMapping / undoSnakeGridMapping through the reference class itself
+    rng = np.random.default_rng(w * h)
+    data = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    mapped = np.zeros_like(data)
+    ref.ref_snake_do_mapping(w, h, data.ctypes.data, mapped.ctypes.data)
+    want = np.zeros_like(data)
+    want.reshape(-1, 3)[mine] = data.reshape(-1, 3)
+    assert np.array_equal(mapped, want)
+    back = np.zeros_like(data)
+    ref.ref_snake_undo_mapping(w, h, mapped.ctypes.data, back.ctypes.data)
+    assert np.array_equal(back, data)
+
+
+# ---------------- JPEG ----------------
+
+def _golden_cases():
+    z = np.load(os.path.join(GOLDEN, "jpeg_golden.npz"))
+    n = len([k for k in z.files if k.startswith("in_")])
+    return [(z["in_%02d" % i], int(z["q_%02d" % i]), z["jpg_%02d" % i].tobytes(), z["dec_%02d" % i]) for i in range(n)]
+
+
+def test_jpeg_encode_matches_libjpeg_turbo(oracle):
+    """PIN: byte-exact with libjpeg-turbo (fixtures from tests/golden/make_jpeg_golden.py)."""
+    for img, q, jpg, _ in _golden_cases():
+        assert oracle.jpeg_encode(img, q) == jpg, "shape %s q %d" % (img.shape, q)
+
+
+def test_jpeg_decode_matches_libjpeg_turbo(oracle):
+    for img, q, jpg, dec in _golden_cases():
+        got = oracle.jpeg_decode(jpg)
+        assert got.shape == dec.shape and np.array_equal(got, dec), "shape %s q %d" % (img.shape, q)
+
+
+def test_jpeg_quality_zero_is_clamped_to_one(oracle):
+    """eval.hpp:161 default jpeg_quality=0; libjpeg clamps to 1 (jpeg_quality_scaling)."""
+    img = np.arange(16 * 16 * 3, dtype=np.uint8).reshape(16, 16, 3)
+    assert oracle.jpeg_encode(img, 0) == oracle.jpeg_encode(img, 1)
