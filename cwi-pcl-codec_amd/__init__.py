@@ -2,7 +2,8 @@
 
 The product is the C-ABI shared library built from csrc/ (libpcc_hip.so, declared in
 include/pcc_codec.h).  This Python package only holds the ctypes binding used by the
-tests and bench.py, and the deterministic synthetic frame generator.  The directory name
-contains a hyphen, so it is imported by path: see __graft_entry__.load_package().
+tests and bench.py (binding.py, which also mirrors the reference class interface), and
+the deterministic synthetic frame generator.  The directory name contains a hyphen, so
+it is imported by path: see __graft_entry__.load_package().
 """
-from . import synthetic  # noqa: F401
+from . import binding, synthetic  # noqa: F401

@@ -1,0 +1,375 @@
+"""ctypes binding of libpcc_hip.so (include/pcc_codec.h) and a host-side mirror of the
+reference class interface.
+
+`OctreePointCloudCodecV2` below has the public surface of
+pcl::io::OctreePointCloudCodecV2<PointXYZRGB> (codec.h:108-227): same constructor argument
+order and meaning, encodePointCloud / decodePointCloud / getPerformanceMetrics /
+getOutputCloud, so the parity tests read like calls into the reference.  Everything it
+does goes through the C ABI; there is no Python or CPU implementation of the hot path
+here, and constructing it without a usable GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcc_hip.so")
+
+POINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("rgba", "<u4"), ("pad", "<u4", (3,))]
+)
+
+PCC_OK = 0
+ERR_NAMES = {-1: "PCC_ERR_ARG", -2: "PCC_ERR_HIP", -3: "PCC_ERR_EMPTY", -4: "PCC_ERR_UNSUPPORTED",
+             -5: "PCC_ERR_STREAM", -6: "PCC_ERR_STATE"}
+
+# every symbol include/pcc_codec.h declares
+EXPORTS = [
+    "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
+    "pcc_encode_intra", "pcc_encode_intra_device", "pcc_hotpath_launch", "pcc_hotpath_finish",
+    "pcc_entropy_encode", "pcc_get_output_cloud", "pcc_decode_intra",
+    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_set_profiling",
+    "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
+    "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
+]
+
+
+class PccError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, "%s: %s" % (ERR_NAMES.get(code, str(code)), text))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("octree_resolution", C.c_double), ("point_resolution", C.c_double),
+        ("do_color_encoding", C.c_int32), ("color_bit_resolution", C.c_int32),
+        ("color_coding_type", C.c_int32), ("do_voxel_centroid", C.c_int32),
+        ("create_scalable", C.c_int32), ("do_connectivity", C.c_int32),
+        ("jpeg_quality", C.c_int32), ("macroblock_size", C.c_int32),
+        ("do_icp_color_offset", C.c_int32), ("frame_id", C.c_uint32),
+    ]
+
+
+class HotResult(C.Structure):
+    _fields_ = [
+        ("bbox", C.c_double * 6), ("depth", C.c_uint32), ("n_epochs", C.c_uint32),
+        ("n_points_in", C.c_uint64), ("n_leaves", C.c_uint64), ("n_branches", C.c_uint64),
+        ("occupancy", C.c_void_p), ("bgr", C.c_void_p), ("centroid", C.c_void_p), ("image", C.c_void_p),
+        ("image_w", C.c_uint32), ("image_h", C.c_uint32), ("gpu_ms", C.c_float),
+    ]
+
+
+class Bitstream(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("perf", C.c_uint64 * 3)]
+
+
+class Cloud(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("n", C.c_size_t), ("params", Params), ("bbox", C.c_double * 6),
+                ("depth", C.c_uint32), ("consumed", C.c_size_t)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("count", C.c_int32), ("name", C.c_char_p * 64), ("ms", C.c_float * 64)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libpcc_hip.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libpcc_hip.so is missing: run `python __graft_entry__.py` (build()) first")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    lib.pcc_create.restype = vp
+    lib.pcc_create.argtypes = [i32]
+    lib.pcc_create_host.restype = vp
+    lib.pcc_create_host.argtypes = []
+    lib.pcc_destroy.argtypes = [vp]
+    lib.pcc_destroy.restype = None
+    lib.pcc_last_error.restype = C.c_char_p
+    lib.pcc_last_error.argtypes = [vp]
+    lib.pcc_version.restype = C.c_char_p
+    lib.pcc_encode_intra.argtypes = [vp, vp, sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_encode_intra_device.argtypes = [vp, vp, sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_hotpath_launch.argtypes = [vp, vp, sz, sz, sz, C.POINTER(Params)]
+    lib.pcc_hotpath_finish.argtypes = [vp, C.POINTER(HotResult)]
+    lib.pcc_entropy_encode.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_get_output_cloud.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    lib.pcc_decode_intra.argtypes = [vp, vp, sz, C.POINTER(Cloud)]
+    lib.pcc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.pcc_device_free.argtypes = [vp, vp]
+    lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
+    lib.pcc_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+    lib.pcc_set_profiling.argtypes = [vp, i32]
+    lib.pcc_host_range_encode.restype = sz
+    lib.pcc_host_range_encode.argtypes = [vp, sz, vp, sz]
+    lib.pcc_host_range_decode.restype = sz
+    lib.pcc_host_range_decode.argtypes = [vp, sz, vp, sz]
+    lib.pcc_host_jpeg_encode.restype = sz
+    lib.pcc_host_jpeg_encode.argtypes = [vp, i32, i32, i32, vp, sz]
+    lib.pcc_host_jpeg_decode.argtypes = [vp, sz, vp, sz, C.POINTER(i32), C.POINTER(i32)]
+    lib.pcc_host_snake_position.restype = C.c_uint32
+    lib.pcc_host_snake_position.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.pcc_normalize_group.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.c_double, vp, vp]
+    lib.pcc_restore_scaling.argtypes = [vp, sz, vp, vp]
+    _lib = lib
+    return lib
+
+
+def make_params(octree_bits=10, enh_bits=0, color_bits=8, color_coding_type=1, keep_centroid=0, jpeg_quality=85,
+                frame_id=1, octree_resolution=None, point_resolution=None, create_scalable=0, macroblock_size=16,
+                do_icp_color_offset=0):
+    """The app's parameterisation of the codec (eval.hpp:377-395)."""
+    p = Params()
+    p.octree_resolution = octree_resolution if octree_resolution is not None else 2.0 ** (-octree_bits)
+    p.point_resolution = point_resolution if point_resolution is not None else 2.0 ** (-(octree_bits + enh_bits))
+    p.do_color_encoding = 1 if color_bits > 0 else 0
+    p.color_bit_resolution = color_bits
+    p.color_coding_type = color_coding_type
+    p.do_voxel_centroid = keep_centroid
+    p.create_scalable = create_scalable
+    p.do_connectivity = 0
+    p.jpeg_quality = jpeg_quality
+    p.macroblock_size = macroblock_size
+    p.do_icp_color_offset = do_icp_color_offset
+    p.frame_id = frame_id
+    return p
+
+
+def _bytes_at(ptr, n):
+    return C.string_at(ptr, n) if (ptr and n) else b""
+
+
+class HotProducts:
+    """Host copies of what the GPU stage produced for one frame."""
+
+    def __init__(self, hr: HotResult, copy=True):
+        self.raw = hr
+        self.bbox = np.array(list(hr.bbox), dtype=np.float64)
+        self.depth = int(hr.depth)
+        self.n_epochs = int(hr.n_epochs)
+        self.n_points_in = int(hr.n_points_in)
+        self.n_leaves = int(hr.n_leaves)
+        self.n_branches = int(hr.n_branches)
+        self.image_w, self.image_h = int(hr.image_w), int(hr.image_h)
+        self.gpu_ms = float(hr.gpu_ms)
+        if copy:
+            L, B = self.n_leaves, self.n_branches
+            self.occupancy = np.frombuffer(_bytes_at(hr.occupancy, B), dtype=np.uint8)
+            self.bgr = np.frombuffer(_bytes_at(hr.bgr, 3 * L), dtype=np.uint8)
+            self.centroid_bytes = np.frombuffer(_bytes_at(hr.centroid, 3 * L), dtype=np.uint8)
+            self.snake_image = np.frombuffer(_bytes_at(hr.image, 3 * self.image_w * self.image_h), dtype=np.uint8)
+
+
+class Context:
+    """One pcc_ctx: one GPU, one stream.  `device=None` makes a host-only context."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = self.lib.pcc_create_host() if device is None else self.lib.pcc_create(device)
+        if not self.h:
+            raise RuntimeError("pcc_create(%r) failed: no usable MI355X/HIP device -- the hot path has no CPU "
+                               "fallback" % (device,))
+        self._dev_allocs = []
+
+    def close(self):
+        if self.h:
+            for p in self._dev_allocs:
+                self.lib.pcc_device_free(self.h, p)
+            self._dev_allocs = []
+            self.lib.pcc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != PCC_OK:
+            raise PccError(rc, self.lib.pcc_last_error(self.h).decode())
+
+    # ---- device memory ----
+    def upload(self, points: np.ndarray):
+        points = np.ascontiguousarray(points)
+        p = C.c_void_p()
+        self._check(self.lib.pcc_device_alloc(self.h, max(points.nbytes, 16), C.byref(p)))
+        self._dev_allocs.append(p)
+        if points.nbytes:
+            self._check(self.lib.pcc_device_upload(self.h, p, points.ctypes.data, points.nbytes))
+        return p
+
+    def free(self, dev_ptr):
+        self._dev_allocs = [p for p in self._dev_allocs if p.value != dev_ptr.value]
+        self._check(self.lib.pcc_device_free(self.h, dev_ptr))
+
+    # ---- stages ----
+    def hotpath_launch(self, dev_ptr, n, params, stride=32, rgb_offset=16):
+        self._check(self.lib.pcc_hotpath_launch(self.h, dev_ptr, n, stride, rgb_offset, C.byref(params)))
+
+    def hotpath_finish(self, copy=True):
+        hr = HotResult()
+        self._check(self.lib.pcc_hotpath_finish(self.h, C.byref(hr)))
+        return HotProducts(hr, copy=copy)
+
+    def entropy_encode(self, hot: HotResult, params, copy=True):
+        bs = Bitstream()
+        self._check(self.lib.pcc_entropy_encode(self.h, C.byref(hot), C.byref(params), C.byref(bs)))
+        return (_bytes_at(bs.data, bs.len) if copy else bs.len), [int(x) for x in bs.perf]
+
+    def encode_intra_host(self, points: np.ndarray, params, stride=32, rgb_offset=16):
+        points = np.ascontiguousarray(points)
+        bs = Bitstream()
+        self._check(self.lib.pcc_encode_intra(self.h, points.ctypes.data, len(points), stride, rgb_offset,
+                                              C.byref(params), C.byref(bs)))
+        return _bytes_at(bs.data, bs.len), [int(x) for x in bs.perf]
+
+    def encode_intra_device(self, dev_ptr, n, params, stride=32, rgb_offset=16, copy=True):
+        bs = Bitstream()
+        self._check(self.lib.pcc_encode_intra_device(self.h, dev_ptr, n, stride, rgb_offset, C.byref(params),
+                                                     C.byref(bs)))
+        return (_bytes_at(bs.data, bs.len) if copy else bs.len), [int(x) for x in bs.perf]
+
+    def output_cloud(self):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._check(self.lib.pcc_get_output_cloud(self.h, C.byref(p), C.byref(n)))
+        return np.frombuffer(_bytes_at(p, 32 * n.value), dtype=POINT_DTYPE).copy()
+
+    def decode_intra(self, stream: bytes):
+        src = np.frombuffer(stream, dtype=np.uint8)
+        c = Cloud()
+        self._check(self.lib.pcc_decode_intra(self.h, src.ctypes.data, len(src), C.byref(c)))
+        pts = np.frombuffer(_bytes_at(c.points, 32 * c.n), dtype=POINT_DTYPE).copy()
+        info = dict(bbox=np.array(list(c.bbox)), depth=int(c.depth), consumed=int(c.consumed),
+                    params={k: getattr(c.params, k) for k, _ in Params._fields_})
+        return pts, info
+
+    def set_profiling(self, on):
+        self._check(self.lib.pcc_set_profiling(self.h, 1 if on else 0))
+
+    def kernel_times(self):
+        kt = KernelTimes()
+        self._check(self.lib.pcc_get_kernel_times(self.h, C.byref(kt)))
+        return [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
+
+
+MANUAL_CONFIGURATION = "MANUAL_CONFIGURATION"
+
+
+class OctreePointCloudCodecV2:
+    """Mirror of pcl::io::OctreePointCloudCodecV2<PointXYZRGB> (codec.h:70-368) over the C ABI.
+
+    Constructor arguments are those of codec.h:108-121 in the same order.  Clouds are numpy arrays
+    of POINT_DTYPE (the 32-byte pcl::PointXYZRGB layout); streams are bytes.
+    """
+
+    def __init__(self, compressionProfile_arg=MANUAL_CONFIGURATION, showStatistics_arg=False,
+                 pointResolution_arg=0.001, octreeResolution_arg=0.01, doVoxelGridDownDownSampling_arg=False,
+                 iFrameRate_arg=0, doColorEncoding_arg=True, colorBitResolution_arg=6, colorCodingType_arg=0,
+                 doVoxelGridCentroid_arg=True, createScalableStream_arg=True, codeConnectivity_arg=False,
+                 jpeg_quality_arg=75, num_threads=0, device=0):
+        if compressionProfile_arg != MANUAL_CONFIGURATION:
+            raise NotImplementedError("only MANUAL_CONFIGURATION is used by the reference app (eval.hpp:379)")
+        if not doVoxelGridDownDownSampling_arg:
+            raise NotImplementedError("the reference app always enables voxel-grid coding (eval.hpp:385)")
+        if iFrameRate_arg != 0:
+            raise NotImplementedError("iFrameRate is 0 in the reference: every frame is an I-frame (eval.hpp:386)")
+        self._p = Params()
+        self._p.octree_resolution = octreeResolution_arg
+        self._p.point_resolution = pointResolution_arg
+        self._p.do_color_encoding = 1 if doColorEncoding_arg else 0
+        self._p.color_bit_resolution = colorBitResolution_arg
+        self._p.color_coding_type = colorCodingType_arg
+        self._p.do_voxel_centroid = 1 if doVoxelGridCentroid_arg else 0
+        self._p.create_scalable = 1 if createScalableStream_arg else 0
+        self._p.do_connectivity = 1 if codeConnectivity_arg else 0
+        self._p.jpeg_quality = jpeg_quality_arg
+        self._p.macroblock_size = 16          # codec.h:138
+        self._p.do_icp_color_offset = 0       # codec.h:141
+        self._frame_id = 0
+        self._perf = [0, 0, 0]
+        self._ctx = Context(device)
+        self.last_hot = None
+
+    def setMacroblockSize(self, size):       # codec.h:149
+        self._p.macroblock_size = size
+
+    def setDoICPColorOffset(self, doit):     # codec.h:164
+        self._p.do_icp_color_offset = 1 if doit else 0
+
+    def encodePointCloud(self, cloud_arg: np.ndarray) -> bytes:
+        """codec.h:174-175.  Returns the bytes the reference would append to the ostream;
+        an empty cloud yields b'' (frame dropped, impl.hpp:206-212)."""
+        self._p.frame_id = self._frame_id + 1
+        try:
+            stream, perf = self._ctx.encode_intra_host(cloud_arg, self._p)
+        except PccError as e:
+            if e.code == -3:
+                return b""
+            raise
+        self._frame_id += 1       # frame_ID_++ only happens for non-empty clouds (impl.hpp:133)
+        self._perf = perf
+        return stream
+
+    def decodePointCloud(self, compressed_tree_data_in_arg: bytes):
+        """codec.h:177-178.  Returns (cloud, bytes consumed)."""
+        pts, info = self._ctx.decode_intra(compressed_tree_data_in_arg)
+        return pts, info["consumed"]
+
+    def getPerformanceMetrics(self):          # codec.h:193-197
+        return list(self._perf)
+
+    def getOutputCloud(self):                 # used at eval.hpp:862
+        return self._ctx.output_cloud()
+
+
+# ---- host building blocks (no GPU needed) ----
+
+def host_range_encode(data: bytes) -> bytes:
+    lib = load_library()
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.zeros(len(src) * 2 + 2048, dtype=np.uint8)
+    n = lib.pcc_host_range_encode(src.ctypes.data if len(src) else None, len(src), out.ctypes.data, len(out))
+    return out[:n].tobytes()
+
+
+def host_range_decode(stream: bytes, n: int):
+    lib = load_library()
+    src = np.frombuffer(stream, dtype=np.uint8)
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    used = lib.pcc_host_range_decode(src.ctypes.data, len(src), out.ctypes.data, n)
+    return out[:n].tobytes(), used
+
+
+def host_jpeg_encode(rgb: np.ndarray, quality: int) -> bytes:
+    lib = load_library()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = np.zeros(rgb.size * 2 + 4096, dtype=np.uint8)
+    n = lib.pcc_host_jpeg_encode(rgb.ctypes.data, w, h, quality, out.ctypes.data, len(out))
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def host_jpeg_decode(jpg: bytes, max_pixels=1 << 24) -> np.ndarray:
+    lib = load_library()
+    src = np.frombuffer(jpg, dtype=np.uint8)
+    out = np.zeros(3 * max_pixels, dtype=np.uint8)
+    w, h = C.c_int(), C.c_int()
+    rc = lib.pcc_host_jpeg_decode(src.ctypes.data, len(src), out.ctypes.data, len(out), C.byref(w), C.byref(h))
+    if rc != PCC_OK:
+        raise PccError(rc, "jpeg decode")
+    return out[: 3 * w.value * h.value].reshape(h.value, w.value, 3).copy()
+
+
+def host_snake_perm(w, h):
+    lib = load_library()
+    return np.array([lib.pcc_host_snake_position(i, w, h) for i in range(w * h)], dtype=np.int32)

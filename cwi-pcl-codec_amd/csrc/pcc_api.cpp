@@ -1,0 +1,485 @@
+// pcc_api.cpp -- the C ABI declared in include/pcc_codec.h: context, HBM arena, launch of the
+// HIP hot path, device->host hand-over and the host entropy stage.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pcc_codec.h"
+#include "pcc_device.h"
+#include "pcc_host_codec.h"
+#include "pcc_kernels.h"
+
+using namespace pcc;
+
+namespace {
+
+template <typename T>
+struct DevBuf {  // grow-only device allocation
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) cap = count;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinnedBuf {  // grow-only page-locked host allocation (D2H landing zone)
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max(count, (size_t)4096);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct pcc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  std::string err;
+  bool profiling = false;
+  KernelTimer timer;
+  std::vector<std::pair<const char*, float>> times;
+
+  // HBM arena (see pcc_device.h for the layout)
+  DevBuf<uint8_t> d_points;  // only for the host-input entry point
+  DevBuf<ChunkBox> d_boxes;
+  DevBuf<FrameState> d_state;
+  DevBuf<uint64_t> d_keys_a, d_keys_b, d_partials, d_leaf_code;
+  DevBuf<uint32_t> d_ghist, d_gtot, d_leaf_start, d_leaf_base;
+  DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image;
+  DevBuf<float> d_simplified;  // 4 floats per leaf
+
+  // host landing buffers
+  PinnedBuf<FrameState> h_state;
+  PinnedBuf<uint8_t> h_occ, h_bgr, h_centroid, h_image;
+  PinnedBuf<float> h_simplified;
+  std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
+  std::vector<pcc_point_xyzrgb> dec_points;  // decodePointCloud()
+  Bytes bitstream;
+
+  // frame in flight
+  bool launched = false;
+  size_t n = 0;
+  pcc_params params{};
+  bool simplified_valid = false;
+  size_t last_L = 0;
+  pcc_hot_result last_hot{};
+};
+
+namespace {
+
+int fail(pcc_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+int hip_fail(pcc_ctx* c, hipError_t e, const char* what) {
+  return fail(c, PCC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define PCC_HIP(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+  } while (0)
+
+#define PCC_NEED_GPU()                                                                              \
+  do {                                                                                             \
+    if (ctx->device < 0) return fail(ctx, PCC_ERR_STATE, "host-only context: the hot path needs a GPU"); \
+  } while (0)
+
+int reserve(pcc_ctx* ctx, size_t n) {
+  const size_t tiles = (n + kTile - 1) / kTile;
+  PCC_HIP(ctx->d_boxes.ensure(tiles));
+  PCC_HIP(ctx->d_state.ensure(1));
+  PCC_HIP(ctx->d_keys_a.ensure(n));
+  PCC_HIP(ctx->d_keys_b.ensure(n));
+  PCC_HIP(ctx->d_partials.ensure(tiles));
+  PCC_HIP(ctx->d_ghist.ensure(tiles * kRadixSize));
+  PCC_HIP(ctx->d_gtot.ensure(kRadixSize));
+  PCC_HIP(ctx->d_leaf_start.ensure(n + 1));
+  PCC_HIP(ctx->d_leaf_code.ensure(n));
+  PCC_HIP(ctx->d_leaf_base.ensure(n));
+  PCC_HIP(ctx->d_leaf_t.ensure(n));
+  PCC_HIP(ctx->d_occ.ensure(n * (size_t)kMaxDepth + 64));  // worst case B = L * D
+  PCC_HIP(ctx->d_bgr.ensure(3 * n + 16));
+  PCC_HIP(ctx->d_centroid.ensure(3 * n + 16));
+  PCC_HIP(ctx->d_image.ensure(3 * 256 * (n / 256 + 1) + 16));
+  PCC_HIP(ctx->d_simplified.ensure(4 * n));
+  PCC_HIP(ctx->h_state.ensure(1));
+  return PCC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pcc_version(void) { return "pcc_hip 0.1 (gfx950)"; }
+
+pcc_ctx* pcc_create(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  pcc_ctx* c = new pcc_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+pcc_ctx* pcc_create_host(void) {
+  pcc_ctx* c = new pcc_ctx();
+  c->device = -1;
+  return c;
+}
+
+void pcc_destroy(pcc_ctx* c) {
+  if (!c) return;
+  if (c->device < 0) {
+    delete c;
+    return;
+  }
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release();
+  c->d_partials.release(); c->d_leaf_code.release(); c->d_ghist.release(); c->d_gtot.release();
+  c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
+  c->d_centroid.release(); c->d_image.release(); c->d_simplified.release();
+  c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
+  c->h_simplified.release();
+  if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+  if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* pcc_last_error(pcc_ctx* c) { return c ? c->err.c_str() : "no context (no usable HIP device?)"; }
+
+int pcc_set_profiling(pcc_ctx* ctx, int enabled) {
+  if (!ctx) return PCC_ERR_ARG;
+  ctx->profiling = enabled != 0;
+  return PCC_OK;
+}
+
+int pcc_get_kernel_times(pcc_ctx* ctx, pcc_kernel_times* out) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  out->count = (int32_t)std::min(ctx->times.size(), (size_t)PCC_MAX_KERNEL_TIMES);
+  for (int i = 0; i < out->count; ++i) {
+    out->name[i] = ctx->times[i].first;
+    out->ms[i] = ctx->times[i].second;
+  }
+  return PCC_OK;
+}
+
+int pcc_device_alloc(pcc_ctx* ctx, size_t bytes, void** dev_ptr) {
+  if (!ctx || !dev_ptr) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  PCC_HIP(hipSetDevice(ctx->device));
+  PCC_HIP(hipMalloc(dev_ptr, bytes ? bytes : 16));
+  return PCC_OK;
+}
+int pcc_device_free(pcc_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  PCC_HIP(hipSetDevice(ctx->device));
+  PCC_HIP(hipFree(dev_ptr));
+  return PCC_OK;
+}
+int pcc_device_upload(pcc_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+  if (!ctx || !dev_dst || (!host_src && bytes)) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  PCC_HIP(hipSetDevice(ctx->device));
+  PCC_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+  return PCC_OK;
+}
+
+int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset,
+                       const pcc_params* prm) {
+  if (!ctx || !prm) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  if (n && !dev_points) return fail(ctx, PCC_ERR_ARG, "null point array");
+  if (stride < 12 || (stride & 3) || rgb_offset + 4 > stride || (rgb_offset & 3))
+    return fail(ctx, PCC_ERR_ARG, "stride/rgb_offset: need stride >= 12, 4-byte aligned fields");
+  if (n >= (1ull << 31)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^31 points");
+  if (!(prm->octree_resolution > 0.0) || !std::isfinite(prm->octree_resolution))
+    return fail(ctx, PCC_ERR_ARG, "octree_resolution must be positive");
+  PCC_HIP(hipSetDevice(ctx->device));
+  ctx->launched = false;
+  ctx->simplified_valid = false;
+  ctx->n = n;
+  ctx->params = *prm;
+  if (n == 0) {  // empty cloud: nothing to launch; finish() reports PCC_ERR_EMPTY
+    ctx->launched = true;
+    return PCC_OK;
+  }
+  int rc = reserve(ctx, n);
+  if (rc != PCC_OK) return rc;
+
+  HotPathArgs a{};
+  a.pv.base = static_cast<const uint8_t*>(dev_points);
+  a.pv.stride = (uint32_t)stride;
+  a.pv.rgb_off = (uint32_t)rgb_offset;
+  a.pv.aligned16 = ((reinterpret_cast<uintptr_t>(dev_points) & 15) == 0 && (stride & 15) == 0 && stride >= 16) ? 1u : 0u;
+  a.n = (uint32_t)n;
+  a.res = prm->octree_resolution;
+  a.lp.do_color = prm->do_color_encoding ? 1u : 0u;
+  a.lp.color_reduction = (prm->color_coding_type == 0) ? (uint32_t)((8 - prm->color_bit_resolution) & 7) : 0u;
+  if (prm->color_coding_type == 0 && prm->color_bit_resolution <= 0) a.lp.color_reduction = 8;
+  a.lp.do_centroid = prm->do_voxel_centroid ? 1u : 0u;
+  a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
+  a.max_passes = 8;  // 64 key bits / 8; the device skips the passes it does not need
+  a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
+  a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
+  a.ghist = ctx->d_ghist.p; a.gtot = ctx->d_gtot.p; a.partials = ctx->d_partials.p;
+  a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
+  a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
+  a.image = ctx->d_image.p; a.simplified = ctx->d_simplified.p;
+  // the key width is bounded by what the host knows: index bits from n, at most 63 code bits
+  {
+    int ibits = 0;
+    while ((n >> ibits) != 0) ++ibits;
+    a.max_passes = std::max(1, (64 - ibits + kRadixBits - 1) / kRadixBits);
+  }
+
+  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+  if (ctx->profiling) ctx->timer.reset();
+  launch_hot_path(a, ctx->stream, ctx->profiling ? &ctx->timer : nullptr);
+  PCC_HIP(hipGetLastError());
+  PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->h_state.p, ctx->d_state.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->launched = true;
+  return PCC_OK;
+}
+
+int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  if (!ctx->launched) return fail(ctx, PCC_ERR_STATE, "pcc_hotpath_finish without pcc_hotpath_launch");
+  ctx->launched = false;
+  memset(out, 0, sizeof(*out));
+  if (ctx->n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
+  PCC_HIP(hipSetDevice(ctx->device));
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  const FrameState& st = *ctx->h_state.p;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end);
+  out->gpu_ms = ms;
+  if (ctx->profiling) ctx->timer.collect(ctx->times);
+  if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
+  if (st.error != kErrNone) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d, key bits %d+%d+%d)", st.error,
+             st.depth, st.vbits, st.flagbit, st.ibits);
+    return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
+  }
+  const size_t L = st.n_leaves, B = st.n_branches;
+  const pcc_params& prm = ctx->params;
+  const bool color = prm.do_color_encoding != 0;
+  const bool image = color && prm.color_coding_type == 1;
+  const uint32_t W = 256, H = (uint32_t)(L / 256 + 1);
+
+  PCC_HIP(ctx->h_occ.ensure(B + 16));
+  PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, B, hipMemcpyDeviceToHost, ctx->stream));
+  if (color) {
+    PCC_HIP(ctx->h_bgr.ensure(3 * L + 16));
+    PCC_HIP(hipMemcpyAsync(ctx->h_bgr.p, ctx->d_bgr.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (image) {
+    PCC_HIP(ctx->h_image.ensure((size_t)3 * W * H + 16));
+    PCC_HIP(hipMemcpyAsync(ctx->h_image.p, ctx->d_image.p, (size_t)3 * W * H, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (prm.do_voxel_centroid) {
+    PCC_HIP(ctx->h_centroid.ensure(3 * L + 16));
+    PCC_HIP(hipMemcpyAsync(ctx->h_centroid.p, ctx->d_centroid.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+
+  for (int a = 0; a < 3; ++a) { out->bbox[a] = st.mn[a]; out->bbox[3 + a] = st.mx[a]; }
+  out->depth = (uint32_t)st.depth;
+  out->n_epochs = (uint32_t)st.n_epochs;
+  out->n_points_in = st.n_finite;
+  out->n_leaves = L;
+  out->n_branches = B;
+  out->occupancy = ctx->h_occ.p;
+  out->bgr = color ? ctx->h_bgr.p : nullptr;
+  out->centroid = prm.do_voxel_centroid ? ctx->h_centroid.p : nullptr;
+  out->image = image ? ctx->h_image.p : nullptr;
+  out->image_w = image ? W : 0;
+  out->image_h = image ? H : 0;
+  ctx->last_L = L;
+  ctx->simplified_valid = true;
+  ctx->last_hot = *out;
+  return PCC_OK;
+}
+
+int pcc_entropy_encode(pcc_ctx* ctx, const pcc_hot_result* hot, const pcc_params* prm, pcc_bitstream* out) {
+  if (!ctx || !hot || !prm || !out) return PCC_ERR_ARG;
+  entropy_encode_frame(*hot, *prm, ctx->bitstream, out->perf);
+  out->data = ctx->bitstream.data();
+  out->len = ctx->bitstream.size();
+  return PCC_OK;
+}
+
+int pcc_encode_intra_device(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset,
+                            const pcc_params* prm, pcc_bitstream* out) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  int rc = pcc_hotpath_launch(ctx, dev_points, n, stride, rgb_offset, prm);
+  if (rc != PCC_OK) return rc;
+  pcc_hot_result hot;
+  rc = pcc_hotpath_finish(ctx, &hot);
+  if (rc != PCC_OK) return rc;
+  return pcc_entropy_encode(ctx, &hot, prm, out);
+}
+
+int pcc_encode_intra(pcc_ctx* ctx, const void* host_points, size_t n, size_t stride, size_t rgb_offset,
+                     const pcc_params* prm, pcc_bitstream* out) {
+  if (!ctx || !out || !prm) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  memset(out, 0, sizeof(*out));
+  if (n && !host_points) return fail(ctx, PCC_ERR_ARG, "null point array");
+  if (n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
+  PCC_HIP(hipSetDevice(ctx->device));
+  PCC_HIP(ctx->d_points.ensure(n * stride + 16));
+  PCC_HIP(hipMemcpyAsync(ctx->d_points.p, host_points, n * stride, hipMemcpyHostToDevice, ctx->stream));
+  return pcc_encode_intra_device(ctx, ctx->d_points.p, n, stride, rgb_offset, prm, out);
+}
+
+int pcc_get_output_cloud(pcc_ctx* ctx, const pcc_point_xyzrgb** points, size_t* n) {
+  if (!ctx || !points || !n) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  if (!ctx->simplified_valid) return fail(ctx, PCC_ERR_STATE, "no encoded frame to take the simplified cloud from");
+  PCC_HIP(hipSetDevice(ctx->device));
+  const size_t L = ctx->last_L;
+  PCC_HIP(ctx->h_simplified.ensure(4 * L + 4));
+  PCC_HIP(hipMemcpyAsync(ctx->h_simplified.p, ctx->d_simplified.p, 16 * L, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->out_cloud.resize(L);
+  const bool color = ctx->params.do_color_encoding != 0;
+  for (size_t i = 0; i < L; ++i) {  // a default-constructed PointXYZRGB with x,y,z,r,g,b overwritten (impl.hpp:1515,1554-1576)
+    pcc_point_xyzrgb& p = ctx->out_cloud[i];
+    const float* s = ctx->h_simplified.p + 4 * i;
+    p.x = s[0]; p.y = s[1]; p.z = s[2]; p.w = 1.0f;
+    uint32_t rgba;
+    memcpy(&rgba, s + 3, 4);
+    p.rgba = color ? rgba : 0xFF000000u;
+    p.pad[0] = p.pad[1] = p.pad[2] = 0;
+  }
+  *points = ctx->out_cloud.data();
+  *n = L;
+  return PCC_OK;
+}
+
+int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud* out) {
+  if (!ctx || !out || (!stream && len)) return PCC_ERR_ARG;
+  const int rc = decode_frame(stream, len, ctx->dec_points, *out);
+  out->points = ctx->dec_points.data();
+  out->n = ctx->dec_points.size();
+  if (rc != PCC_OK) return fail(ctx, rc, "decode: frame header not found, or stream truncated/corrupt");
+  return PCC_OK;
+}
+
+size_t pcc_host_range_encode(const uint8_t* in, size_t n, uint8_t* out, size_t out_cap) {
+  Bytes b;
+  StaticRangeCoder::encode(in, n, b);
+  if (b.size() > out_cap) return 0;
+  memcpy(out, b.data(), b.size());
+  return b.size();
+}
+size_t pcc_host_range_decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n) {
+  return StaticRangeCoder::decode(in, in_len, out, n);
+}
+size_t pcc_host_jpeg_encode(const uint8_t* rgb, int w, int h, int quality, uint8_t* out, size_t out_cap) {
+  if (!rgb || w <= 0 || h <= 0) return 0;
+  Bytes b;
+  BaselineJpeg::encode_rgb(rgb, w, h, quality, b);
+  if (b.size() > out_cap) return 0;
+  memcpy(out, b.data(), b.size());
+  return b.size();
+}
+int pcc_host_jpeg_decode(const uint8_t* jpg, size_t len, uint8_t* rgb, size_t rgb_cap, int* w, int* h) {
+  Bytes b;
+  if (!w || !h || !BaselineJpeg::decode_rgb(jpg, len, b, *w, *h)) return PCC_ERR_STREAM;
+  if (b.size() > rgb_cap) return PCC_ERR_ARG;
+  memcpy(rgb, b.data(), b.size());
+  return PCC_OK;
+}
+uint32_t pcc_host_snake_position(uint32_t i, uint32_t w, uint32_t h) { return snake_position(i, w, h); }
+
+int pcc_normalize_group(pcc_point_xyzrgb** clouds, const size_t* sizes, size_t n_clouds, double f, float bb_min[3],
+                        float bb_max[3]) {
+  // normalize_pointclouds (impl.hpp:1871-1967): a running box that is re-initialised from a
+  // frame's own extent whenever that frame does not fit strictly inside it
+  if (!clouds || !sizes || !bb_min || !bb_max) return PCC_ERR_ARG;
+  float mnb[3] = {1000.f, 1000.f, 1000.f}, mxb[3] = {-1000.f, -1000.f, -1000.f};
+  bool init = false;
+  for (size_t k = 0; k < n_clouds; ++k) {
+    pcc_point_xyzrgb* c = clouds[k];
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (size_t i = 0; i < sizes[k]; ++i) {  // pcl::getMinMax3D skips non-finite points
+      const float q[3] = {c[i].x, c[i].y, c[i].z};
+      if (!std::isfinite(q[0]) || !std::isfinite(q[1]) || !std::isfinite(q[2])) continue;
+      for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], q[a]); mx[a] = std::max(mx[a], q[a]); }
+    }
+    if (!(mn[0] > mnb[0] && mn[1] > mnb[1] && mn[2] > mnb[2])) init = false;
+    if (!(mx[0] < mxb[0] && mx[1] < mxb[1] && mx[2] < mxb[2])) init = false;
+    if (!init) {
+      for (int a = 0; a < 3; ++a) {
+        mnb[a] = (float)((double)mn[a] - f * (double)fabsf(mx[a] - mn[a]));
+        mxb[a] = (float)((double)mx[a] + f * (double)fabsf(mx[a] - mn[a]));
+      }
+      init = true;
+    }
+    const float dyn[3] = {mxb[0] - mnb[0], mxb[1] - mnb[1], mxb[2] - mnb[2]};
+    for (size_t i = 0; i < sizes[k]; ++i) {
+      c[i].x -= mnb[0]; c[i].y -= mnb[1]; c[i].z -= mnb[2];
+      c[i].x /= dyn[0]; c[i].y /= dyn[1]; c[i].z /= dyn[2];
+    }
+  }
+  for (int a = 0; a < 3; ++a) { bb_min[a] = mnb[a]; bb_max[a] = mxb[a]; }
+  return PCC_OK;
+}
+
+int pcc_restore_scaling(pcc_point_xyzrgb* cloud, size_t n, const float bb_min[3], const float bb_max[3]) {
+  if ((!cloud && n) || !bb_min || !bb_max) return PCC_ERR_ARG;
+  const float dyn[3] = {bb_max[0] - bb_min[0], bb_max[1] - bb_min[1], bb_max[2] - bb_min[2]};
+  for (size_t i = 0; i < n; ++i) {  // impl.hpp:1969-1986: multiply, then add
+    cloud[i].x *= dyn[0]; cloud[i].y *= dyn[1]; cloud[i].z *= dyn[2];
+    cloud[i].x += bb_min[0]; cloud[i].y += bb_min[1]; cloud[i].z += bb_min[2];
+  }
+  return PCC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// pcc_device.h -- data layout shared by the HIP kernels and the host-side launcher.
+//
+// HBM layout of one frame in flight (all arrays allocated once per context for the
+// largest N seen; 288 GB of HBM3E makes worst-case sizing cheap and removes every
+// size-dependent host<->device round trip from the middle of the pipeline):
+//
+//   points      N x stride B   caller's pcl::PointXYZRGB array (x,y,z at 0, colour word at rgb_off)
+//   chunk_box   ceil(N/2048) x 32 B   per-chunk AABB + first finite index + finite count
+//   state       1 x FrameState  epochs of the adaptive bounding box, sort geometry, L, B
+//   keys[2]     N x u64         packed (flag | morton | index) sort keys, ping-pong
+//   radix_hist  256 x ceil(N/2048) x u32   per-tile digit counts / row prefixes
+//   tile_part   ceil(N/2048) x u64         (sum t << 32 | sum head) partials of the leaf scan
+//   leaf_start  (N+1) x u32     first sorted position of each leaf
+//   leaf_code   N x u64         morton code of each leaf (sorted, unique)
+//   leaf_base   N x u32         DFS byte offset of the first branch node a leaf opens
+//   leaf_t      N x u8          number of branch nodes a leaf opens
+//   occupancy   N x 21 B (+pad) DFS occupancy stream, worst case L*D
+//   bgr / centroid 3N B each, image 3*256*(N/256+1) B, simplified N x 16 B
+#pragma once
+#include <stdint.h>
+
+namespace pcc {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
+constexpr int kItems = 8;          // items per thread in tiled kernels
+constexpr int kTile = kBlock * kItems;  // 2048 items per tile / bbox chunk
+constexpr int kMaxEpochs = 40;     // depth <= 32 => at most 33 growth events (+ first point)
+constexpr int kMaxDepth = 21;      // 3*D morton bits must fit 63 bits
+constexpr int kRadixBits = 8;
+constexpr int kRadixSize = 1 << kRadixBits;
+
+struct ChunkBox {          // 32 bytes
+  float mn[3];
+  float mx[3];
+  int32_t first_finite;    // global index of the first finite point in the chunk, or -1
+  int32_t n_finite;
+};
+
+enum FrameError : int32_t {
+  kErrNone = 0,
+  kErrDepth = 1,           // depth > kMaxDepth
+  kErrKeyBits = 2,         // morton bits + flag + index bits > 64
+  kErrEpochs = 3,          // more than kMaxEpochs growth epochs
+};
+
+struct FrameState {
+  // ---- adaptive bounding box (P2) ----
+  double mn[3], mx[3];               // final box (header bytes)
+  int32_t depth;                     // final depth D
+  int32_t n_epochs;                  // 0 => no finite point
+  int32_t first_finite;
+  uint32_t n_finite;
+  int32_t ep_index[kMaxEpochs];      // epoch e holds for point indices in [ep_index[e], ep_index[e+1])
+  double ep_mn[kMaxEpochs][3];       // box origin in force during epoch e
+  uint32_t ep_shift[kMaxEpochs][3];  // key offset from the re-rootings that came after epoch e
+  int32_t n_growth_events;           // raw growth count (reporting)
+  // ---- sort geometry ----
+  int32_t vbits_axis;                // varying key bits per axis
+  int32_t vbits;                     // 3 * vbits_axis
+  int32_t ibits;                     // index bits in the packed key
+  int32_t flagbit;                   // 1 if non-finite points exist (extra sort bit above the code)
+  int32_t npasses;                   // radix passes actually needed
+  uint32_t prefix[3];                // constant high key bits per axis (in place)
+  // ---- leaves ----
+  uint32_t n_leaves;                 // L
+  uint32_t n_branches;               // B
+  int32_t error;                     // FrameError
+  int32_t pad_;
+};
+
+}  // namespace pcc

@@ -1,0 +1,946 @@
+// pcc_host_codec.cpp -- host stages: frame header, static range coder, baseline JPEG, decoder.
+//
+// These are the serial parts of the reference that the north star keeps on the CPU.  They are
+// written for throughput (one pass, table driven, no per-symbol allocation) but compute exactly
+// what the reference's libraries compute:
+//   range coder = pcl::StaticRangeCoder (PCL 1.10 entropy_range_coder.hpp; call sites impl.hpp:1694..1798)
+//   JPEG        = libjpeg-turbo as configured by jpeg_io.hpp:259-314 (encode) and :110-188 (decode)
+//   header      = impl.hpp:1472-1486 + the PCL base header it calls at :1477
+#include "pcc_host_codec.h"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace pcc {
+
+// =============================================================================================
+// static range coder
+// =============================================================================================
+namespace {
+constexpr uint64_t kTop = 1ull << 56;
+constexpr uint64_t kBottom = 1ull << 48;
+
+inline void cumulative_table(const uint8_t* in, size_t n, uint32_t freq[257]) {
+  // four interleaved histograms: avoids store-to-load stalls on runs of equal bytes
+  uint32_t h[4][256];
+  memset(h, 0, sizeof(h));
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    ++h[0][in[i]]; ++h[1][in[i + 1]]; ++h[2][in[i + 2]]; ++h[3][in[i + 3]];
+  }
+  for (; i < n; ++i) ++h[0][in[i]];
+  freq[0] = 0;
+  for (int s = 0; s < 256; ++s) {
+    const uint64_t c = (uint64_t)h[0][s] + h[1][s] + h[2][s] + h[3][s];
+    uint32_t v = freq[s] + (uint32_t)c;
+    if (v <= freq[s]) v = freq[s] + 1;  // forced strictly increasing: absent symbols get count 1
+    freq[s + 1] = v;
+  }
+  // PCL rescales while freq[256] >= 2^48; unreachable with a 32-bit table.
+}
+}  // namespace
+
+size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
+  uint32_t freq[257];
+  cumulative_table(in, n, freq);
+  const size_t start = out.size();
+  out.resize(start + sizeof(freq) + n + n / 2 + 64);  // worst case ~ n*log2(n+256)/8; grown below if needed
+  uint8_t* p = out.data() + start;
+  memcpy(p, freq, sizeof(freq));
+  size_t pos = sizeof(freq);
+  size_t cap = out.size() - start;
+
+  const uint64_t total = freq[256];
+  uint64_t low = 0, range = ~0ull;
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned ch = in[i];
+    range /= total;
+    low += (uint64_t)freq[ch] * range;
+    range *= (uint64_t)(freq[ch + 1] - freq[ch]);
+    if (pos + 16 > cap) {  // a symbol emits at most 8 bytes
+      out.resize(start + cap * 2);
+      p = out.data() + start;
+      cap = out.size() - start;
+    }
+    // emit while the top byte is settled, or the range underflowed (then it is clamped to the
+    // distance to the next 2^48 boundary: range = -low & (2^48 - 1))
+    for (;;) {
+      if ((low ^ (low + range)) >= kTop) {
+        if (range >= kBottom) break;
+        range = (0 - low) & (kBottom - 1);
+      }
+      p[pos++] = (uint8_t)(low >> 56);
+      range <<= 8;
+      low <<= 8;
+    }
+  }
+  for (int i = 0; i < 8; ++i) {
+    p[pos++] = (uint8_t)(low >> 56);
+    low <<= 8;
+  }
+  out.resize(start + pos);
+  return pos;
+}
+
+size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n) {
+  uint32_t freq[257];
+  if (in_len < sizeof(freq) + 8) return 0;
+  memcpy(freq, in, sizeof(freq));
+  size_t pos = sizeof(freq);
+  uint64_t code = 0, low = 0, range = ~0ull;
+  for (int i = 0; i < 8; ++i) code = (code << 8) | in[pos++];
+  const uint64_t total = freq[256];
+  if (total == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    range /= total;
+    if (range == 0) return 0;
+    const uint64_t count = (code - low) / range;
+    unsigned sym = 0;
+    for (unsigned step = 128; step; step >>= 1)
+      if ((uint64_t)freq[sym + step] <= count) sym += step;
+    out[i] = (uint8_t)sym;
+    low += (uint64_t)freq[sym] * range;
+    range *= (uint64_t)(freq[sym + 1] - freq[sym]);
+    for (;;) {
+      if ((low ^ (low + range)) >= kTop) {
+        if (range >= kBottom) break;
+        range = (0 - low) & (kBottom - 1);
+      }
+      const uint8_t b = pos < in_len ? in[pos] : 0;
+      ++pos;
+      code = (code << 8) | b;
+      range <<= 8;
+      low <<= 8;
+    }
+  }
+  return pos <= in_len ? pos : 0;
+}
+
+// =============================================================================================
+// baseline JPEG
+// =============================================================================================
+namespace {
+
+const uint8_t kLumaQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                            14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                            18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                            49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kChromaQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                              24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                             12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                             58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffSpec {
+  uint8_t bits[16];
+  const uint8_t* vals;
+  int nvals;
+};
+const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumaVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kAcChromaVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const HuffSpec kDcLuma = {{0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, kDcVals, 12};
+const HuffSpec kDcChroma = {{0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0}, kDcVals, 12};
+const HuffSpec kAcLuma = {{0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, kAcLumaVals, 162};
+const HuffSpec kAcChroma = {{0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}, kAcChromaVals, 162};
+
+struct HuffEnc {
+  uint32_t code[256];
+  uint8_t len[256];
+  explicit HuffEnc(const HuffSpec& s) {
+    memset(code, 0, sizeof(code));
+    memset(len, 0, sizeof(len));
+    uint32_t c = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; ++l) {
+      for (int i = 0; i < s.bits[l - 1]; ++i, ++k, ++c) {
+        code[s.vals[k]] = c;
+        len[s.vals[k]] = (uint8_t)l;
+      }
+      c <<= 1;
+    }
+  }
+};
+
+// quantiser: divide by 8*q with round-half-up on the magnitude, exactly as jcdctmgr.c; the
+// division is done with a 32-bit reciprocal that is exact for every 17-bit dividend
+struct Quant {
+  uint16_t q[64];      // natural order
+  uint32_t magic[64];  // floor(2^32 / (8q)) + 1
+  uint16_t half[64];   // (8q) >> 1
+  Quant(const uint8_t* basic, int quality) {
+    quality = std::min(100, std::max(1, quality));
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    for (int i = 0; i < 64; ++i) {
+      long t = ((long)basic[i] * scale + 50L) / 100L;
+      t = std::min(255L, std::max(1L, t));
+      q[i] = (uint16_t)t;
+      const uint32_t d = (uint32_t)t << 3;
+      magic[i] = (uint32_t)((1ull << 32) / d) + 1u;
+      half[i] = (uint16_t)(d >> 1);
+    }
+  }
+  inline int16_t apply(int32_t v, int i) const {
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v) + half[i];
+    const uint32_t r = (uint32_t)(((uint64_t)a * magic[i]) >> 32);
+    return (int16_t)(v < 0 ? -(int32_t)r : (int32_t)r);
+  }
+};
+
+#define PCC_FIX_0_298631336 2446
+#define PCC_FIX_0_390180644 3196
+#define PCC_FIX_0_541196100 4433
+#define PCC_FIX_0_765366865 6270
+#define PCC_FIX_0_899976223 7373
+#define PCC_FIX_1_175875602 9633
+#define PCC_FIX_1_501321110 12299
+#define PCC_FIX_1_847759065 15137
+#define PCC_FIX_1_961570560 16069
+#define PCC_FIX_2_053119869 16819
+#define PCC_FIX_2_562915447 20995
+#define PCC_FIX_3_072711026 25172
+inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jfdctint.c: 13-bit constants, 2 extra bits carried between the passes, output scaled by 8
+inline void fdct_1d(const int32_t in[8], int32_t out[8], int shift_even_up, int down_even, int down_odd) {
+  const int32_t t0 = in[0] + in[7], t7 = in[0] - in[7];
+  const int32_t t1 = in[1] + in[6], t6 = in[1] - in[6];
+  const int32_t t2 = in[2] + in[5], t5 = in[2] - in[5];
+  const int32_t t3 = in[3] + in[4], t4 = in[3] - in[4];
+  const int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  if (shift_even_up) {
+    out[0] = (t10 + t11) << shift_even_up;
+    out[4] = (t10 - t11) << shift_even_up;
+  } else {
+    out[0] = descale(t10 + t11, down_even);
+    out[4] = descale(t10 - t11, down_even);
+  }
+  int32_t z1 = (t12 + t13) * PCC_FIX_0_541196100;
+  out[2] = descale(z1 + t13 * PCC_FIX_0_765366865, down_odd);
+  out[6] = descale(z1 + t12 * (-PCC_FIX_1_847759065), down_odd);
+  z1 = t4 + t7;
+  int32_t z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int32_t z5 = (z3 + z4) * PCC_FIX_1_175875602;
+  const int32_t a4 = t4 * PCC_FIX_0_298631336, a5 = t5 * PCC_FIX_2_053119869;
+  const int32_t a6 = t6 * PCC_FIX_3_072711026, a7 = t7 * PCC_FIX_1_501321110;
+  z1 *= -PCC_FIX_0_899976223;
+  z2 *= -PCC_FIX_2_562915447;
+  z3 = z3 * (-PCC_FIX_1_961570560) + z5;
+  z4 = z4 * (-PCC_FIX_0_390180644) + z5;
+  out[7] = descale(a4 + z1 + z3, down_odd);
+  out[5] = descale(a5 + z2 + z4, down_odd);
+  out[3] = descale(a6 + z2 + z3, down_odd);
+  out[1] = descale(a7 + z1 + z4, down_odd);
+}
+
+// samples (already level shifted) -> quantised coefficients in natural order
+inline void fdct_quant(const int32_t samples[64], const Quant& q, int16_t out[64]) {
+  int32_t ws[64];
+  for (int r = 0; r < 8; ++r) fdct_1d(samples + 8 * r, ws + 8 * r, 2, 0, 13 - 2);
+  for (int c = 0; c < 8; ++c) {
+    int32_t col[8], res[8];
+    for (int r = 0; r < 8; ++r) col[r] = ws[8 * r + c];
+    fdct_1d(col, res, 0, 2, 13 + 2);
+    for (int r = 0; r < 8; ++r) out[8 * r + c] = q.apply(res[r], 8 * r + c);
+  }
+}
+
+class BitSink {
+ public:
+  explicit BitSink(Bytes& out) : out_(out) {}
+  inline void put(uint32_t code, int len) {
+    acc_ = (acc_ << len) | (code & ((1u << len) - 1u));
+    n_ += len;
+    while (n_ >= 8) {
+      const uint8_t b = (uint8_t)(acc_ >> (n_ - 8));
+      out_.push_back(b);
+      if (b == 0xFF) out_.push_back(0);
+      n_ -= 8;
+    }
+  }
+  void flush() {
+    put(0x7F, 7);  // pad the last byte with ones (jchuff.c flush_bits)
+    acc_ = 0;
+    n_ = 0;
+  }
+
+ private:
+  Bytes& out_;
+  uint64_t acc_ = 0;
+  int n_ = 0;
+};
+
+inline int bit_length(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }
+
+inline void huff_block(BitSink& bs, const int16_t blk[64], int& last_dc, const HuffEnc& dc, const HuffEnc& ac) {
+  int diff = blk[0] - last_dc;
+  last_dc = blk[0];
+  int mag = diff < 0 ? -diff : diff, low = diff < 0 ? diff - 1 : diff;
+  int nb = bit_length((uint32_t)mag);
+  bs.put(dc.code[nb], dc.len[nb]);
+  if (nb) bs.put((uint32_t)low, nb);
+  int run = 0;
+  for (int k = 1; k < 64; ++k) {
+    const int v = blk[kZigzag[k]];
+    if (v == 0) { ++run; continue; }
+    while (run > 15) { bs.put(ac.code[0xF0], ac.len[0xF0]); run -= 16; }
+    mag = v < 0 ? -v : v;
+    low = v < 0 ? v - 1 : v;
+    nb = bit_length((uint32_t)mag);
+    const int sym = (run << 4) | nb;
+    bs.put(ac.code[sym], ac.len[sym]);
+    bs.put((uint32_t)low, nb);
+    run = 0;
+  }
+  if (run) bs.put(ac.code[0], ac.len[0]);
+}
+
+inline void be16(Bytes& o, unsigned v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+void put_dqt(Bytes& o, int id, const Quant& q) {
+  be16(o, 0xFFDB); be16(o, 67); o.push_back((uint8_t)id);
+  for (int i = 0; i < 64; ++i) o.push_back((uint8_t)q.q[kZigzag[i]]);
+}
+void put_dht(Bytes& o, int tc_th, const HuffSpec& s) {
+  be16(o, 0xFFC4); be16(o, (unsigned)(19 + s.nvals)); o.push_back((uint8_t)tc_th);
+  o.insert(o.end(), s.bits, s.bits + 16);
+  o.insert(o.end(), s.vals, s.vals + s.nvals);
+}
+}  // namespace
+
+void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Bytes& out) {
+  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
+  static const HuffEnc dcl(kDcLuma), acl(kAcLuma), dcc(kDcChroma), acc(kAcChroma);
+
+  // headers: SOI, JFIF APP0, DQT x2, SOF0 (2x2,1x1,1x1), DHT x4, SOS (jcmarker.c order)
+  be16(out, 0xFFD8);
+  be16(out, 0xFFE0); be16(out, 16);
+  const uint8_t jfif[14] = {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+  out.insert(out.end(), jfif, jfif + 14);
+  put_dqt(out, 0, ql);
+  put_dqt(out, 1, qc);
+  be16(out, 0xFFC0); be16(out, 17); out.push_back(8); be16(out, (unsigned)h); be16(out, (unsigned)w); out.push_back(3);
+  const uint8_t comps[9] = {1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1};
+  out.insert(out.end(), comps, comps + 9);
+  put_dht(out, 0x00, kDcLuma); put_dht(out, 0x10, kAcLuma);
+  put_dht(out, 0x01, kDcChroma); put_dht(out, 0x11, kAcChroma);
+  be16(out, 0xFFDA); be16(out, 12);
+  const uint8_t sos[10] = {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
+  out.insert(out.end(), sos, sos + 10);
+
+  // colour planes (jccolor.c rgb_ycc_convert, 16-bit fixed point)
+  const size_t npx = (size_t)w * h;
+  std::vector<uint8_t> planes(3 * npx);
+  uint8_t* Y = planes.data();
+  uint8_t* Cb = Y + npx;
+  uint8_t* Cr = Cb + npx;
+  for (size_t i = 0; i < npx; ++i) {
+    const int32_t r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+    Y[i] = (uint8_t)((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+    Cb[i] = (uint8_t)((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16);
+    Cr[i] = (uint8_t)((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16);
+  }
+
+  const int ch = (h + 1) / 2;                    // real chroma rows
+  const int y_wb = (w + 7) / 8, y_hb = (h + 7) / 8;  // real luma blocks
+  const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
+  out.reserve(out.size() + npx / 2 + 1024);
+  BitSink bs(out);
+  int last_dc[3] = {0, 0, 0};
+  int16_t blk[6][64];
+  int32_t smp[64];
+
+  auto clampi = [](int v, int hi) { return v < hi ? v : hi; };
+  for (int my = 0; my < mcus_y; ++my) {
+    for (int mx = 0; mx < mcus_x; ++mx) {
+      for (int yi = 0; yi < 2; ++yi) {
+        const int by = 2 * my + yi;
+        for (int xi = 0; xi < 2; ++xi) {
+          const int bx = 2 * mx + xi;
+          int16_t* dst = blk[2 * yi + xi];
+          if (by >= y_hb) {  // dummy block row below the image: DC of the block before this row
+            memset(dst, 0, sizeof(blk[0]));
+            dst[0] = blk[2 * yi - 1][0];
+          } else if (bx >= y_wb) {  // dummy block right of the image: DC of the left neighbour
+            memset(dst, 0, sizeof(blk[0]));
+            dst[0] = blk[2 * yi + xi - 1][0];
+          } else {
+            for (int r = 0; r < 8; ++r) {
+              const uint8_t* row = Y + (size_t)clampi(8 * by + r, h - 1) * w;
+              for (int c = 0; c < 8; ++c) smp[8 * r + c] = (int32_t)row[clampi(8 * bx + c, w - 1)] - 128;
+            }
+            fdct_quant(smp, ql, dst);
+          }
+        }
+      }
+      for (int k = 0; k < 2; ++k) {  // h2v2 box downsample with alternating bias 1,2 (jcsample.c)
+        const uint8_t* P = k ? Cr : Cb;
+        for (int r = 0; r < 8; ++r) {
+          const int cr_row = clampi(8 * my + r, ch - 1);  // component rows replicated below the image
+          const uint8_t* r0 = P + (size_t)clampi(2 * cr_row, h - 1) * w;
+          const uint8_t* r1 = P + (size_t)clampi(2 * cr_row + 1, h - 1) * w;
+          for (int c = 0; c < 8; ++c) {
+            const int cc = 8 * mx + c;
+            const int c0 = clampi(2 * cc, w - 1), c1 = clampi(2 * cc + 1, w - 1);
+            smp[8 * r + c] = ((r0[c0] + r0[c1] + r1[c0] + r1[c1] + ((cc & 1) ? 2 : 1)) >> 2) - 128;
+          }
+        }
+        fdct_quant(smp, qc, blk[4 + k]);
+      }
+      for (int i = 0; i < 4; ++i) huff_block(bs, blk[i], last_dc[0], dcl, acl);
+      huff_block(bs, blk[4], last_dc[1], dcc, acc);
+      huff_block(bs, blk[5], last_dc[2], dcc, acc);
+    }
+  }
+  bs.flush();
+  be16(out, 0xFFD9);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder (libjpeg defaults: islow IDCT, fancy upsampling when downsampled_width > 2)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct HuffDec {
+  int32_t maxcode[18];
+  int32_t valoff[17];
+  uint8_t vals[256];
+  bool ok = false;
+  void build(const uint8_t bits[16], const uint8_t* v, int n) {
+    memcpy(vals, v, (size_t)n);
+    int32_t code = 0, p = 0;
+    for (int l = 1; l <= 16; ++l) {
+      if (bits[l - 1]) {
+        valoff[l] = p - code;
+        p += bits[l - 1];
+        code += bits[l - 1];
+        maxcode[l] = code - 1;
+      } else {
+        maxcode[l] = -1;
+      }
+      code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff;
+    ok = true;
+  }
+};
+
+struct BitSource {
+  const uint8_t* p;
+  size_t len, pos;
+  uint32_t acc = 0;
+  int n = 0;
+  bool marker = false;
+  inline int bit() {
+    if (n == 0) {
+      uint8_t v = 0;
+      if (!marker && pos < len) {
+        v = p[pos];
+        if (v == 0xFF) {
+          if (pos + 1 < len && p[pos + 1] == 0) pos += 2;
+          else { marker = true; v = 0; }
+        } else {
+          ++pos;
+        }
+      }
+      acc = v;
+      n = 8;
+    }
+    --n;
+    return (acc >> n) & 1;
+  }
+  inline int bits(int k) {
+    int v = 0;
+    while (k--) v = (v << 1) | bit();
+    return v;
+  }
+  inline int sym(const HuffDec& t) {
+    int32_t code = 0;
+    for (int l = 1; l <= 16; ++l) {
+      code = (code << 1) | bit();
+      if (t.maxcode[l] >= 0 && code <= t.maxcode[l]) return t.vals[(code + t.valoff[l]) & 0xFF];
+    }
+    return 0;
+  }
+};
+inline int extend_sign(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
+
+inline uint8_t idct_clamp(int32_t v) {  // sample_range_limit + CENTERJSAMPLE, index masked to 10 bits
+  const int i = (int)(v & 1023);
+  if (i < 128) return (uint8_t)(128 + i);
+  if (i < 512) return 255;
+  if (i < 896) return 0;
+  return (uint8_t)(i - 896);
+}
+inline void idct_1d(const int32_t in[8], int32_t o[8]) {  // jidctint.c butterfly, unscaled outputs
+  int32_t z2 = in[2], z3 = in[6];
+  int32_t z1 = (z2 + z3) * PCC_FIX_0_541196100;
+  const int32_t e2 = z1 + z3 * (-PCC_FIX_1_847759065), e3 = z1 + z2 * PCC_FIX_0_765366865;
+  const int32_t e0 = (in[0] + in[4]) * 8192, e1 = (in[0] - in[4]) * 8192;
+  const int32_t t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
+  int32_t t0 = in[7], t1 = in[5], t2 = in[3], t3 = in[1];
+  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
+  int32_t z4 = t1 + t3;
+  const int32_t z5 = (z3 + z4) * PCC_FIX_1_175875602;
+  t0 *= PCC_FIX_0_298631336; t1 *= PCC_FIX_2_053119869; t2 *= PCC_FIX_3_072711026; t3 *= PCC_FIX_1_501321110;
+  z1 *= -PCC_FIX_0_899976223; z2 *= -PCC_FIX_2_562915447;
+  z3 = z3 * (-PCC_FIX_1_961570560) + z5;
+  z4 = z4 * (-PCC_FIX_0_390180644) + z5;
+  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+  o[0] = t10 + t3; o[7] = t10 - t3; o[1] = t11 + t2; o[6] = t11 - t2;
+  o[2] = t12 + t1; o[5] = t12 - t1; o[3] = t13 + t0; o[4] = t13 - t0;
+}
+void idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t* dst, int stride) {
+  int32_t ws[64], in[8], o[8];
+  for (int c = 0; c < 8; ++c) {
+    for (int r = 0; r < 8; ++r) in[r] = (int32_t)coef[8 * r + c] * q[8 * r + c];
+    idct_1d(in, o);
+    for (int r = 0; r < 8; ++r) ws[8 * r + c] = descale(o[r], 13 - 2);
+  }
+  for (int r = 0; r < 8; ++r) {
+    idct_1d(ws + 8 * r, o);
+    for (int c = 0; c < 8; ++c) dst[(size_t)r * stride + c] = idct_clamp(descale(o[c], 13 + 2 + 3));
+  }
+}
+}  // namespace
+
+bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h) {
+  uint16_t qt[4][64] = {};
+  HuffDec hd[2][4];
+  int restart = 0;
+  int samp[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, tdc[3] = {0, 0, 0}, tac[3] = {0, 0, 0};
+  w = h = 0;
+  if (len < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return false;
+  size_t pos = 2;
+  bool sos = false;
+  while (!sos && pos + 4 <= len) {
+    if (jpg[pos] != 0xFF) return false;
+    const int m = jpg[pos + 1];
+    pos += 2;
+    if (m == 0xFF) { --pos; continue; }
+    if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    const size_t seg = ((size_t)jpg[pos] << 8) | jpg[pos + 1];
+    if (seg < 2 || pos + seg > len) return false;
+    const uint8_t* s = jpg + pos + 2;
+    const size_t n = seg - 2;
+    if (m == 0xDB) {
+      for (size_t i = 0; i < n;) {
+        const int pq = s[i] >> 4, id = s[i] & 15;
+        ++i;
+        if (id > 3 || i + (pq ? 128 : 64) > n) return false;
+        for (int k = 0; k < 64; ++k) {
+          qt[id][kZigzag[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];
+          i += pq ? 2 : 1;
+        }
+      }
+    } else if (m == 0xC4) {
+      for (size_t i = 0; i < n;) {
+        const int tc = s[i] >> 4, th = s[i] & 15;
+        ++i;
+        if (tc > 1 || th > 3 || i + 16 > n) return false;
+        int cnt = 0;
+        for (int k = 0; k < 16; ++k) cnt += s[i + k];
+        if (cnt > 256 || i + 16 + cnt > n) return false;
+        hd[tc][th].build(s + i, s + i + 16, cnt);
+        i += 16 + (size_t)cnt;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (n < 15 || s[0] != 8 || s[5] != 3) return false;
+      h = (s[1] << 8) | s[2];
+      w = (s[3] << 8) | s[4];
+      for (int c = 0; c < 3; ++c) { samp[c] = s[7 + 3 * c]; tq[c] = s[8 + 3 * c] & 3; }
+    } else if (m == 0xC2 || (m > 0xC4 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+      return false;
+    } else if (m == 0xDD) {
+      restart = (s[0] << 8) | s[1];
+    } else if (m == 0xDA) {
+      if (n < 10 || s[0] != 3) return false;
+      for (int c = 0; c < 3; ++c) { tdc[c] = (s[2 + 2 * c] >> 4) & 3; tac[c] = s[2 + 2 * c] & 3; }
+      sos = true;
+    }
+    pos += seg;
+  }
+  if (!sos || w <= 0 || h <= 0 || samp[0] != 0x22 || samp[1] != 0x11 || samp[2] != 0x11) return false;
+
+  const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
+  const int cw = (w + 1) / 2, chh = (h + 1) / 2;
+  const int yw = mcus_x * 16, cpw = mcus_x * 8;
+  std::vector<uint8_t> Y((size_t)yw * mcus_y * 16), C0((size_t)cpw * mcus_y * 8), C1((size_t)cpw * mcus_y * 8);
+  uint8_t* C[2] = {C0.data(), C1.data()};
+  BitSource br{jpg, len, pos};
+  int last_dc[3] = {0, 0, 0}, count = 0, next_rst = 0;
+  int16_t blk[64];
+  auto one_block = [&](int c, uint8_t* dst, int stride) {
+    memset(blk, 0, sizeof(blk));
+    const int sz = br.sym(hd[0][tdc[c]]);
+    last_dc[c] += sz ? extend_sign(br.bits(sz), sz) : 0;
+    blk[0] = (int16_t)last_dc[c];
+    for (int k = 1; k < 64; ++k) {
+      const int rs = br.sym(hd[1][tac[c]]), r = rs >> 4, s4 = rs & 15;
+      if (s4) {
+        k += r;
+        if (k > 63) break;
+        blk[kZigzag[k]] = (int16_t)extend_sign(br.bits(s4), s4);
+      } else if (r == 15) {
+        k += 15;
+      } else {
+        break;
+      }
+    }
+    idct_block(blk, qt[tq[c]], dst, stride);
+  };
+  for (int my = 0; my < mcus_y; ++my)
+    for (int mx = 0; mx < mcus_x; ++mx) {
+      if (restart && count && count % restart == 0) {
+        br.n = 0; br.marker = false;
+        while (br.pos + 1 < br.len && !(br.p[br.pos] == 0xFF && br.p[br.pos + 1] == 0xD0 + next_rst)) ++br.pos;
+        br.pos += 2;
+        next_rst = (next_rst + 1) & 7;
+        last_dc[0] = last_dc[1] = last_dc[2] = 0;
+      }
+      for (int yi = 0; yi < 2; ++yi)
+        for (int xi = 0; xi < 2; ++xi) one_block(0, Y.data() + (size_t)(16 * my + 8 * yi) * yw + 16 * mx + 8 * xi, yw);
+      one_block(1, C[0] + (size_t)8 * my * cpw + 8 * mx, cpw);
+      one_block(2, C[1] + (size_t)8 * my * cpw + 8 * mx, cpw);
+      ++count;
+    }
+
+  // chroma upsampling (jdsample.c): triangle filter if downsampled_width > 2, else replication
+  const int uw = cpw * 2;
+  std::vector<uint8_t> U0((size_t)uw * chh * 2), U1((size_t)uw * chh * 2);
+  uint8_t* U[2] = {U0.data(), U1.data()};
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < chh; ++r)
+      for (int v = 0; v < 2; ++v) {
+        uint8_t* o = U[k] + (size_t)(2 * r + v) * uw;
+        const uint8_t* in0 = C[k] + (size_t)r * cpw;
+        if (cw <= 2) {
+          for (int c = 0; c < cw; ++c) o[2 * c] = o[2 * c + 1] = in0[c];
+          continue;
+        }
+        const int nr = v == 0 ? std::max(r - 1, 0) : std::min(r + 1, chh - 1);
+        const uint8_t* in1 = C[k] + (size_t)nr * cpw;
+        int cur = in0[0] * 3 + in1[0], nxt = in0[1] * 3 + in1[1], prv;
+        *o++ = (uint8_t)((cur * 4 + 8) >> 4);
+        *o++ = (uint8_t)((cur * 3 + nxt + 7) >> 4);
+        prv = cur; cur = nxt;
+        for (int c = 2; c < cw; ++c) {
+          nxt = in0[c] * 3 + in1[c];
+          *o++ = (uint8_t)((cur * 3 + prv + 8) >> 4);
+          *o++ = (uint8_t)((cur * 3 + nxt + 7) >> 4);
+          prv = cur; cur = nxt;
+        }
+        *o++ = (uint8_t)((cur * 3 + prv + 8) >> 4);
+        *o++ = (uint8_t)((cur * 4 + 7) >> 4);
+      }
+  rgb.resize((size_t)w * h * 3);
+  auto sat = [](int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) {
+      const int y = Y[(size_t)r * yw + c];
+      const int32_t xb = U[0][(size_t)r * uw + c] - 128, xr = U[1][(size_t)r * uw + c] - 128;
+      uint8_t* o = rgb.data() + ((size_t)r * w + c) * 3;
+      o[0] = sat(y + ((91881 * xr + 32768) >> 16));
+      o[1] = sat(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16));
+      o[2] = sat(y + ((116130 * xb + 32768) >> 16));
+    }
+  return true;
+}
+
+// =============================================================================================
+// snake grid mapping, closed form (same as the device code; snake.h:46-71)
+// =============================================================================================
+uint32_t snake_position(uint32_t i, uint32_t W, uint32_t H) {
+  const uint32_t full = H / 8u, hl = H % 8u, per_row = W * 8u;
+  if (i < full * per_row) {
+    const uint32_t br = i / per_row, rem = i % per_row, bw = rem / 64u, q = rem % 64u, r = q / 8u, c = q % 8u;
+    return (br * 8u + r) * W + bw * 8u + ((r & 1u) ? 7u - c : c);
+  }
+  const uint32_t rem = i - full * per_row, blk = 8u * hl, bw = rem / blk, q = rem % blk, r = q / 8u, c = q % 8u;
+  const uint32_t flip = (r + ((hl & 1u) ? bw : 0u)) & 1u;
+  return (full * 8u + r) * W + bw * 8u + (flip ? 7u - c : c);
+}
+
+// =============================================================================================
+// frame header + entropy stage
+// =============================================================================================
+namespace {
+template <typename T>
+inline void put_le(Bytes& o, T v) {
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(&v);
+  o.insert(o.end(), p, p + sizeof(T));
+}
+const char kV2Id[] = "<PCL-OCT-CODECV2-COMPRESSED>";
+const char kV1Id[] = "<PCL-OCT-COMPRESSED>";
+}  // namespace
+
+void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3]) {
+  out.clear();
+  const bool with_color = prm.do_color_encoding != 0;
+  const size_t L = (size_t)hot.n_leaves;
+  // --- 140-byte header ---
+  out.insert(out.end(), kV2Id, kV2Id + 28);
+  out.insert(out.end(), kV1Id, kV1Id + 20);
+  put_le<uint32_t>(out, prm.frame_id);
+  put_le<uint8_t>(out, 1);  // i_frame_
+  put_le<uint8_t>(out, 1);  // do_voxel_grid_enDecoding_
+  put_le<uint8_t>(out, with_color ? 1 : 0);
+  put_le<uint64_t>(out, (uint64_t)L);
+  put_le<double>(out, prm.octree_resolution);
+  put_le<uint8_t>(out, (uint8_t)prm.color_bit_resolution);
+  put_le<double>(out, (double)(float)prm.point_resolution);
+  for (int i = 0; i < 6; ++i) put_le<double>(out, hot.bbox[i]);
+  put_le<uint8_t>(out, prm.do_voxel_centroid ? 1 : 0);
+  put_le<uint8_t>(out, prm.do_connectivity ? 1 : 0);
+  put_le<uint8_t>(out, prm.create_scalable ? 1 : 0);
+  put_le<uint32_t>(out, (uint32_t)prm.color_coding_type);
+  put_le<int32_t>(out, prm.macroblock_size);
+  put_le<uint8_t>(out, prm.do_icp_color_offset ? 1 : 0);
+
+  // --- occupancy bytes ---
+  put_le<uint64_t>(out, hot.n_branches);
+  uint64_t point_len = StaticRangeCoder::encode(hot.occupancy, (size_t)hot.n_branches, out);
+  perf[0] = point_len;
+  if (prm.do_voxel_centroid) {
+    put_le<uint32_t>(out, (uint32_t)(3 * L));
+    point_len += StaticRangeCoder::encode(hot.centroid, 3 * L, out);
+  }
+  perf[1] = point_len - perf[0];
+  perf[2] = 0;
+  if (with_color) {
+    Bytes payload;
+    const uint8_t* src = hot.bgr;
+    size_t src_len = 3 * L;
+    if (prm.color_coding_type == 1) {  // one 256-wide snake-mapped image (jpegcc.h:187-226)
+      BaselineJpeg::encode_rgb(hot.image, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
+      src = payload.data();
+      src_len = payload.size();
+    } else if (prm.color_coding_type == 2) {  // 2048x1 lines (jpegcc.h:244-317)
+      const size_t lines = L / 2048;
+      const uint32_t count = lines ? (uint32_t)lines : 1u;
+      put_le<uint32_t>(payload, count);
+      Bytes one;
+      for (uint32_t i = 0; i < count; ++i) {
+        const size_t start = (size_t)2048 * i;
+        const size_t width = lines == 0 ? L : (i + 1 != count ? 2048 : L - start);
+        one.clear();
+        BaselineJpeg::encode_rgb(hot.bgr + 3 * start, (int)width, 1, prm.jpeg_quality, one);
+        put_le<uint32_t>(payload, (uint32_t)one.size());
+        payload.insert(payload.end(), one.begin(), one.end());
+      }
+      src = payload.data();
+      src_len = payload.size();
+    }
+    put_le<uint64_t>(out, (uint64_t)src_len);
+    perf[2] = StaticRangeCoder::encode(src, src_len, out);
+  }
+}
+
+// =============================================================================================
+// decoder
+// =============================================================================================
+namespace {
+struct Reader {
+  const uint8_t* p;
+  size_t len, pos;
+  template <typename T>
+  bool get(T& v) {
+    if (pos + sizeof(T) > len) return false;
+    memcpy(&v, p + pos, sizeof(T));
+    pos += sizeof(T);
+    return true;
+  }
+  bool sync(const char* id) {  // impl.hpp:1660-1676
+    const size_t n = strlen(id);
+    size_t k = 0;
+    while (k < n) {
+      if (pos >= len) return false;
+      const char c = (char)p[pos++];
+      if (c != id[k++]) k = (id[0] == c) ? 1 : 0;
+    }
+    return true;
+  }
+};
+}  // namespace
+
+int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info) {
+  memset(&info, 0, sizeof(info));
+  points.clear();
+  Reader r{stream, len, 0};
+  if (!r.sync(kV2Id) || !r.sync(kV1Id)) return PCC_ERR_STREAM;
+  pcc_params& p = info.params;
+  uint8_t i_frame = 0, vg = 0, with_color = 0, cbits = 0, u8 = 0;
+  uint64_t count = 0;
+  if (!r.get(p.frame_id) || !r.get(i_frame) || !i_frame) return PCC_ERR_STREAM;
+  if (!r.get(vg) || !r.get(with_color) || !r.get(count) || !r.get(p.octree_resolution) || !r.get(cbits) ||
+      !r.get(p.point_resolution))
+    return PCC_ERR_STREAM;
+  for (int i = 0; i < 6; ++i)
+    if (!r.get(info.bbox[i])) return PCC_ERR_STREAM;
+  p.color_bit_resolution = cbits;
+  p.do_color_encoding = with_color;
+  uint32_t cct = 0;
+  if (!r.get(u8)) return PCC_ERR_STREAM;
+  p.do_voxel_centroid = u8;
+  if (!r.get(u8)) return PCC_ERR_STREAM;
+  p.do_connectivity = u8;
+  if (!r.get(u8)) return PCC_ERR_STREAM;
+  p.create_scalable = u8;
+  if (!r.get(cct) || !r.get(p.macroblock_size) || !r.get(u8)) return PCC_ERR_STREAM;
+  p.color_coding_type = (int32_t)cct;
+  p.do_icp_color_offset = u8;
+  const double res = p.octree_resolution;
+  if (!(res > 0.0)) return PCC_ERR_STREAM;
+
+  // defineBoundingBox + getKeyBitSize
+  {
+    const float mv = FLT_EPSILON;
+    unsigned mk = 2;
+    for (int a = 0; a < 3; ++a) {
+      const double k = ceil((info.bbox[3 + a] - info.bbox[a] - mv) / res);
+      if (!(k >= 0.0 && k < 4294967296.0)) return PCC_ERR_STREAM;
+      mk = std::max(mk, (unsigned)k);
+    }
+    unsigned d = (unsigned)ceil(log2((double)mk) - mv);
+    d = std::min(d, 32u);
+    info.depth = d;
+    const double side = (double)(1ull << d) * res;
+    for (int a = 0; a < 3; ++a) {
+      const double over = (side - (info.bbox[3 + a] - info.bbox[a])) / 2.0;
+      if (over > mv) { info.bbox[a] -= over; info.bbox[3 + a] += over; }
+    }
+  }
+
+  uint64_t occ_n = 0;
+  if (!r.get(occ_n) || occ_n > len * 64 + 64) return PCC_ERR_STREAM;
+  Bytes occ((size_t)occ_n);
+  size_t used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, occ.data(), occ.size());
+  if (!used) return PCC_ERR_STREAM;
+  r.pos += used;
+  Bytes cen;
+  if (p.do_voxel_centroid) {
+    uint32_t n = 0;
+    if (!r.get(n)) return PCC_ERR_STREAM;
+    cen.resize(n);
+    used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, cen.data(), cen.size());
+    if (!used) return PCC_ERR_STREAM;
+    r.pos += used;
+  }
+  Bytes col;
+  if (with_color) {
+    uint64_t n = 0;
+    if (!r.get(n) || n > len * 64 + 64) return PCC_ERR_STREAM;
+    Bytes payload((size_t)n);
+    used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, payload.data(), payload.size());
+    if (!used) return PCC_ERR_STREAM;
+    r.pos += used;
+    if (cct == 1) {  // decodeJPEGSnake (jpegcc.h:228-242)
+      Bytes img;
+      int w = 0, h = 0;
+      if (BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h) && w % 8 == 0) {
+        col.resize(img.size());
+        for (uint32_t i = 0; i < (uint32_t)(w * h); ++i) {
+          const uint32_t px = snake_position(i, (uint32_t)w, (uint32_t)h);
+          col[3 * i] = img[3 * px]; col[3 * i + 1] = img[3 * px + 1]; col[3 * i + 2] = img[3 * px + 2];
+        }
+      }
+    } else if (cct == 2) {  // decodeJPEGLines (jpegcc.h:319-344)
+      Reader lr{payload.data(), payload.size(), 0};
+      uint32_t lines = 0;
+      lr.get(lines);
+      for (uint32_t i = 0; i < lines; ++i) {
+        uint32_t sz = 0;
+        if (!lr.get(sz) || lr.pos + sz > lr.len) break;
+        Bytes img;
+        int w = 0, h = 0;
+        if (BaselineJpeg::decode_rgb(lr.p + lr.pos, sz, img, w, h)) col.insert(col.end(), img.begin(), img.end());
+        lr.pos += sz;
+      }
+    } else {
+      col.swap(payload);
+    }
+  }
+  info.consumed = r.pos;
+
+  // deserializeTree: pre-order walk with an explicit stack (Appendix B), leaves in Morton order
+  points.resize((size_t)count);
+  const unsigned D = info.depth;
+  const unsigned shift = (cct == 0) ? (unsigned)(8 - p.color_bit_resolution) & 7u : 0u;
+  size_t leaf = 0, op = 0;
+  struct Frame { uint8_t bits; int8_t next; };
+  Frame stack[40];
+  uint32_t key[3] = {0, 0, 0};
+  int sp = 0;
+  if (D == 0 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
+  stack[0] = {occ[op++], 0};
+  while (sp >= 0) {
+    Frame& f = stack[sp];
+    int c = f.next;
+    while (c < 8 && !(f.bits & (1u << c))) ++c;
+    if (c == 8) {  // popBranch
+      --sp;
+      key[0] >>= 1; key[1] >>= 1; key[2] >>= 1;
+      continue;
+    }
+    f.next = (int8_t)(c + 1);
+    key[0] = (key[0] << 1) | ((c >> 2) & 1);
+    key[1] = (key[1] << 1) | ((c >> 1) & 1);
+    key[2] = (key[2] << 1) | (c & 1);
+    if ((unsigned)(sp + 1) < D) {
+      if (op >= occ.size() || sp + 1 >= 40) return PCC_ERR_STREAM;
+      stack[++sp] = {occ[op++], 0};
+      continue;
+    }
+    // leaf: deserializeTreeCallback (impl.hpp:1584-1653)
+    if (leaf >= points.size()) return PCC_ERR_STREAM;
+    pcc_point_xyzrgb np;
+    memset(&np, 0, sizeof(np));
+    np.w = 1.0f;
+    float xyz[3];
+    for (int a = 0; a < 3; ++a) {
+      if (p.do_voxel_centroid && 3 * leaf + 2 < cen.size()) {
+        const double lc = (double)key[a] * res + info.bbox[a];
+        xyz[a] = (float)(lc + (float)cen[3 * leaf + a] * 0.001f);  // ptv2.h:115-117
+      } else {
+        xyz[a] = (float)(((double)key[a] + 0.5) * res + info.bbox[a]);  // impl.hpp:1630-1632
+      }
+    }
+    np.x = xyz[0]; np.y = xyz[1]; np.z = xyz[2];
+    if (with_color) {
+      uint32_t c0 = 0, c1 = 0, c2 = 0;
+      if (3 * leaf + 2 < col.size()) { c0 = col[3 * leaf]; c1 = col[3 * leaf + 1]; c2 = col[3 * leaf + 2]; }
+      c0 = (uint8_t)(c0 << shift); c1 = (uint8_t)(c1 << shift); c2 = (uint8_t)(c2 << shift);
+      np.rgba = c0 | (c1 << 8) | (c2 << 16);
+    } else {
+      np.rgba = 0x00FFFFFFu;  // ColorCoding::setDefaultColor
+    }
+    points[leaf++] = np;
+    key[0] >>= 1; key[1] >>= 1; key[2] >>= 1;
+  }
+  info.n = leaf;
+  return leaf == (size_t)count ? PCC_OK : PCC_ERR_STREAM;
+}
+
+}  // namespace pcc

@@ -1,0 +1,42 @@
+// pcc_host_codec.h -- host-side (serial) stages of the codec that stay on the CPU by design:
+// frame header, static range coder, baseline JPEG Huffman coding, stream assembly, and the
+// decoder.  North star: "the serial range/entropy coder runs on the host over the
+// GPU-produced occupancy byte stream".
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/pcc_codec.h"
+
+namespace pcc {
+
+typedef std::vector<uint8_t> Bytes;
+
+// pcl::StaticRangeCoder (call sites impl.hpp:1694,1706,1719 / 1778,1789,1798)
+class StaticRangeCoder {
+ public:
+  // appends 1028-byte table + payload + 8 flush bytes to `out`; returns bytes appended
+  static size_t encode(const uint8_t* in, size_t n, Bytes& out);
+  // returns bytes consumed, 0 on a truncated stream
+  static size_t decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n);
+};
+
+// libjpeg-turbo-compatible baseline JPEG, YCbCr 4:2:0, as driven by jpeg_io.hpp:211-330 / 90-192
+class BaselineJpeg {
+ public:
+  static void encode_rgb(const uint8_t* rgb, int w, int h, int quality, Bytes& out);
+  static bool decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h);
+};
+
+// SnakeGridMapping (snake.h): position of linear element i in a w x h image (w multiple of 8)
+uint32_t snake_position(uint32_t i, uint32_t w, uint32_t h);
+
+// writeFrameHeader + entropyEncoding (impl.hpp:1472-1486, 1682-1760)
+void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3]);
+
+// decodePointCloud (impl.hpp:224-310); returns PCC_OK or PCC_ERR_STREAM
+int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info);
+
+}  // namespace pcc

@@ -1,0 +1,88 @@
+// pcc_kernels.h -- launch interface between the C-ABI layer (pcc_api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "pcc_device.h"
+
+namespace pcc {
+
+// How to read the caller's point array (pcl::PointXYZRGB: stride 32, colour word at 16).
+struct PointView {
+  const uint8_t* base;
+  uint32_t stride;
+  uint32_t rgb_off;
+  uint32_t aligned16;  // base and stride are multiples of 16: x,y,z,w come in one 16-byte load
+};
+
+struct LeafParams {
+  uint32_t do_color;         // cloud_with_color_
+  uint32_t color_reduction;  // colorBitReduction_ (only the PCL colour coder, type 0, ever has one)
+  uint32_t do_centroid;      // do_voxel_centroid_enDecoding_
+  uint32_t write_image;      // colour coding type 1: emit the snake-mapped 256 x H image
+};
+
+struct HotPathArgs {
+  PointView pv;
+  uint32_t n;
+  double res;
+  LeafParams lp;
+  int max_passes;  // radix passes to enqueue (device decides how many do work)
+  ChunkBox* boxes;
+  FrameState* state;
+  uint64_t* keys_a;
+  uint64_t* keys_b;
+  uint32_t* ghist;
+  uint32_t* gtot;
+  uint64_t* partials;
+  uint32_t* leaf_start;
+  uint64_t* leaf_code;
+  uint32_t* leaf_base;
+  uint8_t* leaf_t;
+  uint8_t* occ;
+  uint8_t* bgr;
+  uint8_t* centroid;
+  uint8_t* image;
+  void* simplified;  // float4 per leaf (x, y, z, rgba bits)
+};
+
+// Optional per-kernel timing: one HIP event after every launch, on the launch stream.
+class KernelTimer {
+ public:
+  void reset() { used_ = 0; }
+  void stamp(const char* name, hipStream_t s) {
+    if (used_ == events_.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      events_.push_back(e);
+      names_.push_back(name);
+    }
+    names_[used_] = name;
+    (void)hipEventRecord(events_[used_], s);
+    ++used_;
+  }
+  // after the stream is synchronised: (name, ms) per launch, stamp 0 is the origin
+  void collect(std::vector<std::pair<const char*, float>>& out) const {
+    out.clear();
+    for (size_t i = 1; i < used_; ++i) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, events_[i - 1], events_[i]);
+      out.emplace_back(names_[i], ms);
+    }
+  }
+  ~KernelTimer() {
+    for (auto e : events_) (void)hipEventDestroy(e);
+  }
+
+ private:
+  std::vector<hipEvent_t> events_;
+  std::vector<const char*> names_;
+  size_t used_ = 0;
+};
+
+void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm);
+
+}  // namespace pcc

@@ -1,0 +1,850 @@
+// pcc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the intra-frame
+// hot path of the CWI point-cloud codec.  They replace, with breadth-first array passes,
+// what the reference does with a pointer octree:
+//
+//   P1/P2  addPointsFromInputCloud + adoptBoundingBoxToPoint   -> k_chunk_boxes, k_bbox_events
+//   P3     genOctreeKeyforPoint                                -> k_make_keys
+//   P4     createLeafRecursive + addPointIndex                 -> LSD radix sort (k_radix_*)
+//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_partials/scan/emit + k_leaf_finalize
+//   C2/P6  serializeTreeCallback / encodeAverageOfPoints       -> k_leaf_finalize
+//   C3b    SnakeGridMapping::doMapping                         -> k_leaf_finalize (closed-form position)
+//   C4     PointCodingV2::encodePoint                          -> k_leaf_finalize
+//
+// All of it is integer / byte / fp64-scalar work bound by HBM bandwidth and launch latency:
+// no MFMA anywhere (there is no dense contraction in this path).
+//
+// Floating point discipline: keys and voxel centres are defined by individually rounded
+// double operations (no FMA contraction, no fast-math): explicit __d*_rn intrinsics are
+// used and the file is compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "pcc_device.h"
+#include "pcc_kernels.h"
+
+namespace pcc {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ void load_xyz(const PointView& pv, uint32_t i, float& x, float& y, float& z) {
+  const uint8_t* p = pv.base + (size_t)i * pv.stride;
+  if (pv.aligned16) {  // one 16-byte load per lane (x,y,z,w)
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    x = v.x; y = v.y; z = v.z;
+  } else {
+    const float* f = reinterpret_cast<const float*>(p);
+    x = f[0]; y = f[1]; z = f[2];
+  }
+}
+__device__ __forceinline__ uint32_t load_rgba(const PointView& pv, uint32_t i) {
+  return *reinterpret_cast<const uint32_t*>(pv.base + (size_t)i * pv.stride + pv.rgb_off);
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// 21-bit -> every third bit
+__device__ __forceinline__ uint64_t split3(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffULL;
+  x = (x | x << 16) & 0x1f0000ff0000ffULL;
+  x = (x | x << 8) & 0x100f00f00f00f00fULL;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+  x = (x | x << 2) & 0x1249249249249249ULL;
+  return x;
+}
+__device__ __forceinline__ uint32_t compact3(uint64_t x) {
+  x &= 0x1249249249249249ULL;
+  x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ULL;
+  x = (x ^ (x >> 4)) & 0x100f00f00f00f00fULL;
+  x = (x ^ (x >> 8)) & 0x1f0000ff0000ffULL;
+  x = (x ^ (x >> 16)) & 0x1f00000000ffffULL;
+  x = (x ^ (x >> 32)) & 0x1fffffULL;
+  return (uint32_t)x;
+}
+// x-major triples: child index = (xbit<<2)|(ybit<<1)|zbit  (OctreeKey::getChildIdxWithDepthMask)
+__device__ __forceinline__ uint64_t morton3(uint32_t kx, uint32_t ky, uint32_t kz) {
+  return (split3(kx) << 2) | (split3(ky) << 1) | split3(kz);
+}
+
+__device__ __forceinline__ float wave_min_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// inclusive scan inside a wave
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+  const int lane = lane_id();
+  for (int o = 1; o < 64; o <<= 1) {
+    uint64_t u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = lane_id();
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+// block-wide exclusive scan of one u64 per thread (256 threads); `total` = sum over the block
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_wave /*[4]*/, uint64_t& total) {
+  const uint64_t incl = wave_incl_scan_u64(v);
+  if (lane_id() == 63) s_wave[wave_id()] = incl;
+  __syncthreads();
+  uint64_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const uint64_t s = s_wave[w];
+    if (w < wave_id()) off += s;
+    tot += s;
+  }
+  total = tot;
+  __syncthreads();
+  return off + incl - v;
+}
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t& total) {
+  const uint32_t incl = wave_incl_scan_u32(v);
+  if (lane_id() == 63) s_wave[wave_id()] = incl;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const uint32_t s = s_wave[w];
+    if (w < wave_id()) off += s;
+    tot += s;
+  }
+  total = tot;
+  __syncthreads();
+  return off + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 0: per-chunk bounding boxes (first read of the cloud: 16 of every 32 bytes per point)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_chunk_boxes(PointView pv, uint32_t n, ChunkBox* __restrict__ boxes) {
+  __shared__ float s_mn[3][kBlock / 64], s_mx[3][kBlock / 64];
+  __shared__ int s_first[kBlock / 64], s_cnt[kBlock / 64];
+  const uint32_t base = blockIdx.x * kTile;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  int first = 0x7fffffff, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint32_t i = base + k * kBlock + threadIdx.x;
+    if (i < n) {
+      float x, y, z;
+      load_xyz(pv, i, x, y, z);
+      if (finite3(x, y, z)) {
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+        mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+        mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        first = min(first, (int)i);
+        ++cnt;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { mn[a] = wave_min_f(mn[a]); mx[a] = wave_max_f(mx[a]); }
+  first = wave_min_i(first);
+  cnt = (int)wave_sum_u64((uint64_t)cnt);
+  if (lane_id() == 0) {
+    const int w = wave_id();
+    for (int a = 0; a < 3; ++a) { s_mn[a][w] = mn[a]; s_mx[a][w] = mx[a]; }
+    s_first[w] = first; s_cnt[w] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ChunkBox b;
+    int c = 0, f = 0x7fffffff;
+    for (int a = 0; a < 3; ++a) { b.mn[a] = FLT_MAX; b.mx[a] = -FLT_MAX; }
+    for (int w = 0; w < kBlock / 64; ++w) {
+      for (int a = 0; a < 3; ++a) { b.mn[a] = fminf(b.mn[a], s_mn[a][w]); b.mx[a] = fmaxf(b.mx[a], s_mx[a][w]); }
+      f = min(f, s_first[w]); c += s_cnt[w];
+    }
+    b.first_finite = c ? f : -1;
+    b.n_finite = c;
+    boxes[blockIdx.x] = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1: the adaptive bounding box (P2) -- sequential and order dependent by definition.
+// One workgroup walks the cloud in order, but skips every chunk whose AABB already fits the
+// current box, so only chunks that contain a growth event are ever re-read (typically one).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_min_int(int v, int* s_red) {
+  if (threadIdx.x == 0) *s_red = 0x7fffffff;
+  __syncthreads();
+  v = wave_min_i(v);
+  if (lane_id() == 0 && v != 0x7fffffff) atomicMin(s_red, v);
+  __syncthreads();
+  const int r = *s_red;
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n, uint32_t n_chunks,
+                                                        const ChunkBox* __restrict__ boxes, double res,
+                                                        FrameState* __restrict__ st) {
+  __shared__ float s_p[3][kTile];
+  __shared__ int s_red;
+  __shared__ double s_mn[3], s_mx[3];
+  __shared__ int s_depth, s_nev, s_err;
+  __shared__ int ev_index[kMaxEpochs], ev_lowered[kMaxEpochs], ev_depth_before[kMaxEpochs];
+  __shared__ double ev_mn[kMaxEpochs][3];
+  __shared__ float s_g[6][kBlock / 64];
+  __shared__ unsigned s_nfin;
+
+  const double eps = (double)FLT_EPSILON;  // PCL: const float minValue = numeric_limits<float>::epsilon()
+
+  // ---- A: first finite point, finite count, global AABB (from the chunk boxes) ----
+  int first = 0x7fffffff;
+  unsigned nfin = 0;
+  float g[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t c = threadIdx.x; c < n_chunks; c += kBlock) {
+    const ChunkBox b = boxes[c];
+    if (b.n_finite > 0) {
+      first = min(first, b.first_finite);
+      nfin += (unsigned)b.n_finite;
+      for (int a = 0; a < 3; ++a) { g[a] = fminf(g[a], b.mn[a]); g[3 + a] = fmaxf(g[3 + a], b.mx[a]); }
+    }
+  }
+  if (threadIdx.x == 0) s_nfin = 0;
+  const int i0 = block_min_int(first, &s_red);
+  nfin = (unsigned)wave_sum_u64(nfin);
+  for (int a = 0; a < 3; ++a) { g[a] = wave_min_f(g[a]); g[3 + a] = wave_max_f(g[3 + a]); }
+  if (lane_id() == 0) {
+    atomicAdd(&s_nfin, nfin);
+    for (int a = 0; a < 6; ++a) s_g[a][wave_id()] = g[a];
+  }
+  __syncthreads();
+
+  if (i0 == 0x7fffffff) {  // no finite point: the reference drops the frame (impl.hpp:206-212)
+    if (threadIdx.x == 0) {
+      st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
+      st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
+      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->flagbit = 0; st->n_growth_events = 0;
+    }
+    return;
+  }
+
+  // ---- B: box from the first point (adoptBoundingBoxToPoint, empty-tree branch + getKeyBitSize) ----
+  if (threadIdx.x == 0) {
+    float p[3];
+    load_xyz(pv, (uint32_t)i0, p[0], p[1], p[2]);
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = __dsub_rn((double)p[a], __ddiv_rn(res, 2.0));
+      mx[a] = __dadd_rn((double)p[a], __ddiv_rn(res, 2.0));
+    }
+    unsigned max_voxels = 2;
+    for (int a = 0; a < 3; ++a) {
+      const unsigned k = (unsigned)ceil(__ddiv_rn(__dsub_rn(__dsub_rn(mx[a], mn[a]), eps), res));
+      max_voxels = max(max_voxels, k);
+    }
+    int depth = (int)ceil(__dsub_rn(log2((double)max_voxels), eps));
+    depth = min(depth, 32);
+    const double side = __dmul_rn((double)(1u << depth), res);
+    for (int a = 0; a < 3; ++a) {
+      const double over = __ddiv_rn(__dsub_rn(side, __dsub_rn(mx[a], mn[a])), 2.0);
+      if (over > eps) { mn[a] = __dsub_rn(mn[a], over); mx[a] = __dadd_rn(mx[a], over); }
+    }
+    for (int a = 0; a < 3; ++a) { s_mn[a] = mn[a]; s_mx[a] = mx[a]; ev_mn[0][a] = mn[a]; }
+    s_depth = depth;
+    ev_index[0] = i0; ev_lowered[0] = 0; ev_depth_before[0] = 0;
+    s_nev = 1;
+    s_err = kErrNone;
+  }
+  __syncthreads();
+
+  // ---- C: walk forward; only chunks whose AABB violates the current box are opened ----
+  int cur = i0 + 1;
+  int loaded = -1;
+  while (cur < (int)n) {
+    const double mn0 = s_mn[0], mn1 = s_mn[1], mn2 = s_mn[2];
+    const double mx0 = s_mx[0], mx1 = s_mx[1], mx2 = s_mx[2];
+    const int c0 = cur / kTile;
+    int cand = 0x7fffffff;
+    for (int c = c0 + (int)threadIdx.x; c < (int)n_chunks; c += kBlock) {
+      const ChunkBox b = boxes[c];
+      if (b.n_finite > 0) {
+        const bool viol = ((double)b.mn[0] < mn0) | ((double)b.mn[1] < mn1) | ((double)b.mn[2] < mn2) |
+                          ((double)b.mx[0] >= mx0) | ((double)b.mx[1] >= mx1) | ((double)b.mx[2] >= mx2);
+        if (viol) { cand = c; break; }  // ascending per thread: the first hit is this thread's minimum
+      }
+    }
+    const int cmin = block_min_int(cand, &s_red);
+    if (cmin == 0x7fffffff) break;  // everything that is left fits
+    if (cmin != loaded) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kItems; ++k) {
+        const int e = k * kBlock + (int)threadIdx.x;
+        const uint32_t i = (uint32_t)cmin * kTile + (uint32_t)e;
+        float x = __builtin_nanf(""), y = x, z = x;
+        if (i < n) {
+          load_xyz(pv, i, x, y, z);
+          if (!finite3(x, y, z)) { x = y = z = __builtin_nanf(""); }
+        }
+        s_p[0][e] = x; s_p[1][e] = y; s_p[2][e] = z;
+      }
+      loaded = cmin;
+      __syncthreads();
+    }
+    const int start_e = max(cur - cmin * kTile, 0);
+    int ce = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int e = k * kBlock + (int)threadIdx.x;
+      if (e >= start_e && ce == 0x7fffffff) {
+        const double x = (double)s_p[0][e], y = (double)s_p[1][e], z = (double)s_p[2][e];
+        const bool viol = (x < mn0) | (y < mn1) | (z < mn2) | (x >= mx0) | (y >= mx1) | (z >= mx2);
+        if (viol) ce = e;
+      }
+    }
+    const int emin = block_min_int(ce, &s_red);
+    if (emin == 0x7fffffff) {  // cannot happen for an exact AABB; stay safe
+      cur = (cmin + 1) * kTile;
+      continue;
+    }
+    if (threadIdx.x == 0) {
+      // grow until the point fits (adoptBoundingBoxToPoint, bounding_box_defined_ branch)
+      const double p[3] = {(double)s_p[0][emin], (double)s_p[1][emin], (double)s_p[2][emin]};
+      double mn[3] = {s_mn[0], s_mn[1], s_mn[2]}, mx[3] = {s_mx[0], s_mx[1], s_mx[2]};
+      int depth = s_depth, nev = s_nev;
+      for (;;) {
+        bool lo[3], up[3], any = false;
+        for (int a = 0; a < 3; ++a) { lo[a] = p[a] < mn[a]; up[a] = p[a] >= mx[a]; any |= lo[a] | up[a]; }
+        if (!any) break;
+        if (nev >= kMaxEpochs || depth >= 31) { s_err = kErrEpochs; break; }
+        double side = __dmul_rn((double)(1u << depth), res);
+        int lowered = 0;
+        for (int a = 0; a < 3; ++a)
+          if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
+        ev_depth_before[nev] = depth;
+        ++depth;
+        side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
+        for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
+        ev_index[nev] = cmin * kTile + emin;
+        ev_lowered[nev] = lowered;
+        for (int a = 0; a < 3; ++a) ev_mn[nev][a] = mn[a];
+        ++nev;
+      }
+      for (int a = 0; a < 3; ++a) { s_mn[a] = mn[a]; s_mx[a] = mx[a]; }
+      s_depth = depth; s_nev = nev;
+    }
+    __syncthreads();
+    if (s_err != kErrNone) break;
+    cur = cmin * kTile + emin + 1;
+  }
+  __syncthreads();
+
+  // ---- D: epoch table, sort geometry ----
+  if (threadIdx.x == 0) {
+    const int nev = s_nev, depth = s_depth;
+    int ne = 0;
+    for (int k = 0; k < nev; ++k) {
+      if (k + 1 < nev && ev_index[k + 1] == ev_index[k]) continue;  // same point grew the box again
+      unsigned shift[3] = {0, 0, 0};
+      for (int j = k + 1; j < nev; ++j)
+        for (int a = 0; a < 3; ++a)
+          if (ev_lowered[j] & (1 << a)) shift[a] += 1u << ev_depth_before[j];
+      st->ep_index[ne] = ev_index[k];
+      for (int a = 0; a < 3; ++a) { st->ep_mn[ne][a] = ev_mn[k][a]; st->ep_shift[ne][a] = shift[a]; }
+      ++ne;
+    }
+    st->n_epochs = ne;
+    st->n_growth_events = nev - 1;
+    st->depth = depth;
+    st->first_finite = i0;
+    st->n_finite = s_nfin;
+    for (int a = 0; a < 3; ++a) { st->mn[a] = s_mn[a]; st->mx[a] = s_mx[a]; }
+    int err = s_err;
+    if (depth > kMaxDepth) err = kErrDepth;
+
+    // varying key bits from the global AABB under the final origin, +-1 voxel of slack
+    float gmin[3], gmax[3];
+    for (int a = 0; a < 3; ++a) {
+      gmin[a] = FLT_MAX; gmax[a] = -FLT_MAX;
+      for (int w = 0; w < kBlock / 64; ++w) { gmin[a] = fminf(gmin[a], s_g[a][w]); gmax[a] = fmaxf(gmax[a], s_g[3 + a][w]); }
+    }
+    int vb = 0;
+    unsigned kmin[3], kmax[3];
+    const unsigned klim = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u);
+    for (int a = 0; a < 3; ++a) {
+      const double lo = __ddiv_rn(__dsub_rn((double)gmin[a], s_mn[a]), res);
+      const double hi = __ddiv_rn(__dsub_rn((double)gmax[a], s_mn[a]), res);
+      unsigned kl = lo > 0.0 ? (unsigned)lo : 0u;
+      unsigned kh = hi > 0.0 ? (unsigned)hi : 0u;
+      kl = kl > 0 ? kl - 1 : 0;
+      kh = kh < klim ? kh + 1 : klim;
+      kmin[a] = kl; kmax[a] = kh;
+      const unsigned x = kl ^ kh;
+      const int nb = x ? 32 - __clz((int)x) : 0;
+      vb = max(vb, nb);
+    }
+    for (int a = 0; a < 3; ++a) st->prefix[a] = vb >= 32 ? 0u : ((kmin[a] >> vb) << vb);
+    const int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
+    const int flag = s_nfin < n ? 1 : 0;
+    st->vbits_axis = vb;
+    st->vbits = 3 * vb;
+    st->ibits = ibits;
+    st->flagbit = flag;
+    st->npasses = (3 * vb + flag + kRadixBits - 1) / kRadixBits;
+    if (err == kErrNone && 3 * vb + flag + ibits > 64) err = kErrKeyBits;
+    if (err != kErrNone) st->npasses = 0;
+    st->error = err;
+    st->n_leaves = 0;
+    st->n_branches = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 2: octree keys (P3) -> packed sort keys  [flag | morton(vbits) | point index(ibits)]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_make_keys(PointView pv, uint32_t n, double res,
+                                                      FrameState* __restrict__ st, uint64_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int ne = st->n_epochs;
+  if (ne == 0 || st->error != kErrNone) return;
+  if (i >= n) return;
+  const int vb = st->vbits_axis, vbits = st->vbits, ibits = st->ibits;
+  float x, y, z;
+  load_xyz(pv, i, x, y, z);
+  uint64_t packed;
+  if (finite3(x, y, z) && (int)i >= st->ep_index[0]) {
+    int e = ne - 1;
+    if ((int)(blockIdx.x * kBlock) < st->ep_index[ne - 1]) {  // rare: block overlaps an earlier epoch
+      while (e > 0 && st->ep_index[e] > (int)i) --e;
+    }
+    const float p[3] = {x, y, z};
+    unsigned k[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double d = __ddiv_rn(__dsub_rn((double)p[a], st->ep_mn[e][a]), res);
+      k[a] = (unsigned)d + st->ep_shift[e][a];
+      ok &= vb >= 32 || ((k[a] >> vb) == (st->prefix[a] >> vb));
+    }
+    if (!ok) st->error = kErrKeyBits;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
+    const unsigned m = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
+    packed = (morton3(k[0] & m, k[1] & m, k[2] & m) << ibits) | (uint64_t)i;
+  } else {
+    packed = (1ull << (vbits + ibits)) | (uint64_t)i;  // non-finite: sorts behind every real key
+  }
+  keys[i] = packed;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 3: stable LSD radix sort of the packed keys, 8-bit digits over bits [ibits, ibits+vbits+flag)
+// Per pass: k_radix_hist (LDS-staged digit histogram per 2048-key tile) -> k_radix_scan (row
+// prefixes per digit) -> k_radix_scatter (wave ballot/popc ranking, stable).
+// Passes beyond st->npasses return at once, so the host never has to read the depth back.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ const uint64_t* pick_in(const FrameState* st, int pass, const uint64_t* a, const uint64_t* b) {
+  (void)st;
+  return (pass & 1) ? b : a;
+}
+
+__global__ __launch_bounds__(kBlock) void k_radix_hist(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                       uint32_t n, int pass, const FrameState* __restrict__ st,
+                                                       uint32_t n_tiles, uint32_t* __restrict__ ghist) {
+  if (pass >= st->npasses) return;
+  __shared__ uint32_t s_h[kRadixSize];
+  const uint64_t* in = pick_in(st, pass, buf_a, buf_b);
+  const int shift = st->ibits + pass * kRadixBits;
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kTile;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint32_t i = base + k * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&s_h[(in[i] >> shift) & (kRadixSize - 1)], 1u);
+  }
+  __syncthreads();
+  ghist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive prefix of that digit's counts over the tiles + digit total
+__global__ __launch_bounds__(kBlock) void k_radix_scan(int pass, const FrameState* __restrict__ st, uint32_t n_tiles,
+                                                       uint32_t* __restrict__ ghist, uint32_t* __restrict__ gtot) {
+  if (pass >= st->npasses) return;
+  __shared__ uint32_t s_w[kBlock / 64];
+  uint32_t* row = ghist + (size_t)blockIdx.x * n_tiles;
+  uint32_t carry = 0;
+  for (uint32_t c = 0; c < n_tiles; c += kBlock) {
+    const uint32_t j = c + threadIdx.x;
+    const uint32_t v = j < n_tiles ? row[j] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_u32(v, s_w, tot);
+    if (j < n_tiles) row[j] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) gtot[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                          uint64_t* __restrict__ out_a, uint64_t* __restrict__ out_b,
+                                                          uint32_t n, int pass, const FrameState* __restrict__ st,
+                                                          uint32_t n_tiles, const uint32_t* __restrict__ ghist,
+                                                          const uint32_t* __restrict__ gtot) {
+  if (pass >= st->npasses) return;
+  __shared__ uint32_t s_off[kRadixSize];          // global offset of this tile's first key per digit
+  __shared__ uint32_t s_cnt[kBlock / 64][kRadixSize];
+  __shared__ uint32_t s_run[kRadixSize];
+  __shared__ uint32_t s_w[kBlock / 64];
+  const uint64_t* in = pick_in(st, pass, buf_a, buf_b);
+  uint64_t* out = (pass & 1) ? out_a : out_b;  // ping-pong: pass 0 reads a writes b
+  const int shift = st->ibits + pass * kRadixBits;
+  const int lane = lane_id(), wave = wave_id();
+  const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+  {
+    uint32_t tot;
+    const uint32_t dbase = block_excl_scan_u32(gtot[threadIdx.x], s_w, tot);
+    s_off[threadIdx.x] = dbase + ghist[(size_t)threadIdx.x * n_tiles + blockIdx.x];
+    s_run[threadIdx.x] = 0;
+  }
+  const uint32_t base = blockIdx.x * kTile;
+  for (int k = 0; k < kItems; ++k) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = base + k * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    const uint64_t key = valid ? in[i] : 0ull;
+    const uint32_t d = (uint32_t)(key >> shift) & (kRadixSize - 1);
+    // lanes of this wave holding the same digit (8 ballots)
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+    if (valid && rank == 0) s_cnt[wave][d] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    {  // thread = digit: turn per-wave counts into per-wave start ranks (tile order = k, wave, lane)
+      const uint32_t dd = threadIdx.x;
+      uint32_t run = s_run[dd];
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) {
+        const uint32_t c = s_cnt[w][dd];
+        s_cnt[w][dd] = run;
+        run += c;
+      }
+      s_run[dd] = run;
+    }
+    __syncthreads();
+    if (valid) out[s_off[d] + s_cnt[wave][d] + rank] = key;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 4: leaves.  head(i) = code(i) != code(i-1);  t(j) = index of the highest 3-bit triple in
+// which leaf j differs from leaf j-1 (= number of branch nodes whose first leaf is j; t(0) = D).
+// One u64 scan carries both sums: low word = leaf id, high word = DFS byte offset (closed form
+// of the pre-order stream).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t head_t(uint64_t code, uint64_t prev, bool is_first, int depth) {
+  if (is_first) return ((uint64_t)depth << 32) | 1ull;
+  const uint64_t x = code ^ prev;
+  if (x == 0) return 0ull;
+  const int msb = 63 - __clzll((long long)x);
+  return ((uint64_t)(msb / 3) << 32) | 1ull;
+}
+
+__global__ __launch_bounds__(kBlock) void k_leaf_partials(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                          const FrameState* __restrict__ st, uint64_t* __restrict__ partials) {
+  __shared__ uint64_t s_w[kBlock / 64];
+  const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
+  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const int ibits = st->ibits, depth = st->depth;
+  const uint32_t i0 = blockIdx.x * kTile + threadIdx.x * kItems;
+  uint64_t acc = 0;
+  if (i0 < nfin) {
+    uint64_t prev = i0 ? (keys[i0 - 1] >> ibits) : 0ull;
+#pragma unroll
+    for (int e = 0; e < kItems; ++e) {
+      const uint32_t i = i0 + e;
+      if (i < nfin) {
+        const uint64_t code = keys[i] >> ibits;
+        acc += head_t(code, prev, i == 0, depth);
+        prev = code;
+      }
+    }
+  }
+  acc = wave_sum_u64(acc);
+  if (lane_id() == 0) s_w[wave_id()] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(kBlock) void k_leaf_scan_partials(uint32_t n_tiles, FrameState* __restrict__ st,
+                                                               uint64_t* __restrict__ partials, uint32_t* __restrict__ leaf_start) {
+  __shared__ uint64_t s_w[kBlock / 64];
+  uint64_t carry = 0;
+  for (uint32_t c = 0; c < n_tiles; c += kBlock) {
+    const uint32_t j = c + threadIdx.x;
+    const uint64_t v = j < n_tiles ? partials[j] : 0ull;
+    uint64_t tot;
+    const uint64_t ex = block_excl_scan_u64(v, s_w, tot);
+    if (j < n_tiles) partials[j] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t L = (uint32_t)(carry & 0xffffffffu);
+    st->n_leaves = L;
+    st->n_branches = (uint32_t)(carry >> 32);
+    leaf_start[L] = (st->error == kErrNone) ? st->n_finite : 0u;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_leaf_emit(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                      const FrameState* __restrict__ st, const uint64_t* __restrict__ partials,
+                                                      uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
+                                                      uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t) {
+  __shared__ uint64_t s_w[kBlock / 64];
+  const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
+  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const int ibits = st->ibits, depth = st->depth;
+  const uint32_t i0 = blockIdx.x * kTile + threadIdx.x * kItems;
+  if (blockIdx.x * kTile >= nfin) return;
+  uint64_t ht[kItems], code[kItems];
+  uint64_t acc = 0;
+  {
+    uint64_t prev = (i0 && i0 < nfin) ? (keys[i0 - 1] >> ibits) : 0ull;
+#pragma unroll
+    for (int e = 0; e < kItems; ++e) {
+      const uint32_t i = i0 + e;
+      ht[e] = 0; code[e] = 0;
+      if (i < nfin) {
+        code[e] = keys[i] >> ibits;
+        ht[e] = head_t(code[e], prev, i == 0, depth);
+        prev = code[e];
+      }
+      acc += ht[e];
+    }
+  }
+  uint64_t tot;
+  uint64_t ex = block_excl_scan_u64(acc, s_w, tot) + partials[blockIdx.x];
+#pragma unroll
+  for (int e = 0; e < kItems; ++e) {
+    if (ht[e] & 1ull) {
+      const uint32_t id = (uint32_t)(ex & 0xffffffffu);
+      leaf_start[id] = i0 + e;
+      leaf_code[id] = code[e];
+      leaf_base[id] = (uint32_t)(ex >> 32);
+      leaf_t[id] = (uint8_t)(ht[e] >> 32);
+    }
+    ex += ht[e];
+  }
+}
+
+// zero the DFS stream (B is only known on the device)
+__global__ __launch_bounds__(kBlock) void k_zero_occ(const FrameState* __restrict__ st, uint4* __restrict__ occ) {
+  const uint32_t nvec = (st->n_branches + 15u) / 16u + 1u;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += gridDim.x * kBlock) occ[i] = make_uint4(0, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 5: one thread per leaf: colour mean (P6), voxel centre / centroid (C2, C4), snake-mapped
+// image pixel (C3b), and the leaf's contributions to the occupancy bytes (P5).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void or_byte(uint8_t* occ, uint32_t off, uint32_t bits) {
+  atomicOr(reinterpret_cast<unsigned int*>(occ + (off & ~3u)), bits << (8u * (off & 3u)));
+}
+
+// SnakeGridIterator (snake.h:46-71) in closed form: linear element i -> pixel index, W multiple of 8
+__device__ __forceinline__ uint32_t snake_pos(uint32_t i, uint32_t W, uint32_t H) {
+  const uint32_t full = H / 8u, hl = H % 8u, per_row = W * 8u;
+  if (i < full * per_row) {
+    const uint32_t br = i / per_row, rem = i % per_row;
+    const uint32_t bw = rem / 64u, q = rem % 64u, r = q / 8u, c = q % 8u;
+    const uint32_t cc = (r & 1u) ? 7u - c : c;
+    return (br * 8u + r) * W + bw * 8u + cc;
+  }
+  // last, partial block row: hl rows per block; with an odd hl the direction flag is not reset
+  // between blocks, so every other block starts right-to-left (reference quirk, kept)
+  const uint32_t rem = i - full * per_row, blk = 8u * hl;
+  const uint32_t bw = rem / blk, q = rem % blk, r = q / 8u, c = q % 8u;
+  const uint32_t flip = (r + ((hl & 1u) ? bw : 0u)) & 1u;
+  const uint32_t cc = flip ? 7u - c : c;
+  return (full * 8u + r) * W + bw * 8u + cc;
+}
+
+__device__ __forceinline__ void leaf_colour(const PointView& pv, const uint64_t* keys, uint64_t imask, uint32_t s, uint32_t e,
+                                            uint32_t red, uint32_t& b, uint32_t& g, uint32_t& r) {
+  uint32_t s0 = 0, s1 = 0, s2 = 0;
+  for (uint32_t i = s; i < e; ++i) {
+    const uint32_t w = load_rgba(pv, (uint32_t)(keys[i] & imask));
+    s0 += w & 0xffu; s1 += (w >> 8) & 0xffu; s2 += (w >> 16) & 0xffu;
+  }
+  const uint32_t cnt = e - s;
+  if (cnt > 1) { s0 /= cnt; s1 /= cnt; s2 /= cnt; }
+  b = (s0 >> red) & 0xffu; g = (s1 >> red) & 0xffu; r = (s2 >> red) & 0xffu;
+}
+
+__global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double res, LeafParams lp,
+                                                          const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                          const FrameState* __restrict__ st,
+                                                          const uint32_t* __restrict__ leaf_start, const uint64_t* __restrict__ leaf_code,
+                                                          const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
+                                                          uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
+                                                          uint8_t* __restrict__ image, float4* __restrict__ simplified) {
+  const uint32_t L = st->n_leaves;
+  if (L == 0) return;
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const int ibits = st->ibits, D = st->depth;
+  const uint64_t imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
+  const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
+
+  if (j >= L) {
+    // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
+    if (lp.write_image && j < W * H) {
+      uint32_t b, g, r;
+      leaf_colour(pv, keys, imask, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
+      const uint32_t px = snake_pos(j, W, H);
+      image[3 * px] = (uint8_t)b; image[3 * px + 1] = (uint8_t)g; image[3 * px + 2] = (uint8_t)r;
+    }
+    return;
+  }
+
+  const uint32_t s = leaf_start[j], e = leaf_start[j + 1];
+  const uint64_t code = leaf_code[j];
+  const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
+  const uint64_t full = code | pfx;
+  const uint32_t key[3] = {compact3(full >> 2), compact3(full >> 1), compact3(full)};
+
+  uint32_t cb = 0, cg = 0, cr = 0;
+  if (lp.do_color) {
+    leaf_colour(pv, keys, imask, s, e, lp.color_reduction, cb, cg, cr);
+    bgr[3 * j] = (uint8_t)cb; bgr[3 * j + 1] = (uint8_t)cg; bgr[3 * j + 2] = (uint8_t)cr;
+    if (lp.write_image) {
+      const uint32_t px = snake_pos(j, W, H);
+      image[3 * px] = (uint8_t)cb; image[3 * px + 1] = (uint8_t)cg; image[3 * px + 2] = (uint8_t)cr;
+    }
+  }
+
+  // lower voxel corner (impl.hpp:1519-1521), then centre (impl.hpp:1560-1562) or centroid (:1566-1573)
+  double lc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) lc[a] = __dadd_rn(__dmul_rn((double)key[a], res), st->mn[a]);
+  float c[3];
+  if (!lp.do_centroid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
+  } else {
+    float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
+    for (uint32_t i = s; i < e; ++i) {
+      float x, y, z;
+      load_xyz(pv, (uint32_t)(keys[i] & imask), x, y, z);
+      sx = __fadd_rn(sx, x); sy = __fadd_rn(sy, y); sz = __fadd_rn(sz, z);
+    }
+    const float cnt = (float)(e - s);
+    c[0] = __fdiv_rn(sx, cnt); c[1] = __fdiv_rn(sy, cnt); c[2] = __fdiv_rn(sz, cnt);
+    const double prec = (double)0.001f;  // PointCoding default precision (ptv2.h:89-91)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
+      d = max(-127, min(127, d));
+      centroid[3 * j + a] = (uint8_t)d;
+    }
+  }
+  if (simplified) {
+    const uint32_t rgba = cb | (cg << 8) | (cr << 16) | 0xff000000u;
+    simplified[j] = make_float4(c[0], c[1], c[2], __uint_as_float(rgba));
+  }
+
+  // occupancy: the t(j) branch nodes this leaf opens sit at base(j).. in the stream; each gets the
+  // child bit on this leaf's path.  The topmost one is itself a new child of an older node.
+  const int t = leaf_t[j];
+  const uint32_t base = leaf_base[j];
+  for (int q = 0; q < t; ++q) {
+    const int level = D - t + q;
+    const uint32_t child = (uint32_t)(full >> (3 * (D - 1 - level))) & 7u;
+    or_byte(occ, base + (uint32_t)q, 1u << child);
+  }
+  if (j > 0) {
+    const int m = t;
+    const uint32_t child = (uint32_t)(full >> (3 * m)) & 7u;
+    const int sh = 3 * (m + 1);
+    const uint64_t pcode = sh >= 64 ? 0ull : ((code >> sh) << sh);
+    uint32_t lo = 0, hi = j;  // first leaf f in [0, j) with leaf_code[f] >= pcode
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (leaf_code[mid] < pcode) lo = mid + 1; else hi = mid;
+    }
+    const int tf = leaf_t[lo];
+    const uint32_t off = leaf_base[lo] + (uint32_t)((D - m - 1) - (D - tf));
+    or_byte(occ, off, 1u << child);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch sequence
+// ------------------------------------------------------------------------------------------
+#define PCC_STAMP(name)                                      \
+  do {                                                       \
+    if (tm) tm->stamp(name, stream);                         \
+  } while (0)
+
+void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) {
+  const uint32_t n = a.n;
+  const uint32_t n_tiles = (n + kTile - 1) / kTile;
+  const uint32_t n_blocks = (n + kBlock - 1) / kBlock;
+  PCC_STAMP("begin");
+  hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes);
+  PCC_STAMP("k_chunk_boxes");
+  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.state);
+  PCC_STAMP("k_bbox_events");
+  hipLaunchKernelGGL(k_make_keys, dim3(n_blocks), dim3(kBlock), 0, stream, a.pv, n, a.res, a.state, a.keys_a);
+  PCC_STAMP("k_make_keys");
+  for (int pass = 0; pass < a.max_passes; ++pass) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, n, pass, a.state, n_tiles, a.ghist);
+    PCC_STAMP("k_radix_hist");
+    hipLaunchKernelGGL(k_radix_scan, dim3(kRadixSize), dim3(kBlock), 0, stream, pass, a.state, n_tiles, a.ghist, a.gtot);
+    PCC_STAMP("k_radix_scan");
+    hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, n, pass,
+                       a.state, n_tiles, a.ghist, a.gtot);
+    PCC_STAMP("k_radix_scatter");
+  }
+  hipLaunchKernelGGL(k_leaf_partials, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.state, a.partials);
+  PCC_STAMP("k_leaf_partials");
+  hipLaunchKernelGGL(k_leaf_scan_partials, dim3(1), dim3(kBlock), 0, stream, n_tiles, a.state, a.partials, a.leaf_start);
+  PCC_STAMP("k_leaf_scan_partials");
+  hipLaunchKernelGGL(k_leaf_emit, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.state, a.partials, a.leaf_start,
+                     a.leaf_code, a.leaf_base, a.leaf_t);
+  PCC_STAMP("k_leaf_emit");
+  hipLaunchKernelGGL(k_zero_occ, dim3(512), dim3(kBlock), 0, stream, a.state, reinterpret_cast<uint4*>(a.occ));
+  PCC_STAMP("k_zero_occ");
+  const uint32_t fin_blocks = (n + 256u + kBlock - 1) / kBlock;  // leaves + up to 256 padding pixels
+  hipLaunchKernelGGL(k_leaf_finalize, dim3(fin_blocks), dim3(kBlock), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.state,
+                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
+                     reinterpret_cast<float4*>(a.simplified));
+  PCC_STAMP("k_leaf_finalize");
+}
+
+}  // namespace pcc

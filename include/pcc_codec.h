@@ -1,0 +1,171 @@
+/*
+ * pcc_codec.h -- C ABI of libpcc_hip.so: the MI355X-native intra-frame hot path of the
+ * CWI point-cloud codec (cwi-dis/cwi-pcl-codec).
+ *
+ * The reference has no plugin / FFI layer: its boundary is the C++ class template
+ * pcl::io::OctreePointCloudCodecV2<PointT> (codec.h:70-368, instantiated once at
+ * cloud_codec_v2/src/point_cloud_codec_v2.cpp:45).  The drop-in is therefore a
+ * same-named header-only C++ shim (cwi-pcl-codec_amd/shim/) whose methods forward to
+ * the entry points below; INTEGRATION.md shows the binding.  Everything that crosses
+ * this boundary is plain C: pointers, sizes, PODs.  No C++ or torch types.
+ *
+ * Reference file abbreviations (relative to /root/reference):
+ *   codec.h  = cloud_codec_v2/include/pcl/cloud_codec_v2/point_cloud_codec_v2.h
+ *   impl.hpp = cloud_codec_v2/include/pcl/cloud_codec_v2/impl/point_cloud_codec_v2_impl.hpp
+ *   eval.hpp = apps/evaluate_compression/include/pcl/apps/evaluate_compression/impl/evaluate_compression_impl.hpp
+ *
+ * Threading: a pcc_ctx is bound to one GPU and one HIP stream and is not re-entrant
+ * (like the reference's codec object, which holds per-frame state).  Contexts share
+ * nothing, so "one frame per GPU" is just N contexts on N host threads.
+ * Ownership: input buffers are caller-owned; every pointer returned in an out-struct
+ * is library-owned and stays valid until the next call on the same context.
+ * Errors: every call returns PCC_OK (0) or a negative code; pcc_last_error() gives text.
+ */
+#ifndef PCC_CODEC_H
+#define PCC_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCC_OK 0
+#define PCC_ERR_ARG (-1)        /* bad argument */
+#define PCC_ERR_HIP (-2)        /* a HIP runtime call failed (no GPU, OOM, ...) */
+#define PCC_ERR_EMPTY (-3)      /* no finite input point: the reference drops the frame (impl.hpp:206-212) */
+#define PCC_ERR_UNSUPPORTED (-4) /* depth > 21 or key+index bits > 64 */
+#define PCC_ERR_STREAM (-5)     /* decode: header not found / truncated / corrupt */
+#define PCC_ERR_STATE (-6)      /* call order (finish without launch, ...) */
+
+typedef struct pcc_ctx pcc_ctx;
+
+/* pcl::PointXYZRGB as the reference lays it out: 32 bytes, colour word at offset 16. */
+typedef struct pcc_point_xyzrgb {
+  float x, y, z, w;
+  uint32_t rgba; /* b | g<<8 | r<<16 | a<<24 */
+  uint32_t pad[3];
+} pcc_point_xyzrgb;
+
+/* Codec configuration: the arguments of the reference constructor (codec.h:108-121, as
+ * called at eval.hpp:377-395) plus the two setters the app uses (codec.h:149,164). */
+typedef struct pcc_params {
+  double octree_resolution;      /* octreeResolution_arg */
+  double point_resolution;       /* pointResolution_arg (written to the header) */
+  int32_t do_color_encoding;     /* doColorEncoding_arg */
+  int32_t color_bit_resolution;  /* colorBitResolution_arg */
+  int32_t color_coding_type;     /* colorCodingType_arg: 0 PCL, 1 JPEG snake, 2 JPEG lines, 3 raw */
+  int32_t do_voxel_centroid;     /* doVoxelGridCentroid_arg */
+  int32_t create_scalable;       /* createScalableStream_arg (header flag only) */
+  int32_t do_connectivity;       /* codeConnectivity_arg (header flag only) */
+  int32_t jpeg_quality;          /* jpeg_quality_arg */
+  int32_t macroblock_size;       /* setMacroblockSize (header field) */
+  int32_t do_icp_color_offset;   /* setDoICPColorOffset(bool) (header flag) */
+  uint32_t frame_id;             /* value of frame_ID_ after the ++ at impl.hpp:133 */
+} pcc_params;
+
+/* What the GPU stage hands to the host entropy stage (all host pointers). */
+typedef struct pcc_hot_result {
+  double bbox[6];            /* adaptive bounding box: min xyz, max xyz (header bytes) */
+  uint32_t depth;            /* final octree depth D */
+  uint32_t n_epochs;         /* bounding-box growth epochs seen */
+  uint64_t n_points_in;      /* finite input points (object_count_) */
+  uint64_t n_leaves;         /* L = occupied voxels = point_count_ in the header */
+  uint64_t n_branches;       /* B = occupancy bytes */
+  const uint8_t *occupancy;  /* B bytes, depth-first pre-order (serializeTree) */
+  const uint8_t *bgr;        /* 3L bytes (b,g,r) per voxel in leaf order; NULL if no colour */
+  const uint8_t *centroid;   /* 3L bytes; NULL unless do_voxel_centroid */
+  const uint8_t *image;      /* snake-mapped 3*W*H image (color_coding_type 1), else NULL */
+  uint32_t image_w, image_h;
+  float gpu_ms;              /* HIP-event time of the kernel sequence */
+} pcc_hot_result;
+
+typedef struct pcc_bitstream {
+  const uint8_t *data;
+  size_t len;
+  uint64_t perf[3];          /* getPerformanceMetrics(): octree, centroid, colour bytes (codec.h:193-197) */
+} pcc_bitstream;
+
+typedef struct pcc_cloud {
+  const pcc_point_xyzrgb *points;
+  size_t n;
+  pcc_params params;         /* as recovered from the frame header */
+  double bbox[6];
+  uint32_t depth;
+  size_t consumed;           /* bytes of the input consumed */
+} pcc_cloud;
+
+/* Per-kernel timing of the last hot-path run (HIP events on the context's stream). */
+#define PCC_MAX_KERNEL_TIMES 64
+typedef struct pcc_kernel_times {
+  int32_t count;
+  const char *name[PCC_MAX_KERNEL_TIMES];
+  float ms[PCC_MAX_KERNEL_TIMES];
+} pcc_kernel_times;
+
+/* ---- lifetime ---- */
+pcc_ctx *pcc_create(int device);                 /* replaces `new OctreePointCloudCodecV2` (eval.hpp:377) */
+/* A context without a GPU: only the host stages work on it (pcc_entropy_encode, pcc_decode_intra).
+ * Every GPU entry point returns PCC_ERR_STATE -- there is no CPU fallback for the hot path. */
+pcc_ctx *pcc_create_host(void);
+void pcc_destroy(pcc_ctx *ctx);
+const char *pcc_last_error(pcc_ctx *ctx);
+const char *pcc_version(void);
+
+/* ---- encodePointCloud (codec.h:174-175, impl.hpp:80-213) ----
+ * One call = one I-frame: H2D of the caller's cloud, GPU hot path, host entropy stage. */
+int pcc_encode_intra(pcc_ctx *ctx, const void *host_points, size_t n, size_t stride, size_t rgb_offset,
+                     const pcc_params *params, pcc_bitstream *out);
+
+/* Same with the cloud already resident in HBM (bench / pipelines). */
+int pcc_encode_intra_device(pcc_ctx *ctx, const void *dev_points, size_t n, size_t stride, size_t rgb_offset,
+                            const pcc_params *params, pcc_bitstream *out);
+
+/* ---- the three stages of encodePointCloud, separately (for overlap across frames) ---- */
+/* addPointsFromInputCloud + serializeTree + leaf callbacks (impl.hpp:99,166,1509-1578) on the GPU; asynchronous. */
+int pcc_hotpath_launch(pcc_ctx *ctx, const void *dev_points, size_t n, size_t stride, size_t rgb_offset,
+                       const pcc_params *params);
+/* wait for the kernels, bring occupancy bytes / colour image / centroid bytes to the host */
+int pcc_hotpath_finish(pcc_ctx *ctx, pcc_hot_result *out);
+/* writeFrameHeader + entropyEncoding (impl.hpp:175-178, 1472-1486, 1682-1760): host only, no GPU calls;
+ * may run on another thread while the context's GPU stage works on the next frame IF `ctx_for_output`
+ * is a different context (the bitstream is stored there). */
+int pcc_entropy_encode(pcc_ctx *ctx_for_output, const pcc_hot_result *hot, const pcc_params *params,
+                       pcc_bitstream *out);
+
+/* getOutputCloud() (eval.hpp:862): the simplified cloud of the last encode, L points (impl.hpp:1576). */
+int pcc_get_output_cloud(pcc_ctx *ctx, const pcc_point_xyzrgb **points, size_t *n);
+
+/* ---- decodePointCloud (codec.h:177-178, impl.hpp:224-310) ---- */
+int pcc_decode_intra(pcc_ctx *ctx, const uint8_t *stream, size_t len, pcc_cloud *out);
+
+/* ---- helpers around the path ---- */
+/* device memory for callers that keep clouds resident (bench, multi-frame pipelines) */
+int pcc_device_alloc(pcc_ctx *ctx, size_t bytes, void **dev_ptr);
+int pcc_device_free(pcc_ctx *ctx, void *dev_ptr);
+int pcc_device_upload(pcc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int pcc_get_kernel_times(pcc_ctx *ctx, pcc_kernel_times *out);
+/* enable per-kernel HIP-event timing (off by default: events between launches cost a little) */
+int pcc_set_profiling(pcc_ctx *ctx, int enabled);
+
+/* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
+/* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).
+ * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */
+size_t pcc_host_range_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap);
+size_t pcc_host_range_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t n);
+/* JPEGWriter::writeJPEG / JPEGReader::readJPEG (jpeg_io.hpp:211-330 / 90-192), RGB, 4:2:0 */
+size_t pcc_host_jpeg_encode(const uint8_t *rgb, int w, int h, int quality, uint8_t *out, size_t out_cap);
+int pcc_host_jpeg_decode(const uint8_t *jpg, size_t len, uint8_t *rgb, size_t rgb_cap, int *w, int *h);
+/* SnakeGridMapping iterator position (snake_grid_mapping.h:46-71) in closed form */
+uint32_t pcc_host_snake_position(uint32_t i, uint32_t w, uint32_t h);
+
+/* normalize_pointclouds / restore_scaling for one group (codec.h:216-227, impl.hpp:1871-1986), host side */
+int pcc_normalize_group(pcc_point_xyzrgb **clouds, const size_t *sizes, size_t n_clouds, double bb_expand_factor,
+                        float bb_min[3], float bb_max[3]);
+int pcc_restore_scaling(pcc_point_xyzrgb *cloud, size_t n, const float bb_min[3], const float bb_max[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_CODEC_H */

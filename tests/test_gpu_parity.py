@@ -1,0 +1,297 @@
+"""Parity tests proper: the HIP hot path (through the C ABI) against the CPU oracle.
+
+Integer / byte / index work: bit-exact.  The only floating point in the path is fp64 key
+arithmetic and fp32 voxel centres / centroids, all individually rounded: also bit-exact.
+"""
+import numpy as np
+import pytest
+
+import sortform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.binding.Context(0)
+    yield c
+    c.close()
+
+
+def cloud(pkg, xyz, rgb=None, seed=0):
+    xyz = np.asarray(xyz, dtype=np.float32)
+    pts = np.zeros(len(xyz), dtype=pkg.binding.POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts["w"] = 1.0
+    if rgb is None:
+        rgb = np.random.default_rng(seed).integers(0, 256, (len(xyz), 3))
+    rgb = np.asarray(rgb, dtype=np.uint32)
+    pts["rgba"] = rgb[:, 2] | (rgb[:, 1] << 8) | (rgb[:, 0] << 16) | np.uint32(0xFF000000)
+    return pts
+
+
+def run_gpu(ctx, pts, params, stride=32, rgb_offset=16, raw=None):
+    dev = ctx.upload(pts if raw is None else raw)
+    try:
+        ctx.hotpath_launch(dev, len(pts), params, stride=stride, rgb_offset=rgb_offset)
+        hot = ctx.hotpath_finish()
+        stream, perf = ctx.entropy_encode(hot.raw, params)
+        simplified = ctx.output_cloud()
+    finally:
+        ctx.free(dev)
+    return hot, stream, perf, simplified
+
+
+def assert_matches_oracle(pkg, oracle, ctx, pts, **kw):
+    po = oracle.make_params(**kw)
+    pg = pkg.binding.make_params(**kw)
+    want = oracle.encode_intra(pts, po)
+    hot, stream, perf, simplified = run_gpu(ctx, pts, pg)
+    assert hot.depth == want.depth
+    assert np.array_equal(hot.bbox, want.bbox)
+    assert (hot.n_points_in, hot.n_leaves, hot.n_branches) == (want.n_points_in, want.n_leaves, want.n_branches)
+    assert np.array_equal(hot.occupancy, want.occupancy)
+    assert np.array_equal(hot.bgr, want.bgr)
+    assert np.array_equal(hot.centroid_bytes, want.centroid_bytes)
+    if kw.get("color_coding_type", 1) == 1 and kw.get("color_bits", 8) > 0:
+        assert (hot.image_w, hot.image_h) == (want.image_w, want.image_h)
+        assert np.array_equal(hot.snake_image, want.snake_image)
+    assert simplified.tobytes() == want.simplified.tobytes()
+    assert stream == want.bitstream
+    assert perf == want.perf
+    return hot, want
+
+
+# ---------------- micro cases (the reference's edge cases) ----------------
+
+def test_appendix_f_worked_example(pkg, oracle, ctx):
+    xyz = [(0.50, 0.50, 0.50), (0.60, 0.40, 0.52), (0.95, 0.10, 0.50), (0.50, 0.50, 0.51)]
+    pts = cloud(pkg, xyz, rgb=[(3, 1, 0), (33, 21, 10), (63, 41, 20), (8, 2, 1)])
+    hot, _ = assert_matches_oracle(pkg, oracle, ctx, pts, octree_resolution=0.25, point_resolution=0.25,
+                                   color_coding_type=0)
+    assert hot.occupancy.tolist() == [0x28, 0xA0, 0x08] and hot.depth == 2
+
+
+def test_single_point(pkg, oracle, ctx):
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, [(0.3, 0.4, 0.5)]), octree_bits=4)
+
+
+def test_two_points_one_growth(pkg, oracle, ctx):
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, [(0.3, 0.4, 0.5), (0.9, 0.4, 0.5)]), octree_bits=6,
+                          color_coding_type=0)
+
+
+def test_growth_every_direction(pkg, oracle, ctx):
+    xyz = [(0.5, 0.5, 0.5), (0.9, 0.5, 0.5), (0.1, 0.5, 0.5), (0.5, 0.9, 0.5), (0.5, 0.1, 0.5),
+           (0.5, 0.5, 0.9), (0.5, 0.5, 0.1), (0.95, 0.95, 0.95), (0.02, 0.02, 0.02)]
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_bits=5, color_coding_type=0)
+
+
+def test_empty_and_all_nan_are_dropped(pkg, ctx):
+    b = pkg.binding
+    for pts in (np.zeros(0, dtype=b.POINT_DTYPE), cloud(pkg, [(np.nan, 0, 0), (0, np.inf, 0), (1, 1, -np.inf)])):
+        with pytest.raises(b.PccError) as e:
+            ctx.encode_intra_host(pts, b.make_params())
+        assert e.value.code == -3  # PCC_ERR_EMPTY: the reference drops the frame (impl.hpp:206-212)
+
+
+def test_nan_points_are_skipped(pkg, oracle, ctx):
+    rng = np.random.default_rng(8)
+    xyz = rng.uniform(0.2, 0.8, (5000, 3)).astype(np.float32)
+    xyz[rng.integers(0, 5000, 700), rng.integers(0, 3, 700)] = np.nan
+    xyz[rng.integers(0, 5000, 50), 0] = np.inf
+    xyz[0] = np.nan  # the first points are not finite either
+    xyz[1] = -np.inf
+    hot, want = assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_bits=7)
+    assert hot.n_points_in < 5000
+
+
+def test_duplicates_and_colour_mean_truncation(pkg, oracle, ctx):
+    base = np.random.default_rng(4).uniform(0.3, 0.7, (300, 3)).astype(np.float32)
+    xyz = np.repeat(base, 7, axis=0)  # 7 identical points per voxel, different colours
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz, seed=1), octree_bits=8, color_coding_type=0)
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz, seed=2), octree_bits=8, color_coding_type=0, keep_centroid=1)
+
+
+def test_points_on_voxel_boundaries(pkg, oracle, ctx):
+    g = (np.arange(0, 64, dtype=np.float32) / 64.0)
+    xyz = np.stack(np.meshgrid(g[::4], g[::4], g[::8], indexing="ij"), -1).reshape(-1, 3)
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_bits=6, color_coding_type=0)
+
+
+@pytest.mark.parametrize("res", [0.01, 0.0037, 0.37, 1.0 / 3.0])
+def test_non_power_of_two_resolution(pkg, oracle, ctx, res):
+    """fp64 key arithmetic must round exactly like the reference (no FMA contraction, true division)."""
+    rng = np.random.default_rng(int(res * 1e6))
+    sc = 40.0 * res
+    xyz = (rng.normal(size=(20000, 3)) * sc + rng.normal(size=3) * sc).astype(np.float32)
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_resolution=res, point_resolution=res,
+                          color_coding_type=0, keep_centroid=1)
+
+
+def test_sorted_input_spreads_growth_events(pkg, oracle, ctx):
+    """Scan-line ordered clouds grow the box late and across many chunks."""
+    rng = np.random.default_rng(12)
+    xyz = rng.uniform(0.0, 1.0, (60000, 3)).astype(np.float32)
+    xyz = xyz[np.lexsort((xyz[:, 2], xyz[:, 1], xyz[:, 0]))]
+    hot, _ = assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_bits=8)
+    assert hot.n_epochs >= 3  # several distinct points grow the box, not just the first few
+
+
+def test_large_coordinates_and_deep_tree(pkg, oracle, ctx):
+    rng = np.random.default_rng(13)
+    xyz = (rng.uniform(-1, 1, (30000, 3)) * 100.0 + 300.0).astype(np.float32)
+    hot, _ = assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_resolution=0.01, point_resolution=0.01,
+                                   color_coding_type=0)
+    assert hot.depth >= 15
+
+
+def test_unaligned_stride_and_colour_offset(pkg, oracle, ctx):
+    """pcc_encode_* takes stride / rgb_offset: a packed 16-byte XYZ+RGBA layout must give the same frame."""
+    pts = pkg.synthetic.sphere_shell(20000, 31)
+    packed = np.zeros(len(pts), dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")]))
+    for f in ("x", "y", "z", "rgba"):
+        packed[f] = pts[f]
+    kw = dict(octree_bits=8, color_coding_type=1)
+    want = oracle.encode_intra(pts, oracle.make_params(**kw))
+    pg = pkg.binding.make_params(**kw)
+    dev = ctx.upload(packed)
+    ctx.hotpath_launch(dev, len(pts), pg, stride=16, rgb_offset=12)
+    hot = ctx.hotpath_finish()
+    stream, _ = ctx.entropy_encode(hot.raw, pg)
+    ctx.free(dev)
+    assert stream == want.bitstream
+    # 20-byte stride: not 16-byte aligned -> scalar load path
+    odd = np.zeros(len(pts), dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("q", "<f4"), ("rgba", "<u4")]))
+    for f in ("x", "y", "z", "rgba"):
+        odd[f] = pts[f]
+    dev = ctx.upload(odd)
+    ctx.hotpath_launch(dev, len(pts), pg, stride=20, rgb_offset=16)
+    hot = ctx.hotpath_finish()
+    stream, _ = ctx.entropy_encode(hot.raw, pg)
+    ctx.free(dev)
+    assert stream == want.bitstream
+
+
+def test_bad_arguments(pkg, ctx):
+    b = pkg.binding
+    pts = pkg.synthetic.sphere_shell(100, 1)
+    dev = ctx.upload(pts)
+    with pytest.raises(b.PccError) as e:
+        ctx.hotpath_launch(dev, 100, b.make_params(), stride=8)
+    assert e.value.code == -1
+    with pytest.raises(b.PccError) as e:
+        ctx.hotpath_launch(dev, 100, b.make_params(octree_resolution=0.0))
+    assert e.value.code == -1
+    with pytest.raises(b.PccError) as e:
+        ctx.hotpath_finish()
+    assert e.value.code == -6
+    ctx.free(dev)
+
+
+# ---------------- all coding modes ----------------
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("centroid", [0, 1])
+def test_modes_bitstream_identical(pkg, oracle, ctx, mode, centroid):
+    pts = pkg.synthetic.sphere_shell(30000, 0x40 + mode)
+    assert_matches_oracle(pkg, oracle, ctx, pts, octree_bits=7, color_bits=6 if mode == 0 else 8,
+                          color_coding_type=mode, keep_centroid=centroid, jpeg_quality=75)
+
+
+def test_geometry_only(pkg, oracle, ctx):
+    assert_matches_oracle(pkg, oracle, ctx, pkg.synthetic.uniform_volume(40000, 3), octree_bits=7, color_bits=0)
+
+
+@pytest.mark.parametrize("L", [255, 256, 257, 2047, 2048, 2049, 4096 + 8 * 256])
+def test_snake_image_heights(pkg, oracle, ctx, L):
+    """Image height H = L/256 + 1 hits full block rows, odd partial rows and the 256 | L extra row."""
+    g = np.arange(L, dtype=np.float32)
+    xyz = np.stack([(g % 64) / 64.0, ((g // 64) % 64) / 64.0, (g // 4096) / 64.0], 1) + 1.0 / 256
+    hot, want = assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, xyz), octree_bits=6, color_coding_type=1)
+    assert hot.n_leaves == L
+
+
+# ---------------- BASELINE.json configurations ----------------
+
+def test_cfg1_100k_depth8(pkg, oracle, ctx):
+    pts = pkg.synthetic.make_frame("cfg1")
+    assert_matches_oracle(pkg, oracle, ctx, pts, octree_bits=8, color_bits=8, color_coding_type=1, jpeg_quality=85)
+
+
+def test_cfg2_1m_depth10_surface(pkg, oracle, ctx):
+    pts = pkg.synthetic.make_frame("cfg2")
+    hot, _ = assert_matches_oracle(pkg, oracle, ctx, pts, octree_bits=10, color_bits=8, color_coding_type=1,
+                                   jpeg_quality=85)
+    assert hot.n_points_in == 1_000_000
+
+
+def test_cfg2_1m_depth10_uniform(pkg, oracle, ctx):
+    pts = pkg.synthetic.make_frame("cfg2u")
+    assert_matches_oracle(pkg, oracle, ctx, pts, octree_bits=10, color_bits=8, color_coding_type=1, jpeg_quality=85)
+
+
+def test_cfg3_gop_of_8_frames(pkg, oracle, ctx):
+    """GOP=8 intra-only: frame ids 1..8, every frame an independent I-frame (reduced to 100k points/frame)."""
+    enc = pkg.binding.OctreePointCloudCodecV2(pkg.binding.MANUAL_CONFIGURATION, False, 2.0 ** -10, 2.0 ** -10, True, 0,
+                                              True, 8, 1, False, False, False, 85, 1)
+    for f in range(8):
+        pts = pkg.synthetic.make_frame("cfg3", frame=f, n=100_000)
+        stream = enc.encodePointCloud(pts)
+        want = oracle.encode_intra(pts, oracle.make_params(octree_bits=10, jpeg_quality=85, frame_id=f + 1), keep=False)
+        assert stream == want.bitstream
+        assert enc.getPerformanceMetrics() == want.perf
+
+
+def test_cfg4_reduced_parity_and_full_size_properties(pkg, oracle, ctx):
+    # parity at 1M points with cfg4's settings (depth 12, geometry only)
+    pts = pkg.synthetic.make_frame("cfg4", n=1_000_000)
+    assert_matches_oracle(pkg, oracle, ctx, pts, octree_bits=12, color_bits=0)
+    # the full 10M-point frame through size-independent properties
+    pts = pkg.synthetic.make_frame("cfg4")
+    pg = pkg.binding.make_params(octree_bits=12, color_bits=0)
+    hot, stream, perf, simplified = run_gpu(ctx, pts, pg)
+    assert hot.n_points_in == len(pts)
+    pop = int(np.unpackbits(hot.occupancy).sum())
+    assert pop == hot.n_branches - 1 + hot.n_leaves          # every non-root node is somebody's child bit
+    assert (hot.occupancy != 0).all()                         # no branch node without children
+    dec, info = ctx.decode_intra(stream)                      # own decoder rebuilds exactly L leaves ...
+    assert len(dec) == hot.n_leaves and info["consumed"] == len(stream)
+    for a in "xyz":                                           # ... at the encoder's voxel centres
+        assert np.array_equal(dec[a], simplified[a])
+    keys = np.stack([dec[a].astype(np.float64) for a in "xyz"], 1)
+    res = 2.0 ** -12
+    k = np.floor((keys - hot.bbox[:3]) / res).astype(np.uint64)
+    code = sortform.morton(k, hot.depth)
+    assert (np.diff(code.astype(np.int64)) > 0).all()        # leaves strictly ascending in Morton order
+    # every input point falls in an encoded voxel (encode -> decode covers the input)
+    pk = np.floor((np.stack([pts[a].astype(np.float64) for a in "xyz"], 1)[::997] - hot.bbox[:3]) / res).astype(np.uint64)
+    pc = sortform.morton(pk, hot.depth)
+    assert np.isin(pc, code).all()
+
+
+# ---------------- the mirrored class interface ----------------
+
+def test_codec_class_round_trip(pkg, oracle):
+    b = pkg.binding
+    enc = b.OctreePointCloudCodecV2(b.MANUAL_CONFIGURATION, False, 2.0 ** -9, 2.0 ** -9, True, 0, True, 8, 1, False,
+                                    False, False, 85, 1)
+    dec = b.OctreePointCloudCodecV2(b.MANUAL_CONFIGURATION, False, 2.0 ** -9, 2.0 ** -9, True, 0, True, 8, 1, False,
+                                    False, False, 85, 1)
+    pts = pkg.synthetic.sphere_shell(50_000, 0x99)
+    assert enc.encodePointCloud(np.zeros(0, dtype=b.POINT_DTYPE)) == b""   # dropped, frame id not advanced
+    stream = enc.encodePointCloud(pts)
+    want = oracle.encode_intra(pts, oracle.make_params(octree_bits=9, jpeg_quality=85, frame_id=1))
+    assert stream == want.bitstream and enc.getPerformanceMetrics() == want.perf
+    out, used = dec.decodePointCloud(stream)
+    ref = oracle.decode_intra(stream)
+    assert used == len(stream) and out.tobytes() == ref.points.tobytes()
+    assert enc.getOutputCloud().tobytes() == want.simplified.tobytes()
+    # colour PSNR of decoded vs encoder-side per-voxel colours: same number as the oracle's decode (<= 0.01 dB apart)
+    def psnr(a, bb):
+        mse = np.mean((a.astype(np.float64) - bb) ** 2)
+        return 10 * np.log10(255.0 ** 2 / mse)
+    enc_bgr = want.bgr.reshape(-1, 3)
+    got = np.stack([out["rgba"] & 0xFF, (out["rgba"] >> 8) & 0xFF, (out["rgba"] >> 16) & 0xFF], 1)
+    exp = np.stack([ref.points["rgba"] & 0xFF, (ref.points["rgba"] >> 8) & 0xFF, (ref.points["rgba"] >> 16) & 0xFF], 1)
+    assert abs(psnr(got, enc_bgr) - psnr(exp, enc_bgr)) <= 0.01

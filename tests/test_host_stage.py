@@ -1,0 +1,153 @@
+"""Host stages of the product library (serial by design) against the oracle, and the C ABI surface.
+
+No GPU work is launched here: the hot-path products fed to pcc_entropy_encode come from the oracle,
+so what is checked is exactly the host code: header, range coder, JPEG, stream assembly, decoder.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.binding.load_library()
+    header = open(os.path.join(ROOT, "include", "pcc_codec.h")).read()
+    declared = set(re.findall(r"\b(pcc_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(pkg.binding.EXPORTS), declared ^ set(pkg.binding.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.pcc_version()
+
+
+def test_struct_layouts_match_header(pkg, oracle):
+    b = pkg.binding
+    assert C.sizeof(b.Params) == 56 and b.POINT_DTYPE.itemsize == 32
+    assert C.sizeof(b.HotResult) == 8 * 6 + 4 + 4 + 8 * 3 + 8 * 4 + 4 + 4 + 4 + 4
+    assert C.sizeof(b.Bitstream) == 8 + 8 + 24
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.binding.Context(0)
+    host = pkg.binding.Context(None)  # host-only context: GPU entry points must refuse
+    pts = pkg.synthetic.sphere_shell(100, 1)
+    with pytest.raises(pkg.binding.PccError) as e:
+        host.encode_intra_host(pts, pkg.binding.make_params())
+    assert e.value.code == -6
+
+
+@pytest.mark.parametrize("n,kind", [(0, "u"), (1, "u"), (256, "all"), (70_000, "skew"), (20_000, "u")])
+def test_range_coder_matches_oracle(pkg, oracle, n, kind):
+    rng = np.random.default_rng(n + 5)
+    if kind == "all":
+        data = bytes(range(256))
+    elif kind == "skew":
+        data = bytes(np.minimum(rng.geometric(0.25, n), 255).astype(np.uint8))
+    else:
+        data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    enc = pkg.binding.host_range_encode(data)
+    assert enc == oracle.rc_encode(data)
+    dec, used = pkg.binding.host_range_decode(enc, len(data))
+    assert dec == data and used == len(enc)
+
+
+def test_jpeg_matches_libjpeg_turbo_golden(pkg):
+    z = np.load(os.path.join(GOLDEN, "jpeg_golden.npz"))
+    n = len([k for k in z.files if k.startswith("in_")])
+    for i in range(n):
+        img, q = z["in_%02d" % i], int(z["q_%02d" % i])
+        assert pkg.binding.host_jpeg_encode(img, q) == z["jpg_%02d" % i].tobytes(), (img.shape, q)
+        assert np.array_equal(pkg.binding.host_jpeg_decode(z["jpg_%02d" % i].tobytes(), 1 << 16), z["dec_%02d" % i])
+
+
+def test_jpeg_matches_oracle_on_random_images(pkg, oracle):
+    rng = np.random.default_rng(99)
+    for (h, w) in [(1, 256), (7, 256), (33, 256), (1, 2048), (1, 3000), (2, 9), (19, 24)]:
+        for q in (5, 60, 85, 97):
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            jpg = oracle.jpeg_encode(img, q)
+            assert pkg.binding.host_jpeg_encode(img, q) == jpg
+            assert np.array_equal(pkg.binding.host_jpeg_decode(jpg, 1 << 16), oracle.jpeg_decode(jpg))
+
+
+@pytest.mark.parametrize("w,h", [(256, 1), (256, 5), (256, 8), (256, 9), (256, 17), (16, 3), (8, 7), (64, 23), (256, 100)])
+def test_snake_closed_form_matches_iterator(pkg, oracle, w, h):
+    assert np.array_equal(pkg.binding.host_snake_perm(w, h), oracle.snake_perm(w, h))
+
+
+def _hot_from_oracle(pkg, r):
+    """Build a pcc_hot_result out of the oracle's intermediate products."""
+    b = pkg.binding
+    hr = b.HotResult()
+    for i in range(6):
+        hr.bbox[i] = r.bbox[i]
+    hr.depth, hr.n_points_in, hr.n_leaves, hr.n_branches = r.depth, r.n_points_in, r.n_leaves, r.n_branches
+    keep = [np.ascontiguousarray(a) for a in (r.occupancy, r.bgr, r.centroid_bytes, r.snake_image)]
+    hr.occupancy = keep[0].ctypes.data
+    hr.bgr = keep[1].ctypes.data if keep[1].size else None
+    hr.centroid = keep[2].ctypes.data if keep[2].size else None
+    hr.image = keep[3].ctypes.data if keep[3].size else None
+    hr.image_w, hr.image_h = r.image_w, r.image_h
+    return hr, keep
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("centroid", [0, 1])
+def test_entropy_stage_and_decoder_match_oracle(pkg, oracle, mode, centroid):
+    pts = pkg.synthetic.sphere_shell(6000, 0x77 + mode)
+    kw = dict(octree_bits=6, color_bits=7 if mode == 0 else 8, color_coding_type=mode, keep_centroid=centroid,
+              jpeg_quality=80, frame_id=3)
+    r = oracle.encode_intra(pts, oracle.make_params(**kw))
+    host = pkg.binding.Context(None)
+    hr, keep = _hot_from_oracle(pkg, r)
+    stream, perf = host.entropy_encode(hr, pkg.binding.make_params(**kw))
+    assert stream == r.bitstream
+    assert perf == r.perf
+    dec, info = host.decode_intra(stream)
+    want = oracle.decode_intra(stream)
+    assert info["consumed"] == want.consumed == len(stream) and info["depth"] == want.depth
+    assert np.array_equal(info["bbox"], want.bbox)
+    assert dec.tobytes() == want.points.tobytes()
+    assert info["params"]["frame_id"] == 3 and info["params"]["color_coding_type"] == mode
+
+
+def test_decoder_rejects_garbage(pkg):
+    host = pkg.binding.Context(None)
+    for bad in (b"", b"hello", b"<PCL-OCT-CODECV2-COMPRESSED><PCL-OCT-COMPRESSED>\x00"):
+        with pytest.raises(pkg.binding.PccError) as e:
+            host.decode_intra(bad)
+        assert e.value.code == -5
+
+
+def test_decoder_syncs_past_leading_junk(pkg, oracle):
+    pts = pkg.synthetic.sphere_shell(500, 5)
+    r = oracle.encode_intra(pts, oracle.make_params(octree_bits=5, color_coding_type=0))
+    host = pkg.binding.Context(None)
+    dec, info = host.decode_intra(b"<<PCL-junk" + r.bitstream)
+    assert len(dec) == r.n_leaves and info["consumed"] == len(r.bitstream) + 10
+
+
+def test_normalize_group_matches_numpy(pkg):
+    b = pkg.binding
+    raw = pkg.synthetic.sphere_shell(3000, 21, centre=(3.0, -1.0, 0.5), radius=1.7, do_normalize=False)
+    a = raw.copy()
+    ref = raw.copy()
+    mn2, mx2 = pkg.synthetic.normalize(ref, 0.2)
+    lib = b.load_library()
+    ptrs = (C.c_void_p * 1)(a.ctypes.data)
+    sizes = (C.c_size_t * 1)(len(a))
+    mn = np.zeros(3, np.float32)
+    mx = np.zeros(3, np.float32)
+    assert lib.pcc_normalize_group(ptrs, sizes, 1, 0.2, mn.ctypes.data, mx.ctypes.data) == 0
+    assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2) and a.tobytes() == ref.tobytes()
+    assert lib.pcc_restore_scaling(a.ctypes.data, len(a), mn.ctypes.data, mx.ctypes.data) == 0
+    for ax in "xyz":
+        assert np.abs(a[ax] - raw[ax]).max() < 1e-5
