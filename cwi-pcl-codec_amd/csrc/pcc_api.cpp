@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -75,7 +76,7 @@ struct pcc_ctx {
   DevBuf<ChunkBox> d_boxes;
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_partials, d_leaf_code;
-  DevBuf<uint32_t> d_ghist, d_gtot, d_leaf_start, d_leaf_base;
+  DevBuf<uint32_t> d_ghist, d_gtot, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image;
   DevBuf<float> d_simplified;  // 4 floats per leaf
 
@@ -122,6 +123,8 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_state.ensure(1));
   PCC_HIP(ctx->d_keys_a.ensure(n));
   PCC_HIP(ctx->d_keys_b.ensure(n));
+  PCC_HIP(ctx->d_idx_a.ensure(n));
+  PCC_HIP(ctx->d_idx_b.ensure(n));
   PCC_HIP(ctx->d_partials.ensure(tiles));
   PCC_HIP(ctx->d_ghist.ensure(tiles * kRadixSize));
   PCC_HIP(ctx->d_gtot.ensure(kRadixSize));
@@ -172,7 +175,7 @@ void pcc_destroy(pcc_ctx* c) {
   }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release();
+  c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_partials.release(); c->d_leaf_code.release(); c->d_ghist.release(); c->d_gtot.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release();
@@ -259,8 +262,13 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.lp.do_centroid = prm->do_voxel_centroid ? 1u : 0u;
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
   a.max_passes = 8;  // 64 key bits / 8; the device skips the passes it does not need
+  {
+    const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
+    a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
+  }
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
+  a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
   a.ghist = ctx->d_ghist.p; a.gtot = ctx->d_gtot.p; a.partials = ctx->d_partials.p;
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
   a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
@@ -269,7 +277,8 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   {
     int ibits = 0;
     while ((n >> ibits) != 0) ++ibits;
-    a.max_passes = std::max(1, (64 - ibits + kRadixBits - 1) / kRadixBits);
+    (void)ibits;
+    a.max_passes = 8;  // up to 63 code bits + flag in pairs mode
   }
 
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
@@ -299,8 +308,8 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
   if (st.error != kErrNone) {
     char buf[160];
-    snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d, key bits %d+%d+%d)", st.error,
-             st.depth, st.vbits, st.flagbit, st.ibits);
+    snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
+             st.error, st.depth, kMaxDepth, st.vbits);
     return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
   }
   const size_t L = st.n_leaves, B = st.n_branches;

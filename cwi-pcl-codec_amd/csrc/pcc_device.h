@@ -8,6 +8,7 @@
 //   chunk_box   ceil(N/2048) x 32 B   per-chunk AABB + first finite index + finite count
 //   state       1 x FrameState  epochs of the adaptive bounding box, sort geometry, L, B
 //   keys[2]     N x u64         packed (flag | morton | index) sort keys, ping-pong
+//   idx[2]      N x u32         point index payload, only touched in pairs mode (code + index bits > 64)
 //   radix_hist  256 x ceil(N/2048) x u32   per-tile digit counts / row prefixes
 //   tile_part   ceil(N/2048) x u64         (sum t << 32 | sum head) partials of the leaf scan
 //   leaf_start  (N+1) x u32     first sorted position of each leaf
@@ -39,7 +40,7 @@ struct ChunkBox {          // 32 bytes
 enum FrameError : int32_t {
   kErrNone = 0,
   kErrDepth = 1,           // depth > kMaxDepth
-  kErrKeyBits = 2,         // morton bits + flag + index bits > 64
+  kErrPrefix = 2,          // a key fell outside the predicted varying-bit window (should not happen)
   kErrEpochs = 3,          // more than kMaxEpochs growth epochs
 };
 
@@ -57,7 +58,8 @@ struct FrameState {
   // ---- sort geometry ----
   int32_t vbits_axis;                // varying key bits per axis
   int32_t vbits;                     // 3 * vbits_axis
-  int32_t ibits;                     // index bits in the packed key
+  int32_t ibits;                     // index bits in the packed key (0 in pairs mode)
+  int32_t packed;                    // 1: [flag|code|index] in one u64;  0: u64 code keys + u32 index payload
   int32_t flagbit;                   // 1 if non-finite points exist (extra sort bit above the code)
   int32_t npasses;                   // radix passes actually needed
   uint32_t prefix[3];                // constant high key bits per axis (in place)
@@ -65,7 +67,6 @@ struct FrameState {
   uint32_t n_leaves;                 // L
   uint32_t n_branches;               // B
   int32_t error;                     // FrameError
-  int32_t pad_;
 };
 
 }  // namespace pcc

@@ -31,10 +31,13 @@ struct HotPathArgs {
   double res;
   LeafParams lp;
   int max_passes;  // radix passes to enqueue (device decides how many do work)
+  int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
   ChunkBox* boxes;
   FrameState* state;
   uint64_t* keys_a;
   uint64_t* keys_b;
+  uint32_t* idx_a;
+  uint32_t* idx_b;
   uint32_t* ghist;
   uint32_t* gtot;
   uint64_t* partials;

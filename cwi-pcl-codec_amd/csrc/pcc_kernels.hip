@@ -204,7 +204,7 @@ __device__ __forceinline__ int block_min_int(int v, int* s_red) {
 
 __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n, uint32_t n_chunks,
                                                         const ChunkBox* __restrict__ boxes, double res,
-                                                        FrameState* __restrict__ st) {
+                                                        int force_pairs, FrameState* __restrict__ st) {
   __shared__ float s_p[3][kTile];
   __shared__ int s_red;
   __shared__ double s_mn[3], s_mx[3];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     if (threadIdx.x == 0) {
       st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
       st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->flagbit = 0; st->n_growth_events = 0;
+      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->flagbit = 0; st->n_growth_events = 0; st->packed = 1;
     }
     return;
   }
@@ -403,14 +403,18 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
       vb = max(vb, nb);
     }
     for (int a = 0; a < 3; ++a) st->prefix[a] = vb >= 32 ? 0u : ((kmin[a] >> vb) << vb);
-    const int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
+    int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
     const int flag = s_nfin < n ? 1 : 0;
+    // code + index in one u64 when they fit (8 B/key/pass); otherwise u64 code keys with a u32
+    // index payload (12 B/key/pass).  The stable sort makes both orders identical.
+    const int packed = (3 * vb + flag + ibits <= 64 && !force_pairs) ? 1 : 0;
+    if (!packed) ibits = 0;
     st->vbits_axis = vb;
     st->vbits = 3 * vb;
     st->ibits = ibits;
+    st->packed = packed;
     st->flagbit = flag;
     st->npasses = (3 * vb + flag + kRadixBits - 1) / kRadixBits;
-    if (err == kErrNone && 3 * vb + flag + ibits > 64) err = kErrKeyBits;
     if (err != kErrNone) st->npasses = 0;
     st->error = err;
     st->n_leaves = 0;
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
 // Stage 2: octree keys (P3) -> packed sort keys  [flag | morton(vbits) | point index(ibits)]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_make_keys(PointView pv, uint32_t n, double res,
-                                                      FrameState* __restrict__ st, uint64_t* __restrict__ keys) {
+                                                      FrameState* __restrict__ st, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ idx) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
@@ -445,12 +450,13 @@ __global__ __launch_bounds__(kBlock) void k_make_keys(PointView pv, uint32_t n, 
       k[a] = (unsigned)d + st->ep_shift[e][a];
       ok &= vb >= 32 || ((k[a] >> vb) == (st->prefix[a] >> vb));
     }
-    if (!ok) st->error = kErrKeyBits;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
+    if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
     const unsigned m = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    packed = (morton3(k[0] & m, k[1] & m, k[2] & m) << ibits) | (uint64_t)i;
+    packed = morton3(k[0] & m, k[1] & m, k[2] & m) << ibits;
   } else {
-    packed = (1ull << (vbits + ibits)) | (uint64_t)i;  // non-finite: sorts behind every real key
+    packed = 1ull << (vbits + ibits);  // non-finite: sorts behind every real key
   }
+  if (st->packed) packed |= (uint64_t)i; else idx[i] = i;
   keys[i] = packed;
 }
 
@@ -502,8 +508,9 @@ __global__ __launch_bounds__(kBlock) void k_radix_scan(int pass, const FrameStat
   if (threadIdx.x == 0) gtot[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
-                                                          uint64_t* __restrict__ out_a, uint64_t* __restrict__ out_b,
+__global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* buf_a, const uint64_t* buf_b,
+                                                          uint64_t* out_a, uint64_t* out_b,
+                                                          uint32_t* idx_a, uint32_t* idx_b,
                                                           uint32_t n, int pass, const FrameState* __restrict__ st,
                                                           uint32_t n_tiles, const uint32_t* __restrict__ ghist,
                                                           const uint32_t* __restrict__ gtot) {
@@ -514,6 +521,9 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* __rest
   __shared__ uint32_t s_w[kBlock / 64];
   const uint64_t* in = pick_in(st, pass, buf_a, buf_b);
   uint64_t* out = (pass & 1) ? out_a : out_b;  // ping-pong: pass 0 reads a writes b
+  const bool pairs = st->packed == 0;
+  const uint32_t* idx_in = (pass & 1) ? idx_b : idx_a;
+  uint32_t* idx_out = (pass & 1) ? idx_a : idx_b;
   const int shift = st->ibits + pass * kRadixBits;
   const int lane = lane_id(), wave = wave_id();
   const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -556,7 +566,11 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* __rest
       s_run[dd] = run;
     }
     __syncthreads();
-    if (valid) out[s_off[d] + s_cnt[wave][d] + rank] = key;
+    if (valid) {
+      const uint32_t pos = s_off[d] + s_cnt[wave][d] + rank;
+      out[pos] = key;
+      if (pairs) idx_out[pos] = idx_in[i];
+    }
     __syncthreads();
   }
 }
@@ -694,11 +708,19 @@ __device__ __forceinline__ uint32_t snake_pos(uint32_t i, uint32_t W, uint32_t H
   return (full * 8u + r) * W + bw * 8u + cc;
 }
 
-__device__ __forceinline__ void leaf_colour(const PointView& pv, const uint64_t* keys, uint64_t imask, uint32_t s, uint32_t e,
+// original point index of sorted element i: low bits of the packed key, or the index payload
+struct IndexOf {
+  const uint64_t* keys;
+  const uint32_t* idx;  // null in packed mode
+  uint64_t imask;
+  __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return idx ? idx[i] : (uint32_t)(keys[i] & imask); }
+};
+
+__device__ __forceinline__ void leaf_colour(const PointView& pv, const IndexOf& index_of, uint32_t s, uint32_t e,
                                             uint32_t red, uint32_t& b, uint32_t& g, uint32_t& r) {
   uint32_t s0 = 0, s1 = 0, s2 = 0;
   for (uint32_t i = s; i < e; ++i) {
-    const uint32_t w = load_rgba(pv, (uint32_t)(keys[i] & imask));
+    const uint32_t w = load_rgba(pv, index_of(i));
     s0 += w & 0xffu; s1 += (w >> 8) & 0xffu; s2 += (w >> 16) & 0xffu;
   }
   const uint32_t cnt = e - s;
@@ -708,6 +730,7 @@ __device__ __forceinline__ void leaf_colour(const PointView& pv, const uint64_t*
 
 __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double res, LeafParams lp,
                                                           const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                          const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
                                                           const FrameState* __restrict__ st,
                                                           const uint32_t* __restrict__ leaf_start, const uint64_t* __restrict__ leaf_code,
                                                           const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
@@ -718,14 +741,17 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, D = st->depth;
-  const uint64_t imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
+  IndexOf index_of;
+  index_of.keys = keys;
+  index_of.idx = st->packed ? nullptr : ((st->npasses & 1) ? idx_b : idx_a);
+  index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
 
   if (j >= L) {
     // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
     if (lp.write_image && j < W * H) {
       uint32_t b, g, r;
-      leaf_colour(pv, keys, imask, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
+      leaf_colour(pv, index_of, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
       const uint32_t px = snake_pos(j, W, H);
       image[3 * px] = (uint8_t)b; image[3 * px + 1] = (uint8_t)g; image[3 * px + 2] = (uint8_t)r;
     }
@@ -740,7 +766,7 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
 
   uint32_t cb = 0, cg = 0, cr = 0;
   if (lp.do_color) {
-    leaf_colour(pv, keys, imask, s, e, lp.color_reduction, cb, cg, cr);
+    leaf_colour(pv, index_of, s, e, lp.color_reduction, cb, cg, cr);
     bgr[3 * j] = (uint8_t)cb; bgr[3 * j + 1] = (uint8_t)cg; bgr[3 * j + 2] = (uint8_t)cr;
     if (lp.write_image) {
       const uint32_t px = snake_pos(j, W, H);
@@ -760,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
     float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
     for (uint32_t i = s; i < e; ++i) {
       float x, y, z;
-      load_xyz(pv, (uint32_t)(keys[i] & imask), x, y, z);
+      load_xyz(pv, index_of(i), x, y, z);
       sx = __fadd_rn(sx, x); sy = __fadd_rn(sy, y); sz = __fadd_rn(sz, z);
     }
     const float cnt = (float)(e - s);
@@ -818,17 +844,17 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("begin");
   hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes);
   PCC_STAMP("k_chunk_boxes");
-  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.state);
+  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, a.state);
   PCC_STAMP("k_bbox_events");
-  hipLaunchKernelGGL(k_make_keys, dim3(n_blocks), dim3(kBlock), 0, stream, a.pv, n, a.res, a.state, a.keys_a);
+  hipLaunchKernelGGL(k_make_keys, dim3(n_blocks), dim3(kBlock), 0, stream, a.pv, n, a.res, a.state, a.keys_a, a.idx_a);
   PCC_STAMP("k_make_keys");
   for (int pass = 0; pass < a.max_passes; ++pass) {
     hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, n, pass, a.state, n_tiles, a.ghist);
     PCC_STAMP("k_radix_hist");
     hipLaunchKernelGGL(k_radix_scan, dim3(kRadixSize), dim3(kBlock), 0, stream, pass, a.state, n_tiles, a.ghist, a.gtot);
     PCC_STAMP("k_radix_scan");
-    hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, n, pass,
-                       a.state, n_tiles, a.ghist, a.gtot);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+                       n, pass, a.state, n_tiles, a.ghist, a.gtot);
     PCC_STAMP("k_radix_scatter");
   }
   hipLaunchKernelGGL(k_leaf_partials, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.state, a.partials);
@@ -841,7 +867,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   hipLaunchKernelGGL(k_zero_occ, dim3(512), dim3(kBlock), 0, stream, a.state, reinterpret_cast<uint4*>(a.occ));
   PCC_STAMP("k_zero_occ");
   const uint32_t fin_blocks = (n + 256u + kBlock - 1) / kBlock;  // leaves + up to 256 padding pixels
-  hipLaunchKernelGGL(k_leaf_finalize, dim3(fin_blocks), dim3(kBlock), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.state,
+  hipLaunchKernelGGL(k_leaf_finalize, dim3(fin_blocks), dim3(kBlock), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state,
                      a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
                      reinterpret_cast<float4*>(a.simplified));
   PCC_STAMP("k_leaf_finalize");

@@ -295,3 +295,18 @@ def test_codec_class_round_trip(pkg, oracle):
     got = np.stack([out["rgba"] & 0xFF, (out["rgba"] >> 8) & 0xFF, (out["rgba"] >> 16) & 0xFF], 1)
     exp = np.stack([ref.points["rgba"] & 0xFF, (ref.points["rgba"] >> 8) & 0xFF, (ref.points["rgba"] >> 16) & 0xFF], 1)
     assert abs(psnr(got, enc_bgr) - psnr(exp, enc_bgr)) <= 0.01
+
+
+def test_pair_sort_mode_matches_packed_mode(pkg, oracle, monkeypatch):
+    """Frames whose code + index bits exceed 64 sort (u64 code, u32 index) pairs; force that path on a small frame."""
+    monkeypatch.setenv("PCC_FORCE_PAIRS", "1")
+    c = pkg.binding.Context(0)
+    try:
+        rng = np.random.default_rng(77)
+        xyz = rng.uniform(0.1, 0.9, (70000, 3)).astype(np.float32)
+        xyz[rng.integers(0, 70000, 300)] = np.nan
+        xyz = np.repeat(xyz, 2, axis=0)[rng.permutation(140000)]
+        for kw in (dict(octree_bits=9, color_coding_type=1), dict(octree_bits=7, color_coding_type=0, keep_centroid=1)):
+            assert_matches_oracle(pkg, oracle, c, cloud(pkg, xyz), **kw)
+    finally:
+        c.close()
