@@ -263,6 +263,10 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
   a.max_passes = 8;  // 64 key bits / 8; the device skips the passes it does not need
   {
+    const char* ab = getenv("PCC_ABLATE");  // profiling hook: switch parts of k_leaf_finalize off (results are then wrong)
+    a.lp.ablate = ab ? (uint32_t)atoi(ab) : 0u;
+  }
+  {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
   }

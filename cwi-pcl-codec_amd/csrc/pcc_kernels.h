@@ -23,6 +23,7 @@ struct LeafParams {
   uint32_t color_reduction;  // colorBitReduction_ (only the PCL colour coder, type 0, ever has one)
   uint32_t do_centroid;      // do_voxel_centroid_enDecoding_
   uint32_t write_image;      // colour coding type 1: emit the snake-mapped 256 x H image
+  uint32_t ablate;           // profiling only (PCC_ABLATE): 1 no colour gather, 2 no colour stores, 4 no occupancy, 8 no simplified
 };
 
 struct HotPathArgs {

@@ -283,17 +283,22 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     const double mn0 = s_mn[0], mn1 = s_mn[1], mn2 = s_mn[2];
     const double mx0 = s_mx[0], mx1 = s_mx[1], mx2 = s_mx[2];
     const int c0 = cur / kTile;
-    int cand = 0x7fffffff;
-    for (int c = c0 + (int)threadIdx.x; c < (int)n_chunks; c += kBlock) {
-      const ChunkBox b = boxes[c];
-      if (b.n_finite > 0) {
-        const bool viol = ((double)b.mn[0] < mn0) | ((double)b.mn[1] < mn1) | ((double)b.mn[2] < mn2) |
-                          ((double)b.mx[0] >= mx0) | ((double)b.mx[1] >= mx1) | ((double)b.mx[2] >= mx2);
-        if (viol) { cand = c; break; }  // ascending per thread: the first hit is this thread's minimum
+    int cmin;
+    if (c0 == loaded) {
+      cmin = loaded;  // keep draining the chunk that is already staged in LDS: no global access at all
+    } else {
+      int cand = 0x7fffffff;
+      for (int c = c0 + (int)threadIdx.x; c < (int)n_chunks; c += kBlock) {
+        const ChunkBox b = boxes[c];
+        if (b.n_finite > 0) {
+          const bool viol = ((double)b.mn[0] < mn0) | ((double)b.mn[1] < mn1) | ((double)b.mn[2] < mn2) |
+                            ((double)b.mx[0] >= mx0) | ((double)b.mx[1] >= mx1) | ((double)b.mx[2] >= mx2);
+          if (viol) { cand = c; break; }  // ascending per thread: the first hit is this thread's minimum
+        }
       }
+      cmin = block_min_int(cand, &s_red);
+      if (cmin == 0x7fffffff) break;  // everything that is left fits
     }
-    const int cmin = block_min_int(cand, &s_red);
-    if (cmin == 0x7fffffff) break;  // everything that is left fits
     if (cmin != loaded) {
       __syncthreads();
 #pragma unroll
@@ -515,9 +520,8 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* buf_a,
                                                           uint32_t n_tiles, const uint32_t* __restrict__ ghist,
                                                           const uint32_t* __restrict__ gtot) {
   if (pass >= st->npasses) return;
-  __shared__ uint32_t s_off[kRadixSize];          // global offset of this tile's first key per digit
-  __shared__ uint32_t s_cnt[kBlock / 64][kRadixSize];
-  __shared__ uint32_t s_run[kRadixSize];
+  __shared__ uint32_t s_off[kRadixSize];               // global offset of this tile's first key per digit
+  __shared__ uint32_t s_cnt[kBlock / 64][kRadixSize];   // per-wave running digit counts, then wave start ranks
   __shared__ uint32_t s_w[kBlock / 64];
   const uint64_t* in = pick_in(st, pass, buf_a, buf_b);
   uint64_t* out = (pass & 1) ? out_a : out_b;  // ping-pong: pass 0 reads a writes b
@@ -532,19 +536,24 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* buf_a,
     uint32_t tot;
     const uint32_t dbase = block_excl_scan_u32(gtot[threadIdx.x], s_w, tot);
     s_off[threadIdx.x] = dbase + ghist[(size_t)threadIdx.x * n_tiles + blockIdx.x];
-    s_run[threadIdx.x] = 0;
-  }
-  const uint32_t base = blockIdx.x * kTile;
-  for (int k = 0; k < kItems; ++k) {
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) s_cnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t i = base + k * kBlock + threadIdx.x;
+  }
+  __syncthreads();
+
+  // Tile order = (wave, round, lane): every wave ranks its own 512 consecutive keys against
+  // wave-private LDS counters, so no workgroup barrier is needed inside the ranking loop (LDS
+  // operations of one wave complete in issue order).
+  const uint32_t wbase = blockIdx.x * kTile + (uint32_t)wave * (kTile / (kBlock / 64));
+  uint64_t key[kItems];
+  uint32_t lrank[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
     const bool valid = i < n;
-    const uint64_t key = valid ? in[i] : 0ull;
-    const uint32_t d = (uint32_t)(key >> shift) & (kRadixSize - 1);
-    // lanes of this wave holding the same digit (8 ballots)
-    uint64_t peers = __ballot(valid);
+    key[r] = valid ? in[i] : 0ull;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixSize - 1);
+    uint64_t peers = __ballot(valid);  // lanes of this wave holding the same digit (8 ballots)
 #pragma unroll
     for (int b = 0; b < kRadixBits; ++b) {
       const bool bit = (d >> b) & 1u;
@@ -552,26 +561,31 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* buf_a,
       peers &= bit ? bal : ~bal;
     }
     const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-    if (valid && rank == 0) s_cnt[wave][d] = (uint32_t)__popcll(peers);
-    __syncthreads();
-    {  // thread = digit: turn per-wave counts into per-wave start ranks (tile order = k, wave, lane)
-      const uint32_t dd = threadIdx.x;
-      uint32_t run = s_run[dd];
+    const uint32_t prior = s_cnt[wave][d];
+    if (valid && rank == 0) s_cnt[wave][d] = prior + (uint32_t)__popcll(peers);
+    lrank[r] = prior + rank;
+  }
+  __syncthreads();
+  {  // thread = digit: per-wave totals -> per-wave start ranks inside the tile
+    const uint32_t dd = threadIdx.x;
+    uint32_t run = 0;
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) {
-        const uint32_t c = s_cnt[w][dd];
-        s_cnt[w][dd] = run;
-        run += c;
-      }
-      s_run[dd] = run;
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const uint32_t c = s_cnt[w][dd];
+      s_cnt[w][dd] = run;
+      run += c;
     }
-    __syncthreads();
-    if (valid) {
-      const uint32_t pos = s_off[d] + s_cnt[wave][d] + rank;
-      out[pos] = key;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+    if (i < n) {
+      const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixSize - 1);
+      const uint32_t pos = s_off[d] + s_cnt[wave][d] + lrank[r];
+      out[pos] = key[r];
       if (pairs) idx_out[pos] = idx_in[i];
     }
-    __syncthreads();
   }
 }
 
@@ -738,9 +752,35 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
                                                           uint8_t* __restrict__ image, float4* __restrict__ simplified) {
   const uint32_t L = st->n_leaves;
   if (L == 0) return;
-  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t j0 = blockIdx.x * kBlock;
+  const uint32_t j = j0 + threadIdx.x;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, D = st->depth;
+  const int lane = lane_id(), wave = wave_id();
+
+  // Who opened my parent?  The parent of the topmost node leaf j opens (level D-t-1) was opened by
+  // the nearest earlier leaf f with t(f) > t(j).  Inside the workgroup that is a ballot per level
+  // plus a count-leading-zeros; only leaves whose parent predates the block search globally.
+  __shared__ uint64_t s_mask[kBlock / 64][kMaxDepth + 2];
+  __shared__ uint8_t s_t[kBlock];
+  __shared__ uint32_t s_base[kBlock];
+  // The branch nodes opened by this block's leaves are one contiguous piece of the DFS stream:
+  // collect their child bits in LDS and flush whole dwords (one global atomic per dword, not per bit).
+  __shared__ uint32_t s_occ[kBlock * kMaxDepth / 4 + 2];
+  const int t = j < L ? (int)leaf_t[j] : 0;
+  const uint32_t base = j < L ? leaf_base[j] : 0u;
+  s_t[threadIdx.x] = (uint8_t)t;
+  s_base[threadIdx.x] = base;
+  for (int v = 1; v <= D; ++v) {
+    const uint64_t mk = __ballot(j < L && t >= v);
+    if (lane == 0) s_mask[wave][v] = mk;
+  }
+  for (uint32_t k = threadIdx.x; k < kBlock * kMaxDepth / 4 + 2; k += kBlock) s_occ[k] = 0u;
+  __syncthreads();
+  const uint32_t n_here = min((uint32_t)kBlock, L > j0 ? L - j0 : 0u);
+  const uint32_t seg0 = n_here ? (s_base[0] & ~3u) : 0u;  // dword-aligned start of the block's stream piece
+  const uint32_t seg1 = n_here ? s_base[n_here - 1] + s_t[n_here - 1] : 0u;
+
   IndexOf index_of;
   index_of.keys = keys;
   index_of.idx = st->packed ? nullptr : ((st->npasses & 1) ? idx_b : idx_a);
@@ -755,77 +795,101 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
       const uint32_t px = snake_pos(j, W, H);
       image[3 * px] = (uint8_t)b; image[3 * px + 1] = (uint8_t)g; image[3 * px + 2] = (uint8_t)r;
     }
-    return;
-  }
-
-  const uint32_t s = leaf_start[j], e = leaf_start[j + 1];
-  const uint64_t code = leaf_code[j];
-  const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
-  const uint64_t full = code | pfx;
-  const uint32_t key[3] = {compact3(full >> 2), compact3(full >> 1), compact3(full)};
-
-  uint32_t cb = 0, cg = 0, cr = 0;
-  if (lp.do_color) {
-    leaf_colour(pv, index_of, s, e, lp.color_reduction, cb, cg, cr);
-    bgr[3 * j] = (uint8_t)cb; bgr[3 * j + 1] = (uint8_t)cg; bgr[3 * j + 2] = (uint8_t)cr;
-    if (lp.write_image) {
-      const uint32_t px = snake_pos(j, W, H);
-      image[3 * px] = (uint8_t)cb; image[3 * px + 1] = (uint8_t)cg; image[3 * px + 2] = (uint8_t)cr;
-    }
-  }
-
-  // lower voxel corner (impl.hpp:1519-1521), then centre (impl.hpp:1560-1562) or centroid (:1566-1573)
-  double lc[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) lc[a] = __dadd_rn(__dmul_rn((double)key[a], res), st->mn[a]);
-  float c[3];
-  if (!lp.do_centroid) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) c[a] = (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
   } else {
-    float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
-    for (uint32_t i = s; i < e; ++i) {
-      float x, y, z;
-      load_xyz(pv, index_of(i), x, y, z);
-      sx = __fadd_rn(sx, x); sy = __fadd_rn(sy, y); sz = __fadd_rn(sz, z);
-    }
-    const float cnt = (float)(e - s);
-    c[0] = __fdiv_rn(sx, cnt); c[1] = __fdiv_rn(sy, cnt); c[2] = __fdiv_rn(sz, cnt);
-    const double prec = (double)0.001f;  // PointCoding default precision (ptv2.h:89-91)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
-      d = max(-127, min(127, d));
-      centroid[3 * j + a] = (uint8_t)d;
-    }
-  }
-  if (simplified) {
-    const uint32_t rgba = cb | (cg << 8) | (cr << 16) | 0xff000000u;
-    simplified[j] = make_float4(c[0], c[1], c[2], __uint_as_float(rgba));
-  }
+    const uint32_t s = leaf_start[j], e = leaf_start[j + 1];
+    const uint64_t code = leaf_code[j];
+    const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
+    const uint64_t full = code | pfx;
+    const uint32_t key[3] = {compact3(full >> 2), compact3(full >> 1), compact3(full)};
 
-  // occupancy: the t(j) branch nodes this leaf opens sit at base(j).. in the stream; each gets the
-  // child bit on this leaf's path.  The topmost one is itself a new child of an older node.
-  const int t = leaf_t[j];
-  const uint32_t base = leaf_base[j];
-  for (int q = 0; q < t; ++q) {
-    const int level = D - t + q;
-    const uint32_t child = (uint32_t)(full >> (3 * (D - 1 - level))) & 7u;
-    or_byte(occ, base + (uint32_t)q, 1u << child);
-  }
-  if (j > 0) {
-    const int m = t;
-    const uint32_t child = (uint32_t)(full >> (3 * m)) & 7u;
-    const int sh = 3 * (m + 1);
-    const uint64_t pcode = sh >= 64 ? 0ull : ((code >> sh) << sh);
-    uint32_t lo = 0, hi = j;  // first leaf f in [0, j) with leaf_code[f] >= pcode
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (leaf_code[mid] < pcode) lo = mid + 1; else hi = mid;
+    uint32_t cb = 0, cg = 0, cr = 0;
+    if (lp.do_color) {
+      if (!(lp.ablate & 1u)) leaf_colour(pv, index_of, s, e, lp.color_reduction, cb, cg, cr);
+      if (!(lp.ablate & 2u)) {
+        bgr[3 * j] = (uint8_t)cb; bgr[3 * j + 1] = (uint8_t)cg; bgr[3 * j + 2] = (uint8_t)cr;
+        if (lp.write_image) {
+          const uint32_t px = snake_pos(j, W, H);
+          image[3 * px] = (uint8_t)cb; image[3 * px + 1] = (uint8_t)cg; image[3 * px + 2] = (uint8_t)cr;
+        }
+      }
     }
-    const int tf = leaf_t[lo];
-    const uint32_t off = leaf_base[lo] + (uint32_t)((D - m - 1) - (D - tf));
-    or_byte(occ, off, 1u << child);
+
+    // lower voxel corner (impl.hpp:1519-1521), then centre (impl.hpp:1560-1562) or centroid (:1566-1573)
+    double lc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) lc[a] = __dadd_rn(__dmul_rn((double)key[a], res), st->mn[a]);
+    float c[3];
+    if (!lp.do_centroid) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) c[a] = (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
+    } else {
+      float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
+      for (uint32_t i = s; i < e; ++i) {
+        float x, y, z;
+        load_xyz(pv, index_of(i), x, y, z);
+        sx = __fadd_rn(sx, x); sy = __fadd_rn(sy, y); sz = __fadd_rn(sz, z);
+      }
+      const float cnt = (float)(e - s);
+      c[0] = __fdiv_rn(sx, cnt); c[1] = __fdiv_rn(sy, cnt); c[2] = __fdiv_rn(sz, cnt);
+      const double prec = (double)0.001f;  // PointCoding default precision (ptv2.h:89-91)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
+        d = max(-127, min(127, d));
+        centroid[3 * j + a] = (uint8_t)d;
+      }
+    }
+    if (simplified && !(lp.ablate & 8u)) {
+      const uint32_t rgba = cb | (cg << 8) | (cr << 16) | 0xff000000u;
+      simplified[j] = make_float4(c[0], c[1], c[2], __uint_as_float(rgba));
+    }
+
+    // occupancy: the t(j) branch nodes this leaf opens sit at base(j).. in the stream; each gets the
+    // child bit on this leaf's path.  The topmost one is itself a new child of an older node.
+    if (!(lp.ablate & 4u)) {
+      for (int q = 0; q < t; ++q) {
+        const int level = D - t + q;
+        const uint32_t child = (uint32_t)(full >> (3 * (D - 1 - level))) & 7u;
+        const uint32_t lo = base + (uint32_t)q - seg0;
+        atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
+      }
+      if (j > 0) {
+        const int m = t, v = t + 1;  // t < D for every leaf but the first
+        const uint32_t child = (uint32_t)(full >> (3 * m)) & 7u;
+        int fl = -1;
+        uint64_t mk = s_mask[wave][v] & (lane ? (~0ull >> (64 - lane)) : 0ull);
+        if (mk) {
+          fl = wave * 64 + 63 - __clzll((long long)mk);
+        } else {
+          for (int w = wave - 1; w >= 0; --w) {
+            mk = s_mask[w][v];
+            if (mk) { fl = w * 64 + 63 - __clzll((long long)mk); break; }
+          }
+        }
+        if (fl >= 0) {  // parent opened inside this block: its byte lives in the LDS piece
+          const uint32_t lo = s_base[fl] + (uint32_t)((D - m - 1) - (D - (int)s_t[fl])) - seg0;
+          atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
+        } else {
+          const int sh = 3 * (m + 1);
+          const uint64_t pcode = sh >= 64 ? 0ull : ((code >> sh) << sh);
+          uint32_t lo = 0, hi = j0;  // first leaf f before this block with leaf_code[f] >= pcode
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (leaf_code[mid] < pcode) lo = mid + 1; else hi = mid;
+          }
+          or_byte(occ, leaf_base[lo] + (uint32_t)((D - m - 1) - (D - (int)leaf_t[lo])), 1u << child);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (seg1 > seg0) {
+    const uint32_t ndw = (seg1 - seg0 + 3u) >> 2;
+    unsigned int* dst = reinterpret_cast<unsigned int*>(occ + seg0);
+    for (uint32_t k = threadIdx.x; k < ndw; k += kBlock) {
+      const uint32_t v = s_occ[k];
+      if (v) atomicOr(dst + k, v);
+    }
   }
 }
 
