@@ -6,4 +6,4 @@ tests and bench.py (binding.py, which also mirrors the reference class interface
 the deterministic synthetic frame generator.  The directory name contains a hyphen, so
 it is imported by path: see __graft_entry__.load_package().
 """
-from . import binding, synthetic  # noqa: F401
+from . import binding, sharding, synthetic  # noqa: F401

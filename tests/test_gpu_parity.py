@@ -310,3 +310,16 @@ def test_pair_sort_mode_matches_packed_mode(pkg, oracle, monkeypatch):
             assert_matches_oracle(pkg, oracle, c, cloud(pkg, xyz), **kw)
     finally:
         c.close()
+
+
+def test_cpp_shim_example_runs(pkg):
+    """The reference-style C++ caller built against the drop-in header (g++ only) runs end to end."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cwi-pcl-codec_amd", "shim", "examples", "encode_decode")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe)], check=True)
+    r = subprocess.run([exe, "200000", "9"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "decoded voxels" in r.stdout
