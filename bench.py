@@ -90,7 +90,7 @@ def main():
                            color_coding_type=cfg["color_coding_type"], jpeg_quality=cfg["jpeg_quality"],
                            keep_centroid=cfg["keep_centroid"])
     n_points = cfg["n"]
-    workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
+    workers = args.workers or max(1, min(16, (os.cpu_count() or 8) // max(world, 1)))
 
     # ---- frames of this rank, resident in HBM before the clock starts ----
     ctxs = [b.Context(local_rank) for _ in range(workers)]
@@ -99,6 +99,7 @@ def main():
     dev_frames = [ctxs[0].upload(f) for f in host_frames]
     for c in ctxs:
         c.set_profiling(True)
+        c.set_option("copy_image", 0)   # the host stage only needs the quantised JPEG coefficients
 
     lock = threading.Lock()
     ktimes = {}     # kernel name -> [sum ms, launches]

@@ -30,6 +30,7 @@ EXPORTS = [
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_entropy_encode", "pcc_get_output_cloud", "pcc_decode_intra",
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_set_profiling",
+    "pcc_set_option",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
 ]
@@ -57,7 +58,7 @@ class HotResult(C.Structure):
         ("bbox", C.c_double * 6), ("depth", C.c_uint32), ("n_epochs", C.c_uint32),
         ("n_points_in", C.c_uint64), ("n_leaves", C.c_uint64), ("n_branches", C.c_uint64),
         ("occupancy", C.c_void_p), ("bgr", C.c_void_p), ("centroid", C.c_void_p), ("image", C.c_void_p),
-        ("image_w", C.c_uint32), ("image_h", C.c_uint32), ("gpu_ms", C.c_float),
+        ("image_w", C.c_uint32), ("image_h", C.c_uint32), ("gpu_ms", C.c_float), ("jpeg_coefs", C.c_void_p),
     ]
 
 
@@ -107,6 +108,7 @@ def load_library():
     lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
     lib.pcc_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_set_profiling.argtypes = [vp, i32]
+    lib.pcc_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.pcc_host_range_encode.restype = sz
     lib.pcc_host_range_encode.argtypes = [vp, sz, vp, sz]
     lib.pcc_host_range_decode.restype = sz
@@ -251,6 +253,9 @@ class Context:
         info = dict(bbox=np.array(list(c.bbox)), depth=int(c.depth), consumed=int(c.consumed),
                     params={k: getattr(c.params, k) for k, _ in Params._fields_})
         return pts, info
+
+    def set_option(self, name, value):
+        self._check(self.lib.pcc_set_option(self.h, name.encode(), int(value)))
 
     def set_profiling(self, on):
         self._check(self.lib.pcc_set_profiling(self.h, 1 if on else 0))

@@ -79,11 +79,14 @@ struct pcc_ctx {
   DevBuf<uint32_t> d_ghist, d_gtot, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image;
   DevBuf<float> d_simplified;  // 4 floats per leaf
+  DevBuf<int16_t> d_coefs;     // JPEG coefficients of the snake image
 
   // host landing buffers
   PinnedBuf<FrameState> h_state;
   PinnedBuf<uint8_t> h_occ, h_bgr, h_centroid, h_image;
   PinnedBuf<float> h_simplified;
+  PinnedBuf<int16_t> h_coefs;
+  bool jpeg_on_gpu = true, copy_image = true;
   std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
   std::vector<pcc_point_xyzrgb> dec_points;  // decodePointCloud()
   Bytes bitstream;
@@ -137,6 +140,7 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_centroid.ensure(3 * n + 16));
   PCC_HIP(ctx->d_image.ensure(3 * 256 * (n / 256 + 1) + 16));
   PCC_HIP(ctx->d_simplified.ensure(4 * n));
+  PCC_HIP(ctx->d_coefs.ensure((size_t)16 * ((n / 256 + 1 + 15) / 16) * 6 * 64 + 64));
   PCC_HIP(ctx->h_state.ensure(1));
   return PCC_OK;
 }
@@ -178,7 +182,7 @@ void pcc_destroy(pcc_ctx* c) {
   c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_partials.release(); c->d_leaf_code.release(); c->d_ghist.release(); c->d_gtot.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
-  c->d_centroid.release(); c->d_image.release(); c->d_simplified.release();
+  c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
   c->h_simplified.release();
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -192,6 +196,14 @@ const char* pcc_last_error(pcc_ctx* c) { return c ? c->err.c_str() : "no context
 int pcc_set_profiling(pcc_ctx* ctx, int enabled) {
   if (!ctx) return PCC_ERR_ARG;
   ctx->profiling = enabled != 0;
+  return PCC_OK;
+}
+
+int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return PCC_ERR_ARG;
+  if (!strcmp(name, "jpeg_on_gpu")) ctx->jpeg_on_gpu = value != 0;
+  else if (!strcmp(name, "copy_image")) ctx->copy_image = value != 0;
+  else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
 }
 
@@ -277,6 +289,11 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
   a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
   a.image = ctx->d_image.p; a.simplified = ctx->d_simplified.p;
+  a.coefs = nullptr;
+  if (a.lp.write_image && ctx->jpeg_on_gpu) {
+    a.coefs = ctx->d_coefs.p;
+    BaselineJpeg::quantiser(prm->jpeg_quality, a.jq.half, a.jq.magic);
+  }
   // the key width is bounded by what the host knows: index bits from n, at most 63 code bits
   {
     int ibits = 0;
@@ -324,13 +341,21 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
 
   PCC_HIP(ctx->h_occ.ensure(B + 16));
   PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, B, hipMemcpyDeviceToHost, ctx->stream));
-  if (color) {
+  const bool want_bgr = color && (prm.color_coding_type != 1 || ctx->copy_image);
+  if (want_bgr) {
     PCC_HIP(ctx->h_bgr.ensure(3 * L + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_bgr.p, ctx->d_bgr.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
   }
-  if (image) {
+  const bool coefs = image && ctx->jpeg_on_gpu;
+  const bool want_image = image && (ctx->copy_image || !coefs);
+  const size_t n_coefs = (size_t)16 * ((H + 15) / 16) * 6 * 64;
+  if (want_image) {
     PCC_HIP(ctx->h_image.ensure((size_t)3 * W * H + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_image.p, ctx->d_image.p, (size_t)3 * W * H, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (coefs) {
+    PCC_HIP(ctx->h_coefs.ensure(n_coefs + 64));
+    PCC_HIP(hipMemcpyAsync(ctx->h_coefs.p, ctx->d_coefs.p, n_coefs * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
   }
   if (prm.do_voxel_centroid) {
     PCC_HIP(ctx->h_centroid.ensure(3 * L + 16));
@@ -345,9 +370,10 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->n_leaves = L;
   out->n_branches = B;
   out->occupancy = ctx->h_occ.p;
-  out->bgr = color ? ctx->h_bgr.p : nullptr;
+  out->bgr = want_bgr ? ctx->h_bgr.p : nullptr;
   out->centroid = prm.do_voxel_centroid ? ctx->h_centroid.p : nullptr;
-  out->image = image ? ctx->h_image.p : nullptr;
+  out->image = want_image ? ctx->h_image.p : nullptr;
+  out->jpeg_coefs = coefs ? ctx->h_coefs.p : nullptr;
   out->image_w = image ? W : 0;
   out->image_h = image ? H : 0;
   ctx->last_L = L;

@@ -43,21 +43,61 @@ inline void cumulative_table(const uint8_t* in, size_t n, uint32_t freq[257]) {
 }
 }  // namespace
 
+namespace {
+// Exact floor(n / d) for every 64-bit n by multiplication (Granlund-Montgomery round-up method,
+// as in libdivide's u64 path).  The coder divides by the same total for every symbol, and a
+// hardware 64-bit divide is the single most expensive operation of the encode loop.
+struct InvariantDiv64 {
+  uint64_t magic = 0;
+  int shift = 0;
+  bool add = false, pow2 = false;
+  explicit InvariantDiv64(uint64_t d) {
+    if ((d & (d - 1)) == 0) {
+      pow2 = true;
+      shift = __builtin_ctzll(d);
+      return;
+    }
+    const int L = 63 - __builtin_clzll(d);
+    const unsigned __int128 num = (unsigned __int128)1 << (64 + L);
+    uint64_t m = (uint64_t)(num / d);
+    const uint64_t rem = (uint64_t)(num - (unsigned __int128)m * d);
+    const uint64_t e = d - rem;
+    if (e < (1ull << L)) {
+      magic = m + 1;
+      shift = L;
+    } else {  // 65-bit magic: keep the low 64 bits and add n back in
+      const uint64_t twice_rem = rem + rem;
+      m += m;
+      if (twice_rem >= d || twice_rem < rem) m += 1;
+      magic = m + 1;
+      shift = L;
+      add = true;
+    }
+  }
+  inline uint64_t div(uint64_t n) const {
+    if (pow2) return n >> shift;
+    const uint64_t q = (uint64_t)(((unsigned __int128)n * magic) >> 64);
+    if (add) return (((n - q) >> 1) + q) >> shift;
+    return q >> shift;
+  }
+};
+}  // namespace
+
 size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
   uint32_t freq[257];
   cumulative_table(in, n, freq);
   const size_t start = out.size();
-  out.resize(start + sizeof(freq) + n + n / 2 + 64);  // worst case ~ n*log2(n+256)/8; grown below if needed
+  out.resize(start + sizeof(freq) + n + n / 2 + 64);  // grown below if the payload turns out larger
   uint8_t* p = out.data() + start;
   memcpy(p, freq, sizeof(freq));
   size_t pos = sizeof(freq);
   size_t cap = out.size() - start;
 
-  const uint64_t total = freq[256];
+  const InvariantDiv64 by_total(freq[256]);
   uint64_t low = 0, range = ~0ull;
   for (size_t i = 0; i < n; ++i) {
     const unsigned ch = in[i];
-    range /= total;
+    range = by_total.div(range);
     low += (uint64_t)freq[ch] * range;
     range *= (uint64_t)(freq[ch + 1] - freq[ch]);
     if (pos + 16 > cap) {  // a symbol emits at most 8 bytes
@@ -272,24 +312,55 @@ inline void fdct_quant(const int32_t samples[64], const Quant& q, int16_t out[64
 class BitSink {
  public:
   explicit BitSink(Bytes& out) : out_(out) {}
+  // `len` <= 27 bits per call; bytes leave the accumulator four at a time
   inline void put(uint32_t code, int len) {
-    acc_ = (acc_ << len) | (code & ((1u << len) - 1u));
+    acc_ = (acc_ << len) | (uint64_t)(code & ((1u << len) - 1u));
     n_ += len;
-    while (n_ >= 8) {
-      const uint8_t b = (uint8_t)(acc_ >> (n_ - 8));
-      out_.push_back(b);
-      if (b == 0xFF) out_.push_back(0);
-      n_ -= 8;
+    if (n_ >= 32) {
+      n_ -= 32;
+      const uint32_t w = (uint32_t)(acc_ >> n_);
+      if (used_ + 8 > out_.size()) out_.resize(out_.size() * 2 + 4096);
+      uint8_t* p = out_.data() + used_;
+      // 0xFF anywhere in the word?  (SWAR test on the complement for a zero byte)
+      const uint32_t inv = ~w;
+      if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {
+        p[0] = (uint8_t)(w >> 24); p[1] = (uint8_t)(w >> 16); p[2] = (uint8_t)(w >> 8); p[3] = (uint8_t)w;
+        used_ += 4;
+      } else {
+        size_t k = 0;
+        for (int sft = 24; sft >= 0; sft -= 8) {
+          const uint8_t b = (uint8_t)(w >> sft);
+          p[k++] = b;
+          if (b == 0xFF) p[k++] = 0;  // byte stuffing
+        }
+        used_ += k;
+      }
     }
   }
+  void start() { used_ = out_.size(); out_.resize(out_.size() + 4096); }
   void flush() {
-    put(0x7F, 7);  // pad the last byte with ones (jchuff.c flush_bits)
+    // remaining whole bytes, then pad the last one with ones (jchuff.c flush_bits)
+    while (n_ >= 8) {
+      n_ -= 8;
+      emit((uint8_t)(acc_ >> n_));
+    }
+    if (n_ > 0) {
+      const uint8_t b = (uint8_t)(((acc_ << (8 - n_)) | ((1u << (8 - n_)) - 1u)) & 0xFF);
+      emit(b);
+    }
     acc_ = 0;
     n_ = 0;
+    out_.resize(used_);
   }
 
  private:
+  inline void emit(uint8_t b) {
+    if (used_ + 2 > out_.size()) out_.resize(out_.size() * 2 + 4096);
+    out_[used_++] = b;
+    if (b == 0xFF) out_[used_++] = 0;
+  }
   Bytes& out_;
+  size_t used_ = 0;
   uint64_t acc_ = 0;
   int n_ = 0;
 };
@@ -329,13 +400,8 @@ void put_dht(Bytes& o, int tc_th, const HuffSpec& s) {
   o.insert(o.end(), s.bits, s.bits + 16);
   o.insert(o.end(), s.vals, s.vals + s.nvals);
 }
-}  // namespace
-
-void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Bytes& out) {
-  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
-  static const HuffEnc dcl(kDcLuma), acl(kAcLuma), dcc(kDcChroma), acc(kAcChroma);
-
-  // headers: SOI, JFIF APP0, DQT x2, SOF0 (2x2,1x1,1x1), DHT x4, SOS (jcmarker.c order)
+// headers: SOI, JFIF APP0, DQT x2, SOF0 (2x2,1x1,1x1), DHT x4, SOS (jcmarker.c order)
+void put_headers(Bytes& out, int w, int h, const Quant& ql, const Quant& qc) {
   be16(out, 0xFFD8);
   be16(out, 0xFFE0); be16(out, 16);
   const uint8_t jfif[14] = {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
@@ -350,6 +416,81 @@ void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Byt
   be16(out, 0xFFDA); be16(out, 12);
   const uint8_t sos[10] = {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
   out.insert(out.end(), sos, sos + 10);
+}
+
+// one block whose 64 coefficients are already in zigzag order; `dc` overrides zz[0] (dummy blocks)
+inline void huff_block_zz(BitSink& bs, const int16_t* zz, int dc, int& last_dc, const HuffEnc& dct, const HuffEnc& act) {
+  int diff = dc - last_dc;
+  last_dc = dc;
+  int mag = diff < 0 ? -diff : diff, low = diff < 0 ? diff - 1 : diff;
+  int nb = bit_length((uint32_t)mag);
+  bs.put(dct.code[nb], dct.len[nb]);
+  if (nb) bs.put((uint32_t)low, nb);
+  // skip the zero tail in 8-byte steps: most blocks of smooth colour fields end early
+  int last = 63;
+  {
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(zz);
+    int q = 15;
+    while (q > 0 && w[q] == 0) --q;
+    last = 4 * q + 3;
+    while (last > 0 && zz[last] == 0) --last;
+  }
+  int run = 0;
+  for (int k = 1; k <= last; ++k) {
+    const int v = zz[k];
+    if (v == 0) { ++run; continue; }
+    while (run > 15) { bs.put(act.code[0xF0], act.len[0xF0]); run -= 16; }
+    mag = v < 0 ? -v : v;
+    low = v < 0 ? v - 1 : v;
+    nb = bit_length((uint32_t)mag);
+    const int sym = (run << 4) | nb;
+    bs.put(act.code[sym], act.len[sym]);
+    bs.put((uint32_t)low, nb);
+    run = 0;
+  }
+  if (last < 63) bs.put(act.code[0], act.len[0]);
+}
+}  // namespace
+
+void BaselineJpeg::quantiser(int quality, uint16_t half[2][64], uint32_t magic[2][64]) {
+  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
+  for (int i = 0; i < 64; ++i) {
+    half[0][i] = ql.half[i]; magic[0][i] = ql.magic[i];
+    half[1][i] = qc.half[i]; magic[1][i] = qc.magic[i];
+  }
+}
+
+void BaselineJpeg::encode_coefs(const int16_t* coefs, int w, int h, int quality, Bytes& out) {
+  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
+  static const HuffEnc dcl(kDcLuma), acl(kAcLuma), dcc(kDcChroma), acc(kAcChroma);
+  put_headers(out, w, h, ql, qc);
+  const int y_hb = (h + 7) / 8;
+  const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
+  BitSink bs(out);
+  bs.start();
+  int last_dc[3] = {0, 0, 0};
+  for (int my = 0; my < mcus_y; ++my) {
+    const bool dummy_row = 2 * my + 1 >= y_hb;  // the MCU's second luma block row lies below the image
+    for (int mx = 0; mx < mcus_x; ++mx) {
+      const int16_t* m = coefs + ((size_t)my * mcus_x + mx) * 6 * 64;
+      huff_block_zz(bs, m, m[0], last_dc[0], dcl, acl);
+      huff_block_zz(bs, m + 64, m[64], last_dc[0], dcl, acl);
+      // dummy blocks are all zero with the DC of the block just before their row (the top-right one)
+      huff_block_zz(bs, m + 128, dummy_row ? m[64] : m[128], last_dc[0], dcl, acl);
+      huff_block_zz(bs, m + 192, dummy_row ? m[64] : m[192], last_dc[0], dcl, acl);
+      huff_block_zz(bs, m + 256, m[256], last_dc[1], dcc, acc);
+      huff_block_zz(bs, m + 320, m[320], last_dc[2], dcc, acc);
+    }
+  }
+  bs.flush();
+  be16(out, 0xFFD9);
+}
+
+void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Bytes& out) {
+  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
+  static const HuffEnc dcl(kDcLuma), acl(kAcLuma), dcc(kDcChroma), acc(kAcChroma);
+
+  put_headers(out, w, h, ql, qc);
 
   // colour planes (jccolor.c rgb_ycc_convert, 16-bit fixed point)
   const size_t npx = (size_t)w * h;
@@ -367,8 +508,8 @@ void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Byt
   const int ch = (h + 1) / 2;                    // real chroma rows
   const int y_wb = (w + 7) / 8, y_hb = (h + 7) / 8;  // real luma blocks
   const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
-  out.reserve(out.size() + npx / 2 + 1024);
   BitSink bs(out);
+  bs.start();
   int last_dc[3] = {0, 0, 0};
   int16_t blk[6][64];
   int32_t smp[64];
@@ -734,7 +875,10 @@ void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Byte
     const uint8_t* src = hot.bgr;
     size_t src_len = 3 * L;
     if (prm.color_coding_type == 1) {  // one 256-wide snake-mapped image (jpegcc.h:187-226)
-      BaselineJpeg::encode_rgb(hot.image, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
+      if (hot.jpeg_coefs)
+        BaselineJpeg::encode_coefs(hot.jpeg_coefs, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
+      else
+        BaselineJpeg::encode_rgb(hot.image, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
       src = payload.data();
       src_len = payload.size();
     } else if (prm.color_coding_type == 2) {  // 2048x1 lines (jpegcc.h:244-317)

@@ -27,6 +27,12 @@ class StaticRangeCoder {
 class BaselineJpeg {
  public:
   static void encode_rgb(const uint8_t* rgb, int w, int h, int quality, Bytes& out);
+  // Same file from quantised coefficients (6 x 64 per MCU, zigzag order) produced by the GPU front end:
+  // headers + Huffman coding only.  Blocks of dummy rows below the image carry zeros; their DC is
+  // taken from the preceding block here (jccoefct.c).
+  static void encode_coefs(const int16_t* coefs, int w, int h, int quality, Bytes& out);
+  // The quantiser the GPU front end needs for `quality` (natural order; see pcc_kernels.h JpegQuant)
+  static void quantiser(int quality, uint16_t half[2][64], uint32_t magic[2][64]);
   static bool decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h);
 };
 

@@ -26,6 +26,13 @@ struct LeafParams {
   uint32_t ablate;           // profiling only (PCC_ABLATE): 1 no colour gather, 2 no colour stores, 4 no occupancy, 8 no simplified
 };
 
+// Quantiser of the JPEG front end: per component (0 luma, 1 chroma), natural order:
+// half = (8q) >> 1, magic = floor(2^32 / (8q)) + 1 (exact reciprocal for |coef| + half < 2^17).
+struct JpegQuant {
+  uint16_t half[2][64];
+  uint32_t magic[2][64];
+};
+
 struct HotPathArgs {
   PointView pv;
   uint32_t n;
@@ -51,6 +58,8 @@ struct HotPathArgs {
   uint8_t* centroid;
   uint8_t* image;
   void* simplified;  // float4 per leaf (x, y, z, rgba bits)
+  int16_t* coefs;    // quantised JPEG coefficients, 6 x 64 per MCU in zigzag order (null: JPEG on the host)
+  JpegQuant jq;
 };
 
 // Optional per-kernel timing: one HIP event after every launch, on the launch stream.

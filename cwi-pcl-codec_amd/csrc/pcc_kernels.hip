@@ -894,6 +894,115 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
 }
 
 // ------------------------------------------------------------------------------------------
+// Stage 6: JPEG front end on the snake-mapped image (jpeg_io.hpp:259-314 drives libjpeg with
+// JCS_RGB in, YCbCr 4:2:0, islow FDCT, quality-scaled Annex-K tables).  Everything up to the
+// quantised coefficients is exact integer arithmetic and embarrassingly parallel; only the Huffman
+// bit packing stays on the host.  One thread per 8x8 block, six blocks per 16x16 MCU
+// (Y00 Y01 Y10 Y11 Cb Cr), coefficients written in zigzag order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int jpeg_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jfdctint.c butterfly (13-bit constants).  PASS1: even outputs shifted up by 2, odd descaled by 11;
+// PASS2: even descaled by 2, odd by 15.
+template <bool PASS1>
+__device__ __forceinline__ void jpeg_fdct_1d(int& d0, int& d1, int& d2, int& d3, int& d4, int& d5, int& d6, int& d7) {
+  const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+  const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  constexpr int DN = PASS1 ? 11 : 15;
+  d0 = PASS1 ? ((t10 + t11) << 2) : jpeg_descale(t10 + t11, 2);
+  d4 = PASS1 ? ((t10 - t11) << 2) : jpeg_descale(t10 - t11, 2);
+  int z1 = (t12 + t13) * 4433;
+  d2 = jpeg_descale(z1 + t13 * 6270, DN);
+  d6 = jpeg_descale(z1 + t12 * (-15137), DN);
+  z1 = t4 + t7;
+  int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int z5 = (z3 + z4) * 9633;
+  const int a4 = t4 * 2446, a5 = t5 * 16819, a6 = t6 * 25172, a7 = t7 * 12299;
+  z1 *= -7373; z2 *= -20995;
+  z3 = z3 * (-16069) + z5;
+  z4 = z4 * (-3196) + z5;
+  d7 = jpeg_descale(a4 + z1 + z3, DN);
+  d5 = jpeg_descale(a5 + z2 + z4, DN);
+  d3 = jpeg_descale(a6 + z2 + z3, DN);
+  d1 = jpeg_descale(a7 + z1 + z4, DN);
+}
+
+
+__global__ __launch_bounds__(64) void k_jpeg_fdct(const uint8_t* __restrict__ image, const FrameState* __restrict__ st,
+                                                  JpegQuant q, int16_t* __restrict__ coefs) {
+  const uint32_t L = st->n_leaves;
+  if (L == 0) return;
+  const int W = 256, H = (int)(L / 256u + 1u);
+  const int mcus_x = W / 16, mcus_y = (H + 15) / 16;
+  const uint32_t gid = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t mcu = gid / 6u, slot = gid % 6u;
+  if (mcu >= (uint32_t)(mcus_x * mcus_y)) return;
+  const int mx = (int)(mcu % (uint32_t)mcus_x), my = (int)(mcu / (uint32_t)mcus_x);
+  int16_t* out = coefs + (size_t)gid * 64;
+  const int y_hb = (H + 7) / 8, ch = (H + 1) / 2;
+  // compile-time table + full unrolling keeps the 64 samples in registers (no scratch indexing)
+  constexpr uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  int s[64];
+  if (slot < 4) {
+    const int by = 2 * my + (int)(slot >> 1), bx = 2 * mx + (int)(slot & 1);
+    if (by >= y_hb) {  // dummy block row below the image: the host copies the DC of the previous block
+#pragma unroll
+      for (int k = 0; k < 8; ++k) reinterpret_cast<uint4*>(out)[k] = make_uint4(0, 0, 0, 0);
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint8_t* row = image + ((size_t)min(8 * by + r, H - 1) * W + 8 * bx) * 3;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int R = row[3 * c], G = row[3 * c + 1], B = row[3 * c + 2];
+        s[8 * r + c] = ((19595 * R + 38470 * G + 7471 * B + 32768) >> 16) - 128;
+      }
+    }
+  } else {
+    const bool is_cr = slot == 5;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int crow = min(8 * my + r, ch - 1);  // component rows below the image repeat the last real one
+      const uint8_t* r0 = image + ((size_t)min(2 * crow, H - 1) * W + 16 * mx) * 3;
+      const uint8_t* r1 = image + ((size_t)min(2 * crow + 1, H - 1) * W + 16 * mx) * 3;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int sum = (c & 1) ? 2 : 1;  // jcsample.c h2v2_downsample bias 1,2,1,2 (8*mx is even)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint8_t* p = ((k & 2) ? r1 : r0) + 3 * (2 * c + (k & 1));
+          const int R = p[0], G = p[1], B = p[2];
+          sum += is_cr ? ((32768 * R - 27439 * G - 5329 * B + (128 << 16) + 32767) >> 16)
+                       : ((-11059 * R - 21709 * G + 32768 * B + (128 << 16) + 32767) >> 16);
+        }
+        s[8 * r + c] = (sum >> 2) - 128;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    jpeg_fdct_1d<true>(s[8 * r], s[8 * r + 1], s[8 * r + 2], s[8 * r + 3], s[8 * r + 4], s[8 * r + 5], s[8 * r + 6], s[8 * r + 7]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    jpeg_fdct_1d<false>(s[c], s[8 + c], s[16 + c], s[24 + c], s[32 + c], s[40 + c], s[48 + c], s[56 + c]);
+  // quantise: (|v| + 4q) / 8q with the sign restored; the reciprocal is exact for these magnitudes
+  const int comp = slot < 4 ? 0 : 1;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int v = s[i];
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v) + q.half[comp][i];
+    const int r = (int)(((uint64_t)a * q.magic[comp][i]) >> 32);
+    s[i] = v < 0 ? -r : r;
+  }
+#pragma unroll
+  for (int k = 0; k < 64; ++k) out[k] = (int16_t)s[zz[k]];
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launch sequence
 // ------------------------------------------------------------------------------------------
 #define PCC_STAMP(name)                                      \
@@ -935,6 +1044,12 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
                      reinterpret_cast<float4*>(a.simplified));
   PCC_STAMP("k_leaf_finalize");
+  if (a.lp.write_image && a.coefs) {
+    const uint32_t max_h = n / 256u + 1u;
+    const uint32_t max_blocks = 16u * ((max_h + 15u) / 16u) * 6u;  // 8x8 blocks of the tallest possible image
+    hipLaunchKernelGGL(k_jpeg_fdct, dim3((max_blocks + 63u) / 64u), dim3(64), 0, stream, a.image, a.state, a.jq, a.coefs);
+    PCC_STAMP("k_jpeg_fdct");
+  }
 }
 
 }  // namespace pcc

@@ -79,6 +79,9 @@ typedef struct pcc_hot_result {
   const uint8_t *image;      /* snake-mapped 3*W*H image (color_coding_type 1), else NULL */
   uint32_t image_w, image_h;
   float gpu_ms;              /* HIP-event time of the kernel sequence */
+  /* JPEG front end done on the GPU for the snake image: quantised coefficients, 6 blocks of 64 per
+   * 16x16 MCU (Y00 Y01 Y10 Y11 Cb Cr) in zigzag order; NULL if the host has to start from `image`. */
+  const int16_t *jpeg_coefs;
 } pcc_hot_result;
 
 typedef struct pcc_bitstream {
@@ -148,6 +151,12 @@ int pcc_device_upload(pcc_ctx *ctx, void *dev_dst, const void *host_src, size_t 
 int pcc_get_kernel_times(pcc_ctx *ctx, pcc_kernel_times *out);
 /* enable per-kernel HIP-event timing (off by default: events between launches cost a little) */
 int pcc_set_profiling(pcc_ctx *ctx, int enabled);
+/* context knobs (do not change any output byte):
+ *   "jpeg_on_gpu" (default 1): colour conversion, 4:2:0 downsample, FDCT and quantisation of the snake image on
+ *                 the GPU, so that the host only Huffman-codes;  0: the host starts from the image.
+ *   "copy_image"  (default 1): bring the snake-mapped image itself back in pcc_hot_result.image (needed only
+ *                 for inspection when jpeg_on_gpu is 1). */
+int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 
 /* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
 /* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).

@@ -323,3 +323,21 @@ def test_cpp_shim_example_runs(pkg):
     r = subprocess.run([exe, "200000", "9"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "decoded voxels" in r.stdout
+
+
+@pytest.mark.parametrize("L", [200, 2048, 4000, 70001])
+def test_jpeg_front_end_on_gpu_equals_host_jpeg(pkg, oracle, L):
+    """k_jpeg_fdct + host Huffman must give the bytes of the all-host JPEG (and of libjpeg-turbo, via the oracle)."""
+    g = np.arange(L, dtype=np.float32)
+    xyz = np.stack([(g % 128) / 128.0, ((g // 128) % 128) / 128.0, (g // 16384) / 128.0], 1) + 1.0 / 512
+    pts = cloud(pkg, xyz, seed=L)
+    for q in (85, 30):
+        kw = dict(octree_bits=7, color_coding_type=1, jpeg_quality=q)
+        want = oracle.encode_intra(pts, oracle.make_params(**kw), keep=False)
+        for on_gpu, copy_image in ((1, 0), (0, 1)):
+            c = pkg.binding.Context(0)
+            c.set_option("jpeg_on_gpu", on_gpu)
+            c.set_option("copy_image", copy_image)
+            stream, perf = c.encode_intra_host(pts, pkg.binding.make_params(**kw))
+            c.close()
+            assert stream == want.bitstream, (L, q, on_gpu)
