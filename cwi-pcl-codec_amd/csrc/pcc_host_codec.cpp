@@ -19,9 +19,15 @@ namespace pcc {
 // =============================================================================================
 // static range coder
 // =============================================================================================
+// The reference only ever calls the CHAR-vector variant (encodeCharVectorToStream /
+// decodeStreamToCharVector).  That variant is the 32-bit coder: DWord (uint32_t) freq[257] -- hence
+// the 1028-byte table -- DWord low/range, top = 1<<24, bottom = 1<<16, maxRange = 1<<16 (the
+// cumulative table is halved until its total is below 2^16), one output byte = low >> 24, 4 flush
+// bytes.  (The 1<<56 / 1<<48 constants belong to the INT-vector variant, which this path never uses.)
 namespace {
-constexpr uint64_t kTop = 1ull << 56;
-constexpr uint64_t kBottom = 1ull << 48;
+constexpr uint32_t kTop = 1u << 24;
+constexpr uint32_t kBottom = 1u << 16;
+constexpr uint32_t kMaxRange = 1u << 16;
 
 inline void cumulative_table(const uint8_t* in, size_t n, uint32_t freq[257]) {
   // four interleaved histograms: avoids store-to-load stalls on runs of equal bytes
@@ -39,47 +45,21 @@ inline void cumulative_table(const uint8_t* in, size_t n, uint32_t freq[257]) {
     if (v <= freq[s]) v = freq[s] + 1;  // forced strictly increasing: absent symbols get count 1
     freq[s + 1] = v;
   }
-  // PCL rescales while freq[256] >= 2^48; unreachable with a 32-bit table.
+  // "rescale if numerical limits are reached"
+  while (freq[256] >= kMaxRange) {
+    for (int f = 1; f <= 256; ++f) {
+      freq[f] /= 2;
+      if (freq[f] <= freq[f - 1]) freq[f] = freq[f - 1] + 1;
+    }
+  }
 }
-}  // namespace
 
-namespace {
-// Exact floor(n / d) for every 64-bit n by multiplication (Granlund-Montgomery round-up method,
-// as in libdivide's u64 path).  The coder divides by the same total for every symbol, and a
-// hardware 64-bit divide is the single most expensive operation of the encode loop.
-struct InvariantDiv64 {
-  uint64_t magic = 0;
-  int shift = 0;
-  bool add = false, pow2 = false;
-  explicit InvariantDiv64(uint64_t d) {
-    if ((d & (d - 1)) == 0) {
-      pow2 = true;
-      shift = __builtin_ctzll(d);
-      return;
-    }
-    const int L = 63 - __builtin_clzll(d);
-    const unsigned __int128 num = (unsigned __int128)1 << (64 + L);
-    uint64_t m = (uint64_t)(num / d);
-    const uint64_t rem = (uint64_t)(num - (unsigned __int128)m * d);
-    const uint64_t e = d - rem;
-    if (e < (1ull << L)) {
-      magic = m + 1;
-      shift = L;
-    } else {  // 65-bit magic: keep the low 64 bits and add n back in
-      const uint64_t twice_rem = rem + rem;
-      m += m;
-      if (twice_rem >= d || twice_rem < rem) m += 1;
-      magic = m + 1;
-      shift = L;
-      add = true;
-    }
-  }
-  inline uint64_t div(uint64_t n) const {
-    if (pow2) return n >> shift;
-    const uint64_t q = (uint64_t)(((unsigned __int128)n * magic) >> 64);
-    if (add) return (((n - q) >> 1) + q) >> shift;
-    return q >> shift;
-  }
+// Exact floor(n / d) for every 32-bit n and 2 <= d < 2^32: q = mulhi64(ceil(2^64 / d), n).
+// The coder divides by the same total for every symbol; this replaces the hardware divide.
+struct InvariantDiv32 {
+  uint64_t magic;
+  explicit InvariantDiv32(uint32_t d) : magic(~0ull / d + 1) {}
+  inline uint32_t div(uint32_t n) const { return (uint32_t)(((unsigned __int128)magic * n) >> 64); }
 };
 }  // namespace
 
@@ -93,32 +73,32 @@ size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
   size_t pos = sizeof(freq);
   size_t cap = out.size() - start;
 
-  const InvariantDiv64 by_total(freq[256]);
-  uint64_t low = 0, range = ~0ull;
+  const InvariantDiv32 by_total(freq[256]);  // 256 <= total < 2^16
+  uint32_t low = 0, range = ~0u;
   for (size_t i = 0; i < n; ++i) {
     const unsigned ch = in[i];
     range = by_total.div(range);
-    low += (uint64_t)freq[ch] * range;
-    range *= (uint64_t)(freq[ch + 1] - freq[ch]);
-    if (pos + 16 > cap) {  // a symbol emits at most 8 bytes
+    low += freq[ch] * range;
+    range *= freq[ch + 1] - freq[ch];
+    if (pos + 8 > cap) {  // a symbol emits at most 4 bytes
       out.resize(start + cap * 2);
       p = out.data() + start;
       cap = out.size() - start;
     }
     // emit while the top byte is settled, or the range underflowed (then it is clamped to the
-    // distance to the next 2^48 boundary: range = -low & (2^48 - 1))
+    // distance to the next 2^16 boundary: range = -int(low) & (bottom - 1))
     for (;;) {
       if ((low ^ (low + range)) >= kTop) {
         if (range >= kBottom) break;
-        range = (0 - low) & (kBottom - 1);
+        range = (0u - low) & (kBottom - 1);
       }
-      p[pos++] = (uint8_t)(low >> 56);
+      p[pos++] = (uint8_t)(low >> 24);
       range <<= 8;
       low <<= 8;
     }
   }
-  for (int i = 0; i < 8; ++i) {
-    p[pos++] = (uint8_t)(low >> 56);
+  for (int i = 0; i < 4; ++i) {
+    p[pos++] = (uint8_t)(low >> 24);
     low <<= 8;
   }
   out.resize(start + pos);
@@ -127,27 +107,27 @@ size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
 
 size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n) {
   uint32_t freq[257];
-  if (in_len < sizeof(freq) + 8) return 0;
+  if (in_len < sizeof(freq) + 4) return 0;
   memcpy(freq, in, sizeof(freq));
   size_t pos = sizeof(freq);
-  uint64_t code = 0, low = 0, range = ~0ull;
-  for (int i = 0; i < 8; ++i) code = (code << 8) | in[pos++];
-  const uint64_t total = freq[256];
+  uint32_t code = 0, low = 0, range = ~0u;
+  for (int i = 0; i < 4; ++i) code = (code << 8) | in[pos++];
+  const uint32_t total = freq[256];
   if (total == 0) return 0;
   for (size_t i = 0; i < n; ++i) {
     range /= total;
-    if (range == 0) return 0;
-    const uint64_t count = (code - low) / range;
+    if (range == 0) return 0;  // corrupt table: PCL would divide by zero here
+    const uint32_t count = (code - low) / range;
     unsigned sym = 0;
     for (unsigned step = 128; step; step >>= 1)
-      if ((uint64_t)freq[sym + step] <= count) sym += step;
+      if (freq[sym + step] <= count) sym += step;
     out[i] = (uint8_t)sym;
-    low += (uint64_t)freq[sym] * range;
-    range *= (uint64_t)(freq[sym + 1] - freq[sym]);
+    low += freq[sym] * range;
+    range *= freq[sym + 1] - freq[sym];
     for (;;) {
       if ((low ^ (low + range)) >= kTop) {
         if (range >= kBottom) break;
-        range = (0 - low) & (kBottom - 1);
+        range = (0u - low) & (kBottom - 1);
       }
       const uint8_t b = pos < in_len ? in[pos] : 0;
       ++pos;

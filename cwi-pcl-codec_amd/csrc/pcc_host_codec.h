@@ -17,7 +17,7 @@ typedef std::vector<uint8_t> Bytes;
 // pcl::StaticRangeCoder (call sites impl.hpp:1694,1706,1719 / 1778,1789,1798)
 class StaticRangeCoder {
  public:
-  // appends 1028-byte table + payload + 8 flush bytes to `out`; returns bytes appended
+  // appends 1028-byte table + payload + 4 flush bytes to `out`; returns bytes appended
   static size_t encode(const uint8_t* in, size_t n, Bytes& out);
   // returns bytes consumed, 0 on a truncated stream
   static size_t decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n);

@@ -11,11 +11,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # ---------------- range coder ----------------
 
 def test_rc_empty_vector_kat(oracle):
-    """Empty input: table = 0,1,...,256 (every symbol forced to count 1) + 8 flush bytes of zero."""
+    """Empty input: table = 0,1,...,256 (every symbol forced to count 1) + 4 flush bytes of zero."""
     enc = oracle.rc_encode(b"")
-    assert len(enc) == 1028 + 8
+    assert len(enc) == 1028 + 4
     assert struct.unpack("<257I", enc[:1028]) == tuple(range(257))
-    assert enc[1028:] == bytes(8)
+    assert enc[1028:] == bytes(4)
 
 
 def test_rc_single_symbol_table(oracle):
@@ -44,40 +44,67 @@ def test_rc_round_trip(oracle, n, kind):
     assert used == len(enc)  # the decoder consumes exactly what the encoder wrote
 
 
-def test_rc_python_model_agrees(oracle):
-    """Independent pure-Python transcription of the P7 loop (small input)."""
-    rng = np.random.default_rng(11)
-    data = bytes(np.minimum(rng.geometric(0.2, 3000), 255).astype(np.uint8))
-    M = (1 << 64) - 1
+def _py_rc_encode(data):
+    """Independent pure-Python transcription of pcl::StaticRangeCoder::encodeCharVectorToStream
+    (32-bit DWord state, top 1<<24, bottom 1<<16, maxRange 1<<16)."""
+    M = (1 << 32) - 1
     hist = [0] * 257
     for s in data:
         hist[s + 1] += 1
     freq = [0] * 257
     for f in range(1, 257):
-        freq[f] = freq[f - 1] + hist[f]
+        freq[f] = (freq[f - 1] + hist[f]) & M
         if freq[f] <= freq[f - 1]:
             freq[f] = freq[f - 1] + 1
+    while freq[256] >= (1 << 16):
+        for f in range(1, 257):
+            freq[f] //= 2
+            if freq[f] <= freq[f - 1]:
+                freq[f] = freq[f - 1] + 1
     out = bytearray(struct.pack("<257I", *freq))
     low, rng_ = 0, M
-    top, bottom = 1 << 56, 1 << 48
+    top, bottom = 1 << 24, 1 << 16
     for ch in data:
         rng_ //= freq[256]
         low = (low + freq[ch] * rng_) & M
         rng_ = (rng_ * (freq[ch + 1] - freq[ch])) & M
         while True:
-            if ((low ^ ((low + rng_) & M)) < top):
+            if (low ^ ((low + rng_) & M)) < top:
                 pass
             elif rng_ < bottom:
                 rng_ = ((-low) & M) & (bottom - 1)
             else:
                 break
-            out.append(low >> 56)
+            out.append(low >> 24)
             rng_ = (rng_ << 8) & M
             low = (low << 8) & M
-    for _ in range(8):
-        out.append(low >> 56)
+    for _ in range(4):
+        out.append(low >> 24)
         low = (low << 8) & M
-    assert bytes(out) == oracle.rc_encode(data)
+    return bytes(out), freq
+
+
+def test_rc_python_model_agrees(oracle):
+    rng = np.random.default_rng(11)
+    data = bytes(np.minimum(rng.geometric(0.2, 3000), 255).astype(np.uint8))
+    want, freq = _py_rc_encode(data)
+    assert freq[256] == 3000 + 256 - len(set(data))  # no rescale below 2^16 symbols
+    assert want == oracle.rc_encode(data)
+
+
+def test_rc_table_is_rescaled_below_2_16(oracle):
+    """More than 65535 symbols: the cumulative table is halved (maxRange = 1<<16) and stays strictly
+    increasing, so rare symbols keep a non-zero slot; the stream still round-trips."""
+    rng = np.random.default_rng(12)
+    data = bytes(np.minimum(rng.geometric(0.05, 150_000), 255).astype(np.uint8))
+    enc = oracle.rc_encode(data)
+    freq = struct.unpack("<257I", enc[:1028])
+    assert 256 <= freq[256] < (1 << 16)
+    assert all(freq[i + 1] > freq[i] for i in range(256))
+    want, pyfreq = _py_rc_encode(data)
+    assert tuple(pyfreq) == freq and want == enc
+    dec, used = oracle.rc_decode(enc, len(data))
+    assert dec == data and used == len(enc)
 
 
 # ---------------- snake mapping ----------------
