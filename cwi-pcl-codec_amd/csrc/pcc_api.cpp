@@ -75,9 +75,9 @@ struct pcc_ctx {
   DevBuf<uint8_t> d_points;  // only for the host-input entry point
   DevBuf<ChunkBox> d_boxes;
   DevBuf<FrameState> d_state;
-  DevBuf<uint64_t> d_keys_a, d_keys_b, d_partials, d_leaf_code;
-  DevBuf<uint32_t> d_ghist, d_gtot, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
-  DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image;
+  DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
+  DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
+  DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image, d_sync;
   DevBuf<float> d_simplified;  // 4 floats per leaf
   DevBuf<int16_t> d_coefs;     // JPEG coefficients of the snake image
 
@@ -92,6 +92,8 @@ struct pcc_ctx {
   Bytes bitstream;
 
   // frame in flight
+  HotPathArgs args{};          // what was enqueued (kept so that a frame that needs more sort passes can be re-run)
+  int pass_hint = kMaxPasses;  // sort passes to enqueue: the previous frame's need (sequences are coherent)
   bool launched = false;
   size_t n = 0;
   pcc_params params{};
@@ -122,15 +124,16 @@ int hip_fail(pcc_ctx* c, hipError_t e, const char* what) {
 
 int reserve(pcc_ctx* ctx, size_t n) {
   const size_t tiles = (n + kTile - 1) / kTile;
+  const size_t stiles = (n + kSortTile - 1) / kSortTile;
   PCC_HIP(ctx->d_boxes.ensure(tiles));
   PCC_HIP(ctx->d_state.ensure(1));
   PCC_HIP(ctx->d_keys_a.ensure(n));
   PCC_HIP(ctx->d_keys_b.ensure(n));
   PCC_HIP(ctx->d_idx_a.ensure(n));
   PCC_HIP(ctx->d_idx_b.ensure(n));
-  PCC_HIP(ctx->d_partials.ensure(tiles));
-  PCC_HIP(ctx->d_ghist.ensure(tiles * kRadixSize));
-  PCC_HIP(ctx->d_gtot.ensure(kRadixSize));
+  PCC_HIP(ctx->d_hist_rows.ensure(stiles * kMaxPasses * kMaxBins));
+  PCC_HIP(ctx->d_digit_tot.ensure((size_t)kMaxPasses * kMaxBins));
+  PCC_HIP(ctx->d_sync.ensure(sync_area_bytes((uint32_t)n, kMaxPasses)));
   PCC_HIP(ctx->d_leaf_start.ensure(n + 1));
   PCC_HIP(ctx->d_leaf_code.ensure(n));
   PCC_HIP(ctx->d_leaf_base.ensure(n));
@@ -142,6 +145,17 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_simplified.ensure(4 * n));
   PCC_HIP(ctx->d_coefs.ensure((size_t)16 * ((n / 256 + 1 + 15) / 16) * 6 * 64 + 64));
   PCC_HIP(ctx->h_state.ensure(1));
+  return PCC_OK;
+}
+
+// the kernel sequence of one frame + the FrameState read-back, all asynchronous on the context's stream
+int enqueue(pcc_ctx* ctx) {
+  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+  if (ctx->profiling) ctx->timer.reset();
+  launch_hot_path(ctx->args, ctx->stream, ctx->profiling ? &ctx->timer : nullptr);
+  PCC_HIP(hipGetLastError());
+  PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->h_state.p, ctx->d_state.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
   return PCC_OK;
 }
 
@@ -180,7 +194,7 @@ void pcc_destroy(pcc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
-  c->d_partials.release(); c->d_leaf_code.release(); c->d_ghist.release(); c->d_gtot.release();
+  c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
@@ -246,7 +260,7 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   if (n && !dev_points) return fail(ctx, PCC_ERR_ARG, "null point array");
   if (stride < 12 || (stride & 3) || rgb_offset + 4 > stride || (rgb_offset & 3))
     return fail(ctx, PCC_ERR_ARG, "stride/rgb_offset: need stride >= 12, 4-byte aligned fields");
-  if (n >= (1ull << 31)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^31 points");
+  if (n >= (1ull << 30)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^30 points");
   if (!(prm->octree_resolution > 0.0) || !std::isfinite(prm->octree_resolution))
     return fail(ctx, PCC_ERR_ARG, "octree_resolution must be positive");
   PCC_HIP(hipSetDevice(ctx->device));
@@ -273,7 +287,7 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   if (prm->color_coding_type == 0 && prm->color_bit_resolution <= 0) a.lp.color_reduction = 8;
   a.lp.do_centroid = prm->do_voxel_centroid ? 1u : 0u;
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
-  a.max_passes = 8;  // 64 key bits / 8; the device skips the passes it does not need
+  a.max_passes = std::min(std::max(ctx->pass_hint, 1), (int)kMaxPasses);
   {
     const char* ab = getenv("PCC_ABLATE");  // profiling hook: switch parts of k_leaf_finalize off (results are then wrong)
     a.lp.ablate = ab ? (uint32_t)atoi(ab) : 0u;
@@ -285,7 +299,7 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
   a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
-  a.ghist = ctx->d_ghist.p; a.gtot = ctx->d_gtot.p; a.partials = ctx->d_partials.p;
+  a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.sync_area = ctx->d_sync.p;
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
   a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
   a.image = ctx->d_image.p; a.simplified = ctx->d_simplified.p;
@@ -294,20 +308,9 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
     a.coefs = ctx->d_coefs.p;
     BaselineJpeg::quantiser(prm->jpeg_quality, a.jq.half, a.jq.magic);
   }
-  // the key width is bounded by what the host knows: index bits from n, at most 63 code bits
-  {
-    int ibits = 0;
-    while ((n >> ibits) != 0) ++ibits;
-    (void)ibits;
-    a.max_passes = 8;  // up to 63 code bits + flag in pairs mode
-  }
-
-  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
-  if (ctx->profiling) ctx->timer.reset();
-  launch_hot_path(a, ctx->stream, ctx->profiling ? &ctx->timer : nullptr);
-  PCC_HIP(hipGetLastError());
-  PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
-  PCC_HIP(hipMemcpyAsync(ctx->h_state.p, ctx->d_state.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->args = a;
+  rc = enqueue(ctx);
+  if (rc != PCC_OK) return rc;
   ctx->launched = true;
   return PCC_OK;
 }
@@ -322,6 +325,14 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   PCC_HIP(hipSetDevice(ctx->device));
   PCC_HIP(hipStreamSynchronize(ctx->stream));
   const FrameState& st = *ctx->h_state.p;
+  if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
+    // deeper tree than the frames before: run the frame again with every pass enqueued
+    ctx->args.max_passes = kMaxPasses;
+    const int rc = enqueue(ctx);
+    if (rc != PCC_OK) return rc;
+    PCC_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (st.n_epochs != 0 && st.error == kErrNone) ctx->pass_hint = st.npasses;
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end);
   out->gpu_ms = ms;

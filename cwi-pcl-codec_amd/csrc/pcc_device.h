@@ -7,10 +7,13 @@
 //   points      N x stride B   caller's pcl::PointXYZRGB array (x,y,z at 0, colour word at rgb_off)
 //   chunk_box   ceil(N/2048) x 32 B   per-chunk AABB + first finite index + finite count
 //   state       1 x FrameState  epochs of the adaptive bounding box, sort geometry, L, B
-//   keys[2]     N x u64         packed (flag | morton | index) sort keys, ping-pong
+//   keys[2]     N x u64         packed (morton | index) sort keys, ping-pong; ~0 marks a non-finite point
 //   idx[2]      N x u32         point index payload, only touched in pairs mode (code + index bits > 64)
-//   radix_hist  256 x ceil(N/2048) x u32   per-tile digit counts / row prefixes
-//   tile_part   ceil(N/2048) x u64         (sum t << 32 | sum head) partials of the leaf scan
+//   hist_rows   ceil(N/4096) x kMaxPasses x 512 x u32   per-tile digit counts of every pass (from k_make_keys)
+//   digit_tot   kMaxPasses x 512 x u32                  column sums of hist_rows
+//   status      kMaxPasses x ceil(N/4096) x 512 x u32   decoupled look-back words of the sort passes
+//   leaf_status ceil(N/4096) x u64                      decoupled look-back words of the leaf scan
+//   tickets     (kMaxPasses + 1) x u32                  dynamic tile ids (forward progress of the look-back)
 //   leaf_start  (N+1) x u32     first sorted position of each leaf
 //   leaf_code   N x u64         morton code of each leaf (sorted, unique)
 //   leaf_base   N x u32         DFS byte offset of the first branch node a leaf opens
@@ -27,8 +30,15 @@ constexpr int kItems = 8;          // items per thread in tiled kernels
 constexpr int kTile = kBlock * kItems;  // 2048 items per tile / bbox chunk
 constexpr int kMaxEpochs = 40;     // depth <= 32 => at most 33 growth events (+ first point)
 constexpr int kMaxDepth = 21;      // 3*D morton bits must fit 63 bits
-constexpr int kRadixBits = 8;
-constexpr int kRadixSize = 1 << kRadixBits;
+// sort: onesweep-style LSD radix sort, one kernel per pass, digit width chosen per frame (<= 9 bits)
+constexpr int kSortThreads = 512;          // 8 wave64 per workgroup
+constexpr int kSortItems = 8;              // keys per thread
+constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 keys per tile
+constexpr int kMaxDigitBits = 9;
+constexpr int kMaxBins = 1 << kMaxDigitBits;  // 512 = one digit per thread in the look-back
+constexpr int kMaxPasses = 7;              // 63 code bits / 9
+constexpr uint32_t kStatusAggregate = 1u << 30, kStatusInclusive = 2u << 30, kStatusValue = (1u << 30) - 1u;
+constexpr uint32_t kSpinLimit = 1u << 22;  // bounded polling: a lost predecessor becomes an error, not a hang
 
 struct ChunkBox {          // 32 bytes
   float mn[3];
@@ -42,6 +52,8 @@ enum FrameError : int32_t {
   kErrDepth = 1,           // depth > kMaxDepth
   kErrPrefix = 2,          // a key fell outside the predicted varying-bit window (should not happen)
   kErrEpochs = 3,          // more than kMaxEpochs growth epochs
+  kErrPasses = 4,          // the frame needs more sort passes than the host enqueued (host re-launches)
+  kErrSpin = 5,            // a look-back poll ran into kSpinLimit (should not happen)
 };
 
 struct FrameState {
@@ -60,8 +72,10 @@ struct FrameState {
   int32_t vbits;                     // 3 * vbits_axis
   int32_t ibits;                     // index bits in the packed key (0 in pairs mode)
   int32_t packed;                    // 1: [flag|code|index] in one u64;  0: u64 code keys + u32 index payload
-  int32_t flagbit;                   // 1 if non-finite points exist (extra sort bit above the code)
-  int32_t npasses;                   // radix passes actually needed
+  int32_t npasses;                   // radix passes actually needed (>= 1)
+  int32_t pass_bits[kMaxPasses];     // digit width of each pass
+  int32_t pass_shift[kMaxPasses];    // bit position of each digit inside the code (add ibits for the packed key)
+  int32_t passes_launched;           // what the host enqueued (k_bbox_events checks npasses against it)
   uint32_t prefix[3];                // constant high key bits per axis (in place)
   // ---- leaves ----
   uint32_t n_leaves;                 // L

@@ -38,7 +38,7 @@ struct HotPathArgs {
   uint32_t n;
   double res;
   LeafParams lp;
-  int max_passes;  // radix passes to enqueue (device decides how many do work)
+  int max_passes;  // sort passes to enqueue (the device decides how many do work; more needed => kErrPasses)
   int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
   ChunkBox* boxes;
   FrameState* state;
@@ -46,9 +46,9 @@ struct HotPathArgs {
   uint64_t* keys_b;
   uint32_t* idx_a;
   uint32_t* idx_b;
-  uint32_t* ghist;
-  uint32_t* gtot;
-  uint64_t* partials;
+  uint32_t* hist_rows;  // [sort tiles][kMaxPasses][kMaxBins] digit counts from k_make_keys
+  uint32_t* digit_tot;  // [kMaxPasses][kMaxBins]
+  uint8_t* sync_area;   // tickets | leaf scan status | sort status (sync_area_bytes), zeroed by k_chunk_boxes
   uint32_t* leaf_start;
   uint64_t* leaf_code;
   uint32_t* leaf_base;
@@ -96,6 +96,7 @@ class KernelTimer {
   size_t used_ = 0;
 };
 
+size_t sync_area_bytes(uint32_t n, int passes);
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm);
 
 }  // namespace pcc

@@ -4,8 +4,8 @@
 //
 //   P1/P2  addPointsFromInputCloud + adoptBoundingBoxToPoint   -> k_chunk_boxes, k_bbox_events
 //   P3     genOctreeKeyforPoint                                -> k_make_keys
-//   P4     createLeafRecursive + addPointIndex                 -> LSD radix sort (k_radix_*)
-//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_partials/scan/emit + k_leaf_finalize
+//   P4     createLeafRecursive + addPointIndex                 -> LSD radix sort (k_make_keys histograms, k_digit_totals, k_sort_pass)
+//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_scan + k_leaf_finalize
 //   C2/P6  serializeTreeCallback / encodeAverageOfPoints       -> k_leaf_finalize
 //   C3b    SnakeGridMapping::doMapping                         -> k_leaf_finalize (closed-form position)
 //   C4     PointCodingV2::encodePoint                          -> k_leaf_finalize
@@ -106,44 +106,60 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   }
   return v;
 }
-// block-wide exclusive scan of one u64 per thread (256 threads); `total` = sum over the block
-__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_wave /*[4]*/, uint64_t& total) {
-  const uint64_t incl = wave_incl_scan_u64(v);
-  if (lane_id() == 63) s_wave[wave_id()] = incl;
+// block-wide exclusive scan of one value per thread (NW wave64 per workgroup); `total` = block sum
+template <int NW, typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T* s_wave /*[NW]*/, T& total) {
+  T incl = v;
+  const int lane = lane_id();
+  for (int o = 1; o < 64; o <<= 1) {
+    const T u = __shfl_up(incl, o);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) s_wave[wave_id()] = incl;
   __syncthreads();
-  uint64_t off = 0, tot = 0;
+  T off = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kBlock / 64; ++w) {
-    const uint64_t s = s_wave[w];
-    if (w < wave_id()) off += s;
-    tot += s;
+  for (int w = 0; w < NW; ++w) {
+    const T x = s_wave[w];
+    if (w < wave_id()) off += x;
+    tot += x;
   }
   total = tot;
   __syncthreads();
   return off + incl - v;
 }
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_wave /*[4]*/, uint64_t& total) {
+  return block_excl_scan<kBlock / 64, uint64_t>(v, s_wave, total);
+}
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t& total) {
-  const uint32_t incl = wave_incl_scan_u32(v);
-  if (lane_id() == 63) s_wave[wave_id()] = incl;
-  __syncthreads();
-  uint32_t off = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < kBlock / 64; ++w) {
-    const uint32_t s = s_wave[w];
-    if (w < wave_id()) off += s;
-    tot += s;
-  }
-  total = tot;
-  __syncthreads();
-  return off + incl - v;
+  return block_excl_scan<kBlock / 64, uint32_t>(v, s_wave, total);
+}
+
+// words other workgroups of the SAME launch poll: always agent-scope relaxed atomics (one self-describing
+// word per hand-off, so no fence is needed; cdna_hip_programming.md guideline 16, form R2)
+__device__ __forceinline__ void publish_u32(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t poll_u32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_u64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t poll_u64(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
 // Stage 0: per-chunk bounding boxes (first read of the cloud: 16 of every 32 bytes per point)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_chunk_boxes(PointView pv, uint32_t n, ChunkBox* __restrict__ boxes) {
+__global__ __launch_bounds__(kBlock) void k_chunk_boxes(PointView pv, uint32_t n, ChunkBox* __restrict__ boxes,
+                                                        uint4* __restrict__ sync_area, uint32_t sync_vec16) {
   __shared__ float s_mn[3][kBlock / 64], s_mx[3][kBlock / 64];
   __shared__ int s_first[kBlock / 64], s_cnt[kBlock / 64];
+  // every word another workgroup polls later in this frame (tile tickets, look-back status) starts at zero
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < sync_vec16; k += gridDim.x * kBlock)
+    sync_area[k] = make_uint4(0, 0, 0, 0);
   const uint32_t base = blockIdx.x * kTile;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   int first = 0x7fffffff, cnt = 0;
@@ -204,7 +220,8 @@ __device__ __forceinline__ int block_min_int(int v, int* s_red) {
 
 __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n, uint32_t n_chunks,
                                                         const ChunkBox* __restrict__ boxes, double res,
-                                                        int force_pairs, FrameState* __restrict__ st) {
+                                                        int force_pairs, int passes_launched,
+                                                        FrameState* __restrict__ st) {
   __shared__ float s_p[3][kTile];
   __shared__ int s_red;
   __shared__ double s_mn[3], s_mx[3];
@@ -242,7 +259,8 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     if (threadIdx.x == 0) {
       st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
       st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->flagbit = 0; st->n_growth_events = 0; st->packed = 1;
+      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1;
+      st->passes_launched = passes_launched;
     }
     return;
   }
@@ -409,17 +427,32 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     }
     for (int a = 0; a < 3; ++a) st->prefix[a] = vb >= 32 ? 0u : ((kmin[a] >> vb) << vb);
     int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
-    const int flag = s_nfin < n ? 1 : 0;
     // code + index in one u64 when they fit (8 B/key/pass); otherwise u64 code keys with a u32
     // index payload (12 B/key/pass).  The stable sort makes both orders identical.
-    const int packed = (3 * vb + flag + ibits <= 64 && !force_pairs) ? 1 : 0;
+    const int packed = (3 * vb + ibits <= 64 && !force_pairs) ? 1 : 0;
     if (!packed) ibits = 0;
     st->vbits_axis = vb;
     st->vbits = 3 * vb;
     st->ibits = ibits;
     st->packed = packed;
-    st->flagbit = flag;
-    st->npasses = (3 * vb + flag + kRadixBits - 1) / kRadixBits;
+    // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
+    const int vbits = 3 * vb;
+    int np = (vbits + kMaxDigitBits - 1) / kMaxDigitBits;
+    if (np < 1) np = 1;
+    int sh = 0;
+    for (int p = 0; p < kMaxPasses; ++p) {
+      int b = 0;
+      if (p < np) {
+        b = vbits / np + (p < vbits % np ? 1 : 0);
+        if (b < 1) b = 1;
+      }
+      st->pass_bits[p] = b;
+      st->pass_shift[p] = sh;
+      sh += b;
+    }
+    st->passes_launched = passes_launched;
+    if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
+    st->npasses = np;
     if (err != kErrNone) st->npasses = 0;
     st->error = err;
     st->n_leaves = 0;
@@ -428,163 +461,222 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage 2: octree keys (P3) -> packed sort keys  [flag | morton(vbits) | point index(ibits)]
+// Stage 2: octree keys (P3) -> packed sort keys  [morton(vbits) | point index(ibits)]; a non-finite
+// point gets the marker ~0 and is dropped by the first sort pass.  The same kernel counts, per
+// 4096-point tile, the digits of EVERY sort pass in LDS and writes them as one row of hist_rows.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_make_keys(PointView pv, uint32_t n, double res,
-                                                      FrameState* __restrict__ st, uint64_t* __restrict__ keys,
-                                                      uint32_t* __restrict__ idx) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+constexpr uint64_t kInvalidKey = ~0ull;
+
+__global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res,
+                                                            FrameState* __restrict__ st, uint64_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows) {
+  __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
-  if (i >= n) return;
-  const int vb = st->vbits_axis, vbits = st->vbits, ibits = st->ibits;
-  float x, y, z;
-  load_xyz(pv, i, x, y, z);
-  uint64_t packed;
-  if (finite3(x, y, z) && (int)i >= st->ep_index[0]) {
-    int e = ne - 1;
-    if ((int)(blockIdx.x * kBlock) < st->ep_index[ne - 1]) {  // rare: block overlaps an earlier epoch
-      while (e > 0 && st->ep_index[e] > (int)i) --e;
-    }
-    const float p[3] = {x, y, z};
-    unsigned k[3];
-    bool ok = true;
+  const int np = st->npasses;
+  for (int k = threadIdx.x; k < np * kMaxBins; k += kSortThreads) (&s_h[0][0])[k] = 0u;
+  __syncthreads();
+  const int vb = st->vbits_axis, ibits = st->ibits;
+  const bool packed_mode = st->packed != 0;
+  const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
+  const uint32_t base = blockIdx.x * kSortTile;
+  const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
+  const unsigned m = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
+  int pshift[kMaxPasses];
+  uint32_t pmask[kMaxPasses];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double d = __ddiv_rn(__dsub_rn((double)p[a], st->ep_mn[e][a]), res);
-      k[a] = (unsigned)d + st->ep_shift[e][a];
-      ok &= vb >= 32 || ((k[a] >> vb) == (st->prefix[a] >> vb));
+  for (int p = 0; p < kMaxPasses; ++p) { pshift[p] = st->pass_shift[p]; pmask[p] = (1u << st->pass_bits[p]) - 1u; }
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    const uint32_t i = base + k * kSortThreads + threadIdx.x;
+    if (i >= n) break;
+    float x, y, z;
+    load_xyz(pv, i, x, y, z);
+    uint64_t key = kInvalidKey;
+    if (finite3(x, y, z) && (int)i >= ep0) {
+      int e = ne - 1;
+      if (!late) {  // rare: the tile overlaps an earlier epoch
+        while (e > 0 && st->ep_index[e] > (int)i) --e;
+      }
+      const float p[3] = {x, y, z};
+      unsigned kk[3];
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double d = __ddiv_rn(__dsub_rn((double)p[a], st->ep_mn[e][a]), res);
+        kk[a] = (unsigned)d + st->ep_shift[e][a];
+        ok &= vb >= 32 || ((kk[a] >> vb) == (st->prefix[a] >> vb));
+      }
+      if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
+      const uint64_t code = morton3(kk[0] & m, kk[1] & m, kk[2] & m);
+#pragma unroll
+      for (int p = 0; p < kMaxPasses; ++p)
+        if (p < np) atomicAdd(&s_h[p][(uint32_t)(code >> pshift[p]) & pmask[p]], 1u);
+      key = packed_mode ? ((code << ibits) | (uint64_t)i) : code;
     }
-    if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
-    const unsigned m = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    packed = morton3(k[0] & m, k[1] & m, k[2] & m) << ibits;
-  } else {
-    packed = 1ull << (vbits + ibits);  // non-finite: sorts behind every real key
+    if (!packed_mode) idx[i] = i;
+    keys[i] = key;
   }
-  if (st->packed) packed |= (uint64_t)i; else idx[i] = i;
-  keys[i] = packed;
+  __syncthreads();
+  uint32_t* row = hist_rows + (size_t)blockIdx.x * kMaxPasses * kMaxBins;
+  for (int k = threadIdx.x; k < np * kMaxBins; k += kSortThreads) row[k] = (&s_h[0][0])[k];
+}
+
+// column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
+// One workgroup per 64 columns, 16 row groups per column, LDS tree at the end.
+__global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
+                                                       const uint32_t* __restrict__ hist_rows,
+                                                       uint32_t* __restrict__ digit_tot) {
+  __shared__ uint32_t s_part[16][64];
+  const uint32_t col = blockIdx.x * 64u + (threadIdx.x & 63u);
+  const uint32_t pass = col / kMaxBins;
+  if ((int)pass >= st->npasses) return;  // uniform per workgroup (512 columns per pass)
+  const uint32_t g = threadIdx.x >> 6;
+  uint32_t acc = 0;
+  for (uint32_t r = g; r < n_rows; r += 16u) acc += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
+  s_part[g][threadIdx.x & 63u] = acc;
+  __syncthreads();
+  if (g == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += s_part[k][threadIdx.x];
+    digit_tot[col] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage 3: stable LSD radix sort of the packed keys, 8-bit digits over bits [ibits, ibits+vbits+flag)
-// Per pass: k_radix_hist (LDS-staged digit histogram per 2048-key tile) -> k_radix_scan (row
-// prefixes per digit) -> k_radix_scatter (wave ballot/popc ranking, stable).
-// Passes beyond st->npasses return at once, so the host never has to read the depth back.
+// Stage 3: stable LSD radix sort, ONE kernel per pass ("onesweep"): a tile of 4096 keys ranks its
+// keys per digit with wave ballots against wave-private LDS counters, publishes its digit counts
+// and finds the counts of all earlier tiles by decoupled look-back (one self-describing word per
+// (tile, digit): flag | count), then scatters.  Tile ids come from a ticket counter, so a tile only
+// ever waits for tiles that have already started.  Passes beyond st->npasses return at once.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ const uint64_t* pick_in(const FrameState* st, int pass, const uint64_t* a, const uint64_t* b) {
-  (void)st;
-  return (pass & 1) ? b : a;
-}
-
-__global__ __launch_bounds__(kBlock) void k_radix_hist(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
-                                                       uint32_t n, int pass, const FrameState* __restrict__ st,
-                                                       uint32_t n_tiles, uint32_t* __restrict__ ghist) {
+__global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
+                                                            uint64_t* out_a, uint64_t* out_b,
+                                                            uint32_t* idx_a, uint32_t* idx_b, uint32_t n, int pass,
+                                                            FrameState* st, const uint32_t* __restrict__ digit_tot,
+                                                            uint32_t* status_all, uint32_t* tickets,
+                                                            uint32_t n_tiles_max) {
   if (pass >= st->npasses) return;
-  __shared__ uint32_t s_h[kRadixSize];
-  const uint64_t* in = pick_in(st, pass, buf_a, buf_b);
-  const int shift = st->ibits + pass * kRadixBits;
-  s_h[threadIdx.x] = 0;
+  constexpr int NW = kSortThreads / 64;
+  __shared__ uint16_t s_cnt[NW][kMaxBins];  // per-wave running digit counts, then wave start ranks
+  __shared__ uint32_t s_base[kMaxBins];     // global position of this tile's first key per digit
+  __shared__ uint32_t s_scan[NW];
+  __shared__ uint32_t s_tile;
+
+  const uint32_t count = pass == 0 ? n : st->n_finite;  // pass 0 still holds the non-finite markers
+  const uint32_t out_count = st->n_finite;
+  const uint32_t n_tiles = (count + kSortTile - 1) / kSortTile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
+  for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += kSortThreads) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   __syncthreads();
-  const uint32_t base = blockIdx.x * kTile;
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const uint32_t i = base + k * kBlock + threadIdx.x;
-    if (i < n) atomicAdd(&s_h[(in[i] >> shift) & (kRadixSize - 1)], 1u);
-  }
-  __syncthreads();
-  ghist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];
-}
+  const uint32_t tile = s_tile;
+  if (tile >= n_tiles) return;
 
-// one workgroup per digit: exclusive prefix of that digit's counts over the tiles + digit total
-__global__ __launch_bounds__(kBlock) void k_radix_scan(int pass, const FrameState* __restrict__ st, uint32_t n_tiles,
-                                                       uint32_t* __restrict__ ghist, uint32_t* __restrict__ gtot) {
-  if (pass >= st->npasses) return;
-  __shared__ uint32_t s_w[kBlock / 64];
-  uint32_t* row = ghist + (size_t)blockIdx.x * n_tiles;
-  uint32_t carry = 0;
-  for (uint32_t c = 0; c < n_tiles; c += kBlock) {
-    const uint32_t j = c + threadIdx.x;
-    const uint32_t v = j < n_tiles ? row[j] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan_u32(v, s_w, tot);
-    if (j < n_tiles) row[j] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) gtot[blockIdx.x] = carry;
-}
-
-__global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* buf_a, const uint64_t* buf_b,
-                                                          uint64_t* out_a, uint64_t* out_b,
-                                                          uint32_t* idx_a, uint32_t* idx_b,
-                                                          uint32_t n, int pass, const FrameState* __restrict__ st,
-                                                          uint32_t n_tiles, const uint32_t* __restrict__ ghist,
-                                                          const uint32_t* __restrict__ gtot) {
-  if (pass >= st->npasses) return;
-  __shared__ uint32_t s_off[kRadixSize];               // global offset of this tile's first key per digit
-  __shared__ uint32_t s_cnt[kBlock / 64][kRadixSize];   // per-wave running digit counts, then wave start ranks
-  __shared__ uint32_t s_w[kBlock / 64];
-  const uint64_t* in = pick_in(st, pass, buf_a, buf_b);
-  uint64_t* out = (pass & 1) ? out_a : out_b;  // ping-pong: pass 0 reads a writes b
+  const int bits = st->pass_bits[pass];
+  const uint32_t nbins = 1u << bits, mask = nbins - 1u;
   const bool pairs = st->packed == 0;
+  const int shift = st->ibits + st->pass_shift[pass];
+  const uint64_t* in = (pass & 1) ? buf_b : buf_a;  // ping-pong: pass 0 reads a writes b
+  uint64_t* out = (pass & 1) ? out_a : out_b;
   const uint32_t* idx_in = (pass & 1) ? idx_b : idx_a;
   uint32_t* idx_out = (pass & 1) ? idx_a : idx_b;
-  const int shift = st->ibits + pass * kRadixBits;
+  uint32_t* status = status_all + ((size_t)pass * n_tiles_max) * kMaxBins;
   const int lane = lane_id(), wave = wave_id();
   const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
-  {
-    uint32_t tot;
-    const uint32_t dbase = block_excl_scan_u32(gtot[threadIdx.x], s_w, tot);
-    s_off[threadIdx.x] = dbase + ghist[(size_t)threadIdx.x * n_tiles + blockIdx.x];
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) s_cnt[w][threadIdx.x] = 0;
-  }
-  __syncthreads();
+  // global start of every digit = exclusive scan of the digit totals (thread = digit)
+  uint32_t gsum;
+  const uint32_t dtot = threadIdx.x < nbins ? digit_tot[(size_t)pass * kMaxBins + threadIdx.x] : 0u;
+  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
 
   // Tile order = (wave, round, lane): every wave ranks its own 512 consecutive keys against
-  // wave-private LDS counters, so no workgroup barrier is needed inside the ranking loop (LDS
+  // wave-private counters, so no workgroup barrier is needed inside the ranking loop (the LDS
   // operations of one wave complete in issue order).
-  const uint32_t wbase = blockIdx.x * kTile + (uint32_t)wave * (kTile / (kBlock / 64));
-  uint64_t key[kItems];
-  uint32_t lrank[kItems];
+  const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
+  uint64_t key[kSortItems];
+  uint16_t lrank[kSortItems];
 #pragma unroll
-  for (int r = 0; r < kItems; ++r) {
+  for (int r = 0; r < kSortItems; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-    const bool valid = i < n;
-    key[r] = valid ? in[i] : 0ull;
-    const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixSize - 1);
-    uint64_t peers = __ballot(valid);  // lanes of this wave holding the same digit (8 ballots)
+    key[r] = i < count ? in[i] : kInvalidKey;
+  }
 #pragma unroll
-    for (int b = 0; b < kRadixBits; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
+  for (int r = 0; r < kSortItems; ++r) {
+    const bool valid = key[r] != kInvalidKey;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    uint64_t peers = __ballot(valid);  // lanes of this wave holding the same digit
+#pragma unroll
+    for (int b = 0; b < kMaxDigitBits; ++b) {
+      if (b < bits) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+      }
     }
     const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
     const uint32_t prior = s_cnt[wave][d];
-    if (valid && rank == 0) s_cnt[wave][d] = prior + (uint32_t)__popcll(peers);
-    lrank[r] = prior + rank;
+    if (valid && rank == 0) s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
+    lrank[r] = (uint16_t)(prior + rank);
   }
   __syncthreads();
-  {  // thread = digit: per-wave totals -> per-wave start ranks inside the tile
-    const uint32_t dd = threadIdx.x;
+  if (threadIdx.x < nbins) {  // thread = digit
+    const uint32_t d = threadIdx.x;
     uint32_t run = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-      const uint32_t c = s_cnt[w][dd];
-      s_cnt[w][dd] = run;
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = s_cnt[w][d];
+      s_cnt[w][d] = (uint16_t)run;
       run += c;
     }
+    // publish this tile's count, then add up the tiles before it
+    uint32_t* mine = status + (size_t)tile * kMaxBins + d;
+    uint32_t acc = 0;
+    if (tile == 0) {
+      publish_u32(mine, kStatusInclusive | run);
+    } else {
+      publish_u32(mine, kStatusAggregate | run);
+      int j = (int)tile - 1;
+      uint32_t spins = 0;
+      while (j >= 0) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = (j - k >= 0) ? poll_u32(status + (size_t)(j - k) * kMaxBins + d) : kStatusInclusive;
+        int used = 0;
+        bool done = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!done && used == k) {
+            const uint32_t f = v[k] >> 30;
+            if (f != 0) {
+              acc += v[k] & kStatusValue;
+              ++used;
+              done = f == 2;
+            }
+          }
+        }
+        if (done) break;
+        j -= used;
+        if (used == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+        }
+      }
+      publish_u32(mine, kStatusInclusive | ((acc + run) & kStatusValue));
+    }
+    s_base[d] = gbase + acc;
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-    if (i < n) {
-      const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixSize - 1);
-      const uint32_t pos = s_off[d] + s_cnt[wave][d] + lrank[r];
-      out[pos] = key[r];
-      if (pairs) idx_out[pos] = idx_in[i];
+  for (int r = 0; r < kSortItems; ++r) {
+    if (key[r] != kInvalidKey) {
+      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+      const uint32_t pos = s_base[d] + s_cnt[wave][d] + lrank[r];
+      if (pos < out_count) {  // always true unless a look-back gave up (kErrSpin)
+        out[pos] = key[r];
+        if (pairs) idx_out[pos] = idx_in[wbase + (uint32_t)r * 64u + (uint32_t)lane];
+      }
     }
   }
 }
@@ -592,8 +684,9 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint64_t* buf_a,
 // ------------------------------------------------------------------------------------------
 // Stage 4: leaves.  head(i) = code(i) != code(i-1);  t(j) = index of the highest 3-bit triple in
 // which leaf j differs from leaf j-1 (= number of branch nodes whose first leaf is j; t(0) = D).
-// One u64 scan carries both sums: low word = leaf id, high word = DFS byte offset (closed form
-// of the pre-order stream).
+// One chained scan carries both sums (leaf id, DFS byte offset: closed form of the pre-order stream,
+// SURVEY.md row P5) across the tiles: word = flag(2) | sum t (32) | leaf count (30).  The tile that
+// opens a piece of the DFS stream also zeroes it (B is only known on the device).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t head_t(uint64_t code, uint64_t prev, bool is_first, int depth) {
   if (is_first) return ((uint64_t)depth << 32) | 1ull;
@@ -602,69 +695,33 @@ __device__ __forceinline__ uint64_t head_t(uint64_t code, uint64_t prev, bool is
   const int msb = 63 - __clzll((long long)x);
   return ((uint64_t)(msb / 3) << 32) | 1ull;
 }
+__device__ __forceinline__ uint64_t scan_pack(uint64_t ht) { return ((ht >> 32) << 30) | (ht & 0x3fffffffull); }
+__device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30) & 0xffffffffull) << 32) | (w & 0x3fffffffull); }
 
-__global__ __launch_bounds__(kBlock) void k_leaf_partials(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
-                                                          const FrameState* __restrict__ st, uint64_t* __restrict__ partials) {
-  __shared__ uint64_t s_w[kBlock / 64];
+__global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                            FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
+                                                            uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
+                                                            uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
+                                                            uint8_t* __restrict__ occ) {
+  constexpr int NW = kSortThreads / 64;
+  constexpr uint64_t kFlagAgg = 1ull << 62, kFlagIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
+  __shared__ uint64_t s_w[NW];
+  __shared__ uint64_t s_prefix;
+  __shared__ uint32_t s_tile;
   const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
-  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
-  const int ibits = st->ibits, depth = st->depth;
-  const uint32_t i0 = blockIdx.x * kTile + threadIdx.x * kItems;
-  uint64_t acc = 0;
-  if (i0 < nfin) {
-    uint64_t prev = i0 ? (keys[i0 - 1] >> ibits) : 0ull;
-#pragma unroll
-    for (int e = 0; e < kItems; ++e) {
-      const uint32_t i = i0 + e;
-      if (i < nfin) {
-        const uint64_t code = keys[i] >> ibits;
-        acc += head_t(code, prev, i == 0, depth);
-        prev = code;
-      }
-    }
-  }
-  acc = wave_sum_u64(acc);
-  if (lane_id() == 0) s_w[wave_id()] = acc;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
   __syncthreads();
-  if (threadIdx.x == 0) partials[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-__global__ __launch_bounds__(kBlock) void k_leaf_scan_partials(uint32_t n_tiles, FrameState* __restrict__ st,
-                                                               uint64_t* __restrict__ partials, uint32_t* __restrict__ leaf_start) {
-  __shared__ uint64_t s_w[kBlock / 64];
-  uint64_t carry = 0;
-  for (uint32_t c = 0; c < n_tiles; c += kBlock) {
-    const uint32_t j = c + threadIdx.x;
-    const uint64_t v = j < n_tiles ? partials[j] : 0ull;
-    uint64_t tot;
-    const uint64_t ex = block_excl_scan_u64(v, s_w, tot);
-    if (j < n_tiles) partials[j] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    const uint32_t L = (uint32_t)(carry & 0xffffffffu);
-    st->n_leaves = L;
-    st->n_branches = (uint32_t)(carry >> 32);
-    leaf_start[L] = (st->error == kErrNone) ? st->n_finite : 0u;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_leaf_emit(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
-                                                      const FrameState* __restrict__ st, const uint64_t* __restrict__ partials,
-                                                      uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
-                                                      uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t) {
-  __shared__ uint64_t s_w[kBlock / 64];
-  const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
+  const uint32_t tile = s_tile;
+  if ((uint64_t)tile * kSortTile >= nfin) return;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, depth = st->depth;
-  const uint32_t i0 = blockIdx.x * kTile + threadIdx.x * kItems;
-  if (blockIdx.x * kTile >= nfin) return;
-  uint64_t ht[kItems], code[kItems];
+  const uint32_t i0 = tile * kSortTile + threadIdx.x * kSortItems;
+  uint64_t ht[kSortItems], code[kSortItems];
   uint64_t acc = 0;
   {
     uint64_t prev = (i0 && i0 < nfin) ? (keys[i0 - 1] >> ibits) : 0ull;
 #pragma unroll
-    for (int e = 0; e < kItems; ++e) {
+    for (int e = 0; e < kSortItems; ++e) {
       const uint32_t i = i0 + e;
       ht[e] = 0; code[e] = 0;
       if (i < nfin) {
@@ -676,9 +733,42 @@ __global__ __launch_bounds__(kBlock) void k_leaf_emit(const uint64_t* __restrict
     }
   }
   uint64_t tot;
-  uint64_t ex = block_excl_scan_u64(acc, s_w, tot) + partials[blockIdx.x];
+  uint64_t ex = block_excl_scan<NW, uint64_t>(acc, s_w, tot);
+  if (wave_id() == 0) {  // one wave looks back, 64 earlier tiles per step
+    const int lane = lane_id();
+    const uint64_t mine = scan_pack(tot);
+    uint64_t before = 0;
+    if (tile == 0) {
+      if (lane == 0) publish_u64(leaf_status, kFlagIncl | mine);
+    } else {
+      if (lane == 0) publish_u64(leaf_status + tile, kFlagAgg | mine);
+      int j = (int)tile - 1;
+      uint32_t spins = 0;
+      while (j >= 0) {
+        const int jj = j - lane;
+        const uint64_t v = jj >= 0 ? poll_u64(leaf_status + jj) : kFlagIncl;
+        const uint32_t f = (uint32_t)(v >> 62);
+        const uint64_t not_ready = __ballot(f == 0), incl = __ballot(f == 2);
+        const int first_nr = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+        const int first_in = incl ? __ffsll((long long)incl) - 1 : 64;
+        const int take = first_in < first_nr ? first_in + 1 : first_nr;  // lanes [0, take) are usable
+        before += wave_sum_u64(lane < take ? (v & kVal) : 0ull);
+        if (first_in < first_nr) break;
+        j -= take;
+        if (take == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit) { if (lane == 0) st->error = kErrSpin; break; }
+        }
+      }
+      if (lane == 0) publish_u64(leaf_status + tile, kFlagIncl | ((before + mine) & kVal));
+    }
+    if (lane == 0) s_prefix = scan_unpack(before);
+  }
+  __syncthreads();
+  const uint64_t pre = s_prefix;
+  ex += pre;
 #pragma unroll
-  for (int e = 0; e < kItems; ++e) {
+  for (int e = 0; e < kSortItems; ++e) {
     if (ht[e] & 1ull) {
       const uint32_t id = (uint32_t)(ex & 0xffffffffu);
       leaf_start[id] = i0 + e;
@@ -688,12 +778,21 @@ __global__ __launch_bounds__(kBlock) void k_leaf_emit(const uint64_t* __restrict
     }
     ex += ht[e];
   }
-}
-
-// zero the DFS stream (B is only known on the device)
-__global__ __launch_bounds__(kBlock) void k_zero_occ(const FrameState* __restrict__ st, uint4* __restrict__ occ) {
-  const uint32_t nvec = (st->n_branches + 15u) / 16u + 1u;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += gridDim.x * kBlock) occ[i] = make_uint4(0, 0, 0, 0);
+  // zero the piece of the DFS stream this tile's leaves open: bytes [b0, b1)
+  const uint32_t b0 = (uint32_t)(pre >> 32), b1 = b0 + (uint32_t)(tot >> 32);
+  const uint32_t a0 = min((b0 + 15u) & ~15u, b1), a1 = max(b1 & ~15u, a0);
+  for (uint32_t k = b0 + threadIdx.x; k < a0; k += kSortThreads) occ[k] = 0;
+  for (uint32_t k = a0 + threadIdx.x * 16u; k < a1; k += kSortThreads * 16u) *reinterpret_cast<uint4*>(occ + k) = make_uint4(0, 0, 0, 0);
+  for (uint32_t k = a1 + threadIdx.x; k < b1; k += kSortThreads) occ[k] = 0;
+  if ((uint64_t)(tile + 1) * kSortTile >= nfin && threadIdx.x == 0) {  // the last tile closes the frame
+    const uint64_t all = pre + tot;
+    const uint32_t L = (uint32_t)(all & 0xffffffffu);
+    st->n_leaves = L;
+    st->n_branches = (uint32_t)(all >> 32);
+    leaf_start[L] = nfin;
+    // keep the dword that holds the last stream byte clean beyond B (k_leaf_finalize ORs whole dwords)
+    for (uint32_t k = b1; k < ((b1 + 3u) & ~3u); ++k) occ[k] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1010,35 +1109,41 @@ __global__ __launch_bounds__(64) void k_jpeg_fdct(const uint8_t* __restrict__ im
     if (tm) tm->stamp(name, stream);                         \
   } while (0)
 
+size_t sync_area_bytes(uint32_t n, int passes) {
+  const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
+  size_t b = 64;                                   // tickets
+  b += ((tiles * sizeof(uint64_t) + 15) / 16) * 16;  // leaf scan status
+  b += (size_t)passes * tiles * kMaxBins * sizeof(uint32_t);  // sort status
+  return b;
+}
+
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) {
   const uint32_t n = a.n;
-  const uint32_t n_tiles = (n + kTile - 1) / kTile;
-  const uint32_t n_blocks = (n + kBlock - 1) / kBlock;
+  const uint32_t n_tiles = (n + kTile - 1) / kTile;              // bounding-box chunks (2048 points)
+  const uint32_t s_tiles = (n + kSortTile - 1) / kSortTile;      // sort / scan tiles (4096 keys)
+  const int passes = a.max_passes;
+  uint8_t* sync = a.sync_area;
+  uint32_t* tickets = reinterpret_cast<uint32_t*>(sync);
+  uint64_t* leaf_status = reinterpret_cast<uint64_t*>(sync + 64);
+  uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + 64 + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
+  const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
-  hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes);
+  hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes, reinterpret_cast<uint4*>(sync), sync_vec16);
   PCC_STAMP("k_chunk_boxes");
-  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, a.state);
+  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, passes, a.state);
   PCC_STAMP("k_bbox_events");
-  hipLaunchKernelGGL(k_make_keys, dim3(n_blocks), dim3(kBlock), 0, stream, a.pv, n, a.res, a.state, a.keys_a, a.idx_a);
+  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.state, a.keys_a, a.idx_a, a.hist_rows);
   PCC_STAMP("k_make_keys");
-  for (int pass = 0; pass < a.max_passes; ++pass) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, n, pass, a.state, n_tiles, a.ghist);
-    PCC_STAMP("k_radix_hist");
-    hipLaunchKernelGGL(k_radix_scan, dim3(kRadixSize), dim3(kBlock), 0, stream, pass, a.state, n_tiles, a.ghist, a.gtot);
-    PCC_STAMP("k_radix_scan");
-    hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
-                       n, pass, a.state, n_tiles, a.ghist, a.gtot);
-    PCC_STAMP("k_radix_scatter");
+  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / 64u), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot);
+  PCC_STAMP("k_digit_totals");
+  for (int pass = 0; pass < passes; ++pass) {
+    hipLaunchKernelGGL(k_sort_pass, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+                       n, pass, a.state, a.digit_tot, sort_status, tickets, s_tiles);
+    PCC_STAMP("k_sort_pass");
   }
-  hipLaunchKernelGGL(k_leaf_partials, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.state, a.partials);
-  PCC_STAMP("k_leaf_partials");
-  hipLaunchKernelGGL(k_leaf_scan_partials, dim3(1), dim3(kBlock), 0, stream, n_tiles, a.state, a.partials, a.leaf_start);
-  PCC_STAMP("k_leaf_scan_partials");
-  hipLaunchKernelGGL(k_leaf_emit, dim3(n_tiles), dim3(kBlock), 0, stream, a.keys_a, a.keys_b, a.state, a.partials, a.leaf_start,
-                     a.leaf_code, a.leaf_base, a.leaf_t);
-  PCC_STAMP("k_leaf_emit");
-  hipLaunchKernelGGL(k_zero_occ, dim3(512), dim3(kBlock), 0, stream, a.state, reinterpret_cast<uint4*>(a.occ));
-  PCC_STAMP("k_zero_occ");
+  hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
+                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ);
+  PCC_STAMP("k_leaf_scan");
   const uint32_t fin_blocks = (n + 256u + kBlock - 1) / kBlock;  // leaves + up to 256 padding pixels
   hipLaunchKernelGGL(k_leaf_finalize, dim3(fin_blocks), dim3(kBlock), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state,
                      a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,

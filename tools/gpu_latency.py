@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Single-context, one-frame-at-a-time GPU latency of the hot path (no host entropy stage, no
+concurrency): HIP-event time from the first to the last kernel, and per-kernel event times.
+    python tools/gpu_latency.py [workload] [frames]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as G
+
+pkg = G.load_package()
+b, syn = pkg.binding, pkg.synthetic
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+cfg = syn.CONFIGS[wl]
+p = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
+                  jpeg_quality=cfg["jpeg_quality"], keep_centroid=cfg["keep_centroid"])
+ctx = b.Context(0)
+ctx.set_option("copy_image", 0)
+pts = syn.make_frame(wl)
+dev = ctx.upload(pts)
+n = len(pts)
+for prof in (0, 1):
+    ctx.set_profiling(prof)
+    ms, wall = [], []
+    agg = {}
+    for k in range(K + 3):
+        t = time.perf_counter()
+        ctx.hotpath_launch(dev, n, p)
+        hot = ctx.hotpath_finish(copy=False)
+        w = time.perf_counter() - t
+        if k >= 3:
+            ms.append(hot.gpu_ms); wall.append(w * 1e3)
+            if prof:
+                for name, v in ctx.kernel_times():
+                    e = agg.setdefault(name, [0.0, 0]); e[0] += v; e[1] += 1
+    print("%s N=%d L=%d B=%d D=%d  profiling=%d: gpu %.1f us (min %.1f)  launch+finish wall %.1f us" %
+          (wl, n, hot.n_leaves, hot.n_branches, hot.depth, prof, 1e3 * np.mean(ms), 1e3 * np.min(ms), 1e3 * np.mean(wall)))
+    if prof:
+        for name, (tot, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print("   %-22s %5.1f launches/frame  %8.2f us each  %8.2f us/frame" % (name, cnt / K, 1e3 * tot / cnt, 1e3 * tot / K))
+ctx.close()
