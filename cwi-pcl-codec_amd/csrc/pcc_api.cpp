@@ -76,7 +76,7 @@ struct pcc_ctx {
   DevBuf<ChunkBox> d_boxes;
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
-  DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
+  DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image, d_sync;
   DevBuf<float> d_simplified;  // 4 floats per leaf
   DevBuf<int16_t> d_coefs;     // JPEG coefficients of the snake image
@@ -133,6 +133,7 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_idx_b.ensure(n));
   PCC_HIP(ctx->d_hist_rows.ensure(stiles * kMaxPasses * kMaxBins));
   PCC_HIP(ctx->d_digit_tot.ensure((size_t)kMaxPasses * kMaxBins));
+  PCC_HIP(ctx->d_tile_prefix0.ensure(stiles * kMaxBins));
   PCC_HIP(ctx->d_sync.ensure(sync_area_bytes((uint32_t)n, kMaxPasses)));
   PCC_HIP(ctx->d_leaf_start.ensure(n + 1));
   PCC_HIP(ctx->d_leaf_code.ensure(n));
@@ -194,7 +195,7 @@ void pcc_destroy(pcc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
-  c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_sync.release();
+  c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
@@ -282,6 +283,11 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.pv.aligned16 = ((reinterpret_cast<uintptr_t>(dev_points) & 15) == 0 && (stride & 15) == 0 && stride >= 16) ? 1u : 0u;
   a.n = (uint32_t)n;
   a.res = prm->octree_resolution;
+  {
+    int ex = 0;
+    const double mant = frexp(a.res, &ex);  // power of two <=> mantissa 0.5; keep 1/res finite and normal
+    a.inv_res_pow2 = (mant == 0.5 && ex > -1000 && ex < 1000) ? 1.0 / a.res : 0.0;
+  }
   a.lp.do_color = prm->do_color_encoding ? 1u : 0u;
   a.lp.color_reduction = (prm->color_coding_type == 0) ? (uint32_t)((8 - prm->color_bit_resolution) & 7) : 0u;
   if (prm->color_coding_type == 0 && prm->color_bit_resolution <= 0) a.lp.color_reduction = 8;
@@ -299,7 +305,7 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
   a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
-  a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.sync_area = ctx->d_sync.p;
+  a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.tile_prefix0 = ctx->d_tile_prefix0.p; a.sync_area = ctx->d_sync.p;
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
   a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
   a.image = ctx->d_image.p; a.simplified = ctx->d_simplified.p;

@@ -8,10 +8,11 @@
 //   chunk_box   ceil(N/2048) x 32 B   per-chunk AABB + first finite index + finite count
 //   state       1 x FrameState  epochs of the adaptive bounding box, sort geometry, L, B
 //   keys[2]     N x u64         packed (morton | index) sort keys, ping-pong; ~0 marks a non-finite point
-//   idx[2]      N x u32         point index payload, only touched in pairs mode (code + index bits > 64)
+//   idx[2]      N x u32         sort payload: the point's colour word (so that no random gather is needed after
+//                               the sort), or the point index in pairs mode (code + index bits > 64)
 //   hist_rows   ceil(N/4096) x kMaxPasses x 512 x u32   per-tile digit counts of every pass (from k_make_keys)
 //   digit_tot   kMaxPasses x 512 x u32                  column sums of hist_rows
-//   status      kMaxPasses x ceil(N/4096) x 512 x u32   decoupled look-back words of the sort passes
+//   status      kMaxPasses x (tiles + tiles/16) x 512 x u32   look-back words of the sort passes: per tile, per group of 16 tiles
 //   leaf_status ceil(N/4096) x u64                      decoupled look-back words of the leaf scan
 //   tickets     (kMaxPasses + 1) x u32                  dynamic tile ids (forward progress of the look-back)
 //   leaf_start  (N+1) x u32     first sorted position of each leaf
@@ -31,13 +32,14 @@ constexpr int kTile = kBlock * kItems;  // 2048 items per tile / bbox chunk
 constexpr int kMaxEpochs = 40;     // depth <= 32 => at most 33 growth events (+ first point)
 constexpr int kMaxDepth = 21;      // 3*D morton bits must fit 63 bits
 // sort: onesweep-style LSD radix sort, one kernel per pass, digit width chosen per frame (<= 9 bits)
-constexpr int kSortThreads = 512;          // 8 wave64 per workgroup
-constexpr int kSortItems = 8;              // keys per thread
+constexpr int kSortThreads = 1024;         // 16 wave64 per workgroup: four per SIMD hide the ranking latencies
+constexpr int kSortItems = 4;              // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 keys per tile
 constexpr int kMaxDigitBits = 9;
 constexpr int kMaxBins = 1 << kMaxDigitBits;  // 512 = one digit per thread in the look-back
 constexpr int kMaxPasses = 7;              // 63 code bits / 9
 constexpr uint32_t kStatusAggregate = 1u << 30, kStatusInclusive = 2u << 30, kStatusValue = (1u << 30) - 1u;
+constexpr int kLookBackGroup = 16;         // tiles per look-back group (two-level look-back)
 constexpr uint32_t kSpinLimit = 1u << 22;  // bounded polling: a lost predecessor becomes an error, not a hang
 
 struct ChunkBox {          // 32 bytes
@@ -71,7 +73,9 @@ struct FrameState {
   int32_t vbits_axis;                // varying key bits per axis
   int32_t vbits;                     // 3 * vbits_axis
   int32_t ibits;                     // index bits in the packed key (0 in pairs mode)
-  int32_t packed;                    // 1: [flag|code|index] in one u64;  0: u64 code keys + u32 index payload
+  int32_t packed;                    // 1: [code|index] in one u64;  0: u64 code keys + u32 index payload
+  int32_t payload;                   // what the u32 payload of the sort carries: 0 nothing, 1 point index (pairs
+                                     // mode), 2 the point's colour word (packed mode with colour: no gather later)
   int32_t npasses;                   // radix passes actually needed (>= 1)
   int32_t pass_bits[kMaxPasses];     // digit width of each pass
   int32_t pass_shift[kMaxPasses];    // bit position of each digit inside the code (add ibits for the packed key)

@@ -37,6 +37,7 @@ struct HotPathArgs {
   PointView pv;
   uint32_t n;
   double res;
+  double inv_res_pow2;  // 1/res when res is a power of two (then x * inv == x / res exactly), else 0
   LeafParams lp;
   int max_passes;  // sort passes to enqueue (the device decides how many do work; more needed => kErrPasses)
   int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
@@ -48,6 +49,7 @@ struct HotPathArgs {
   uint32_t* idx_b;
   uint32_t* hist_rows;  // [sort tiles][kMaxPasses][kMaxBins] digit counts from k_make_keys
   uint32_t* digit_tot;  // [kMaxPasses][kMaxBins]
+  uint32_t* tile_prefix0;  // [sort tiles][kMaxBins] exclusive tile prefix of the pass-0 digit counts
   uint8_t* sync_area;   // tickets | leaf scan status | sort status (sync_area_bytes), zeroed by k_chunk_boxes
   uint32_t* leaf_start;
   uint64_t* leaf_code;

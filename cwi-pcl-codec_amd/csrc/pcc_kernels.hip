@@ -220,7 +220,7 @@ __device__ __forceinline__ int block_min_int(int v, int* s_red) {
 
 __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n, uint32_t n_chunks,
                                                         const ChunkBox* __restrict__ boxes, double res,
-                                                        int force_pairs, int passes_launched,
+                                                        int force_pairs, int passes_launched, int do_color,
                                                         FrameState* __restrict__ st) {
   __shared__ float s_p[3][kTile];
   __shared__ int s_red;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     if (threadIdx.x == 0) {
       st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
       st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1;
+      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0;
       st->passes_launched = passes_launched;
     }
     return;
@@ -435,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     st->vbits = 3 * vb;
     st->ibits = ibits;
     st->packed = packed;
+    st->payload = packed ? (do_color ? 2 : 0) : 1;
     // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
     const int vbits = 3 * vb;
     int np = (vbits + kMaxDigitBits - 1) / kMaxDigitBits;
@@ -467,7 +468,17 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
 // ------------------------------------------------------------------------------------------
 constexpr uint64_t kInvalidKey = ~0ull;
 
-__global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res,
+#ifdef PCC_KTIME  // developer build only: phase time stamps of k_sort_pass (shader clock), read by tools/ktime.py
+__device__ unsigned long long g_ktime[kMaxPasses * 1024 * 8];
+#define PCC_KT(slot)                                                                                   \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ktime[((size_t)pass * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define PCC_KT(slot) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
                                                             uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows) {
   __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
@@ -478,6 +489,7 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
   __syncthreads();
   const int vb = st->vbits_axis, ibits = st->ibits;
   const bool packed_mode = st->packed != 0;
+  const int payload = st->payload;
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
   const uint32_t base = blockIdx.x * kSortTile;
   const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
@@ -503,7 +515,9 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
       bool ok = true;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const double d = __ddiv_rn(__dsub_rn((double)p[a], st->ep_mn[e][a]), res);
+        // x / res; when res is a power of two the product with its (exact) reciprocal is the same double
+        const double diff = __dsub_rn((double)p[a], st->ep_mn[e][a]);
+        const double d = inv_res_pow2 != 0.0 ? __dmul_rn(diff, inv_res_pow2) : __ddiv_rn(diff, res);
         kk[a] = (unsigned)d + st->ep_shift[e][a];
         ok &= vb >= 32 || ((kk[a] >> vb) == (st->prefix[a] >> vb));
       }
@@ -514,7 +528,8 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
         if (p < np) atomicAdd(&s_h[p][(uint32_t)(code >> pshift[p]) & pmask[p]], 1u);
       key = packed_mode ? ((code << ibits) | (uint64_t)i) : code;
     }
-    if (!packed_mode) idx[i] = i;
+    if (payload == 1) idx[i] = i;
+    else if (payload == 2) idx[i] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
     keys[i] = key;
   }
   __syncthreads();
@@ -523,24 +538,38 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
 }
 
 // column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
-// One workgroup per 64 columns, 16 row groups per column, LDS tree at the end.
+// One workgroup per 64 columns, 16 row groups (contiguous row ranges) per column, LDS combine.
+// For pass 0 the input order of the sort is the tile order of k_make_keys, so the same kernel also
+// writes the exclusive prefix over the tiles (tile_prefix0[tile][digit]): pass 0 needs no look-back.
 __global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
                                                        const uint32_t* __restrict__ hist_rows,
-                                                       uint32_t* __restrict__ digit_tot) {
+                                                       uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0) {
   __shared__ uint32_t s_part[16][64];
-  const uint32_t col = blockIdx.x * 64u + (threadIdx.x & 63u);
+  const uint32_t c = threadIdx.x & 63u;
+  const uint32_t col = blockIdx.x * 64u + c;
   const uint32_t pass = col / kMaxBins;
   if ((int)pass >= st->npasses) return;  // uniform per workgroup (512 columns per pass)
   const uint32_t g = threadIdx.x >> 6;
+  const uint32_t per = (n_rows + 15u) / 16u;
+  const uint32_t r0 = min(g * per, n_rows), r1 = min(r0 + per, n_rows);
   uint32_t acc = 0;
-  for (uint32_t r = g; r < n_rows; r += 16u) acc += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
-  s_part[g][threadIdx.x & 63u] = acc;
+  for (uint32_t r = r0; r < r1; ++r) acc += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
+  s_part[g][c] = acc;
   __syncthreads();
-  if (g == 0) {
-    uint32_t t = 0;
+  uint32_t before = 0, all = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += s_part[k][threadIdx.x];
-    digit_tot[col] = t;
+  for (uint32_t k = 0; k < 16; ++k) {
+    const uint32_t v = s_part[k][c];
+    if (k < g) before += v;
+    all += v;
+  }
+  if (g == 0) digit_tot[col] = all;
+  if (pass == 0) {
+    uint32_t run = before;
+    for (uint32_t r = r0; r < r1; ++r) {
+      tile_prefix0[(size_t)r * kMaxBins + col] = run;
+      run += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
+    }
   }
 }
 
@@ -555,102 +584,172 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
                                                             uint64_t* out_a, uint64_t* out_b,
                                                             uint32_t* idx_a, uint32_t* idx_b, uint32_t n, int pass,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
+                                                            const uint32_t* __restrict__ tile_prefix0,
                                                             uint32_t* status_all, uint32_t* tickets,
                                                             uint32_t n_tiles_max) {
+  PCC_KT(0);
   if (pass >= st->npasses) return;
   constexpr int NW = kSortThreads / 64;
+  // s_raw is used twice: while ranking, one 64-bit lane mask per (wave, digit); afterwards the tile's
+  // keys (and payload) in digit order, so that the global writes are runs
+  __shared__ __attribute__((aligned(16))) uint64_t s_raw[NW * kMaxBins];
+  static_assert(sizeof(uint64_t) * NW * kMaxBins >= (sizeof(uint64_t) + sizeof(uint32_t)) * kSortTile, "reorder buffers must fit");
+  uint64_t* s_match = s_raw;
+  uint64_t* s_keys = s_raw;
+  uint32_t* s_pay = reinterpret_cast<uint32_t*>(s_raw + kSortTile);
   __shared__ uint16_t s_cnt[NW][kMaxBins];  // per-wave running digit counts, then wave start ranks
-  __shared__ uint32_t s_base[kMaxBins];     // global position of this tile's first key per digit
+  __shared__ uint32_t s_gofs[kMaxBins];     // global position of a digit's first key minus its position in s_keys
+  __shared__ uint16_t s_dstart[kMaxBins];   // position of a digit's first key in s_keys
   __shared__ uint32_t s_scan[NW];
   __shared__ uint32_t s_tile;
 
   const uint32_t count = pass == 0 ? n : st->n_finite;  // pass 0 still holds the non-finite markers
   const uint32_t out_count = st->n_finite;
   const uint32_t n_tiles = (count + kSortTile - 1) / kSortTile;
-  if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
+  // Tile id: a tile only ever waits for lower tile ids.  A grid that is co-resident as a whole (one
+  // 1024-thread workgroup per CU always fits) may use blockIdx; a larger one takes a ticket, so that
+  // every tile it waits for has started (dispatch order is not promised).
+  const bool ticketed = gridDim.x > 256u;
+  if (ticketed && threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += kSortThreads) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
+  for (int k = threadIdx.x; k < NW * kMaxBins; k += kSortThreads) s_match[k] = 0ull;
   __syncthreads();
-  const uint32_t tile = s_tile;
+  const uint32_t tile = ticketed ? s_tile : blockIdx.x;
+  PCC_KT(1);
   if (tile >= n_tiles) return;
 
   const int bits = st->pass_bits[pass];
   const uint32_t nbins = 1u << bits, mask = nbins - 1u;
-  const bool pairs = st->packed == 0;
+  const bool with_payload = st->payload != 0;
   const int shift = st->ibits + st->pass_shift[pass];
   const uint64_t* in = (pass & 1) ? buf_b : buf_a;  // ping-pong: pass 0 reads a writes b
   uint64_t* out = (pass & 1) ? out_a : out_b;
-  const uint32_t* idx_in = (pass & 1) ? idx_b : idx_a;
-  uint32_t* idx_out = (pass & 1) ? idx_a : idx_b;
-  uint32_t* status = status_all + ((size_t)pass * n_tiles_max) * kMaxBins;
+  const uint32_t* pay_in = (pass & 1) ? idx_b : idx_a;
+  uint32_t* pay_out = (pass & 1) ? idx_a : idx_b;
+  const uint32_t n_groups_max = (n_tiles_max + kLookBackGroup - 1) / kLookBackGroup;
+  uint32_t* status = status_all + ((size_t)pass * (n_tiles_max + n_groups_max)) * kMaxBins;  // one word per (tile, digit)
+  uint32_t* gstatus = status + (size_t)n_tiles_max * kMaxBins;                                // one per (group, digit)
   const int lane = lane_id(), wave = wave_id();
   const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-
-  // global start of every digit = exclusive scan of the digit totals (thread = digit)
-  uint32_t gsum;
-  const uint32_t dtot = threadIdx.x < nbins ? digit_tot[(size_t)pass * kMaxBins + threadIdx.x] : 0u;
-  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
 
   // Tile order = (wave, round, lane): every wave ranks its own 512 consecutive keys against
   // wave-private counters, so no workgroup barrier is needed inside the ranking loop (the LDS
   // operations of one wave complete in issue order).
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
   uint64_t key[kSortItems];
+  uint32_t pay[kSortItems];
   uint16_t lrank[kSortItems];
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
     key[r] = i < count ? in[i] : kInvalidKey;
+    pay[r] = (with_payload && i < count) ? pay_in[i] : 0u;
   }
+  // global start of every digit = exclusive scan of the digit totals (thread = digit)
+  uint32_t gsum;
+  const uint32_t dtot = threadIdx.x < nbins ? digit_tot[(size_t)pass * kMaxBins + threadIdx.x] : 0u;
+  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
+  // Peers = lanes of this wave whose key has the same digit.  Every lane ORs its lane bit into the
+  // (wave, digit) mask in LDS and reads the mask back: three LDS operations instead of one ballot
+  // and a handful of 64-bit VALU operations per digit bit.  The first peer clears the mask again and
+  // advances the wave's digit counter (LDS operations of one wave execute in program order).
+  uint64_t* wmatch = s_match + (size_t)wave * kMaxBins;
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const bool valid = key[r] != kInvalidKey;
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-    uint64_t peers = __ballot(valid);  // lanes of this wave holding the same digit
-#pragma unroll
-    for (int b = 0; b < kMaxDigitBits; ++b) {
-      if (b < bits) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
-      }
-    }
+    if (valid) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
+    const uint64_t peers = valid ? wmatch[d] : 0ull;
     const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
     const uint32_t prior = s_cnt[wave][d];
-    if (valid && rank == 0) s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
+    if (valid && rank == 0) {
+      wmatch[d] = 0ull;
+      s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
+    }
     lrank[r] = (uint16_t)(prior + rank);
   }
   __syncthreads();
-  if (threadIdx.x < nbins) {  // thread = digit
-    const uint32_t d = threadIdx.x;
-    uint32_t run = 0;
+  PCC_KT(2);
+  const uint32_t d_me = threadIdx.x;  // thread = digit
+  uint32_t run = 0;
+  if (d_me < nbins) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const uint32_t c = s_cnt[w][d];
-      s_cnt[w][d] = (uint16_t)run;
+      const uint32_t c = s_cnt[w][d_me];
+      s_cnt[w][d_me] = (uint16_t)run;
       run += c;
     }
-    // publish this tile's count, then add up the tiles before it
-    uint32_t* mine = status + (size_t)tile * kMaxBins + d;
-    uint32_t acc = 0;
-    if (tile == 0) {
-      publish_u32(mine, kStatusInclusive | run);
-    } else {
-      publish_u32(mine, kStatusAggregate | run);
-      int j = (int)tile - 1;
-      uint32_t spins = 0;
-      while (j >= 0) {
-        uint32_t v[4];
+    // tell later tiles how many keys of this digit the tile holds, as early as possible
+    if (pass != 0) publish_u32(status + (size_t)tile * kMaxBins + d_me, kStatusAggregate | run);
+  }
+  uint32_t tile_valid;
+  const uint32_t dstart = block_excl_scan<NW, uint32_t>(run, s_scan, tile_valid);
+  PCC_KT(3);
+  // Keys of each digit in the tiles before this one: known up front for pass 0 (k_digit_totals).
+  // Otherwise a two-level decoupled look-back over one self-describing word per (tile, digit):
+  // (1) the earlier tiles of the own group of 16; the last tile of a group then publishes the group's
+  // count; (2) the groups before, 16 per poll, ending at the first group that already knows its
+  // inclusive prefix.  To keep the polling traffic off the memory system only ONE lane per awaited
+  // tile polls (the digit-0 word) until it is there; then every thread reads its own digit's words.
+  uint32_t acc = 0;
+  if (pass == 0) {
+    if (d_me < nbins) acc = tile_prefix0[(size_t)tile * kMaxBins + d_me];
+  } else {
+    const uint32_t g = tile / kLookBackGroup, q = tile % kLookBackGroup;
+    uint32_t spins = 0;
+    if (threadIdx.x < q) {
+      while ((poll_u32(status + (size_t)(g * kLookBackGroup + threadIdx.x) * kMaxBins) >> 30) == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+      }
+    }
+    __syncthreads();
+    PCC_KT(4);
+    uint32_t partial = 0;
+    const bool closes_group = q == kLookBackGroup - 1;
+    if (d_me < nbins) {
+      for (;;) {
+        uint32_t sum = 0;
+        bool all = true;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          v[k] = (j - k >= 0) ? poll_u32(status + (size_t)(j - k) * kMaxBins + d) : kStatusInclusive;
+        for (uint32_t k = 0; k < kLookBackGroup - 1; ++k) {
+          if (k < q) {
+            const uint32_t v = poll_u32(status + (size_t)(g * kLookBackGroup + k) * kMaxBins + d_me);
+            all &= (v >> 30) != 0;
+            sum += v & kStatusValue;
+          }
+        }
+        if (all) { partial = sum; break; }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+      }
+      if (closes_group) publish_u32(gstatus + (size_t)g * kMaxBins + d_me, (g == 0 ? kStatusInclusive : kStatusAggregate) | (partial + run));
+    }
+    PCC_KT(5);
+    if (g > 0 && threadIdx.x == 0) {
+      while ((poll_u32(gstatus + (size_t)(g - 1) * kMaxBins) >> 30) == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+      }
+    }
+    __syncthreads();
+    PCC_KT(6);
+    if (d_me < nbins) {
+      uint32_t before = 0;
+      int j = (int)g - 1;
+      while (j >= 0) {
+        uint32_t v[kLookBackGroup];
+#pragma unroll
+        for (int k = 0; k < kLookBackGroup; ++k)
+          v[k] = (j - k >= 0) ? poll_u32(gstatus + (size_t)(j - k) * kMaxBins + d_me) : kStatusInclusive;
         int used = 0;
         bool done = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kLookBackGroup; ++k) {
           if (!done && used == k) {
             const uint32_t f = v[k] >> 30;
             if (f != 0) {
-              acc += v[k] & kStatusValue;
+              before += v[k] & kStatusValue;
               ++used;
               done = f == 2;
             }
@@ -663,19 +762,38 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
           if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
         }
       }
-      publish_u32(mine, kStatusInclusive | ((acc + run) & kStatusValue));
+      if (closes_group && g != 0) publish_u32(gstatus + (size_t)g * kMaxBins + d_me, kStatusInclusive | ((before + partial + run) & kStatusValue));
+      acc = before + partial;
     }
-    s_base[d] = gbase + acc;
+  }
+  if (d_me < nbins) {
+    s_dstart[d_me] = (uint16_t)dstart;
+    s_gofs[d_me] = gbase + acc - dstart;
   }
   __syncthreads();
+  PCC_KT(7);
+  // keys into digit order in LDS ...
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     if (key[r] != kInvalidKey) {
       const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-      const uint32_t pos = s_base[d] + s_cnt[wave][d] + lrank[r];
+      const uint32_t lp = (uint32_t)s_dstart[d] + s_cnt[wave][d] + lrank[r];
+      s_keys[lp] = key[r];
+      if (with_payload) s_pay[lp] = pay[r];
+    }
+  }
+  __syncthreads();
+  // ... and out in runs: consecutive lanes hold consecutive keys of (mostly) the same digit
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    const uint32_t lp = (uint32_t)k * kSortThreads + threadIdx.x;
+    if (lp < tile_valid) {
+      const uint64_t kk = s_keys[lp];
+      const uint32_t d = (uint32_t)(kk >> shift) & mask;
+      const uint32_t pos = s_gofs[d] + lp;
       if (pos < out_count) {  // always true unless a look-back gave up (kErrSpin)
-        out[pos] = key[r];
-        if (pairs) idx_out[pos] = idx_in[wbase + (uint32_t)r * 64u + (uint32_t)lane];
+        out[pos] = kk;
+        if (with_payload) pay_out[pos] = s_pay[lp];
       }
     }
   }
@@ -709,33 +827,47 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
   __shared__ uint64_t s_prefix;
   __shared__ uint32_t s_tile;
   const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  __syncthreads();
-  const uint32_t tile = s_tile;
+  const bool ticketed = gridDim.x > 256u;  // see k_sort_pass
+  if (ticketed) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+  }
+  const uint32_t tile = ticketed ? s_tile : blockIdx.x;
   if ((uint64_t)tile * kSortTile >= nfin) return;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, depth = st->depth;
-  const uint32_t i0 = tile * kSortTile + threadIdx.x * kSortItems;
-  uint64_t ht[kSortItems], code[kSortItems];
-  uint64_t acc = 0;
-  {
-    uint64_t prev = (i0 && i0 < nfin) ? (keys[i0 - 1] >> ibits) : 0ull;
+  const int lane = lane_id(), wave = wave_id();
+  // Every wave owns 512 consecutive sorted keys, read as 8 rows of 64 (coalesced); element (r, lane)
+  // is key wbase + 64 r + lane, so scan order is row-major inside the wave, then wave-major.
+  const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
+  uint64_t ht[kSortItems], code[kSortItems], inc[kSortItems];
 #pragma unroll
-    for (int e = 0; e < kSortItems; ++e) {
-      const uint32_t i = i0 + e;
-      ht[e] = 0; code[e] = 0;
-      if (i < nfin) {
-        code[e] = keys[i] >> ibits;
-        ht[e] = head_t(code[e], prev, i == 0, depth);
-        prev = code[e];
-      }
-      acc += ht[e];
-    }
+  for (int r = 0; r < kSortItems; ++r) {
+    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+    code[r] = i < nfin ? (keys[i] >> ibits) : 0ull;
   }
-  uint64_t tot;
-  uint64_t ex = block_excl_scan<NW, uint64_t>(acc, s_w, tot);
-  if (wave_id() == 0) {  // one wave looks back, 64 earlier tiles per step
-    const int lane = lane_id();
+  uint64_t carry = (lane == 0 && wbase > 0 && wbase < nfin) ? (keys[wbase - 1] >> ibits) : 0ull;  // key before the segment
+  uint64_t wave_tot = 0;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+    uint64_t prev = __shfl_up(code[r], 1);
+    if (lane == 0) prev = carry;
+    ht[r] = i < nfin ? head_t(code[r], prev, i == 0, depth) : 0ull;
+    carry = __shfl(code[r], 63);  // lane 0 of the next row compares against the end of this one
+    inc[r] = wave_incl_scan_u64(ht[r]) + wave_tot;
+    wave_tot = __shfl(inc[r], 63);
+  }
+  if (lane == 63) s_w[wave] = wave_tot;
+  __syncthreads();
+  uint64_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint64_t x = s_w[w];
+    if (w < wave) woff += x;
+    tot += x;
+  }
+  if (wave == 0) {  // one wave looks back, 64 earlier tiles per step
     const uint64_t mine = scan_pack(tot);
     uint64_t before = 0;
     if (tile == 0) {
@@ -766,17 +898,16 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
   }
   __syncthreads();
   const uint64_t pre = s_prefix;
-  ex += pre;
 #pragma unroll
-  for (int e = 0; e < kSortItems; ++e) {
-    if (ht[e] & 1ull) {
+  for (int r = 0; r < kSortItems; ++r) {
+    if (ht[r] & 1ull) {
+      const uint64_t ex = pre + woff + inc[r] - ht[r];
       const uint32_t id = (uint32_t)(ex & 0xffffffffu);
-      leaf_start[id] = i0 + e;
-      leaf_code[id] = code[e];
+      leaf_start[id] = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+      leaf_code[id] = code[r];
       leaf_base[id] = (uint32_t)(ex >> 32);
-      leaf_t[id] = (uint8_t)(ht[e] >> 32);
+      leaf_t[id] = (uint8_t)(ht[r] >> 32);
     }
-    ex += ht[e];
   }
   // zero the piece of the DFS stream this tile's leaves open: bytes [b0, b1)
   const uint32_t b0 = (uint32_t)(pre >> 32), b1 = b0 + (uint32_t)(tot >> 32);
@@ -829,11 +960,12 @@ struct IndexOf {
   __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return idx ? idx[i] : (uint32_t)(keys[i] & imask); }
 };
 
-__device__ __forceinline__ void leaf_colour(const PointView& pv, const IndexOf& index_of, uint32_t s, uint32_t e,
-                                            uint32_t red, uint32_t& b, uint32_t& g, uint32_t& r) {
+// `colour_pay`: the sorted colour words themselves (payload 2), else they are gathered through the point index
+__device__ __forceinline__ void leaf_colour(const PointView& pv, const IndexOf& index_of, const uint32_t* __restrict__ colour_pay,
+                                            uint32_t s, uint32_t e, uint32_t red, uint32_t& b, uint32_t& g, uint32_t& r) {
   uint32_t s0 = 0, s1 = 0, s2 = 0;
   for (uint32_t i = s; i < e; ++i) {
-    const uint32_t w = load_rgba(pv, index_of(i));
+    const uint32_t w = colour_pay ? colour_pay[i] : load_rgba(pv, index_of(i));
     s0 += w & 0xffu; s1 += (w >> 8) & 0xffu; s2 += (w >> 16) & 0xffu;
   }
   const uint32_t cnt = e - s;
@@ -882,7 +1014,9 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
 
   IndexOf index_of;
   index_of.keys = keys;
-  index_of.idx = st->packed ? nullptr : ((st->npasses & 1) ? idx_b : idx_a);
+  const uint32_t* pay_sorted = (st->npasses & 1) ? idx_b : idx_a;
+  index_of.idx = st->payload == 1 ? pay_sorted : nullptr;
+  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
   index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
 
@@ -890,7 +1024,7 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
     // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
     if (lp.write_image && j < W * H) {
       uint32_t b, g, r;
-      leaf_colour(pv, index_of, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
+      leaf_colour(pv, index_of, colour_pay, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
       const uint32_t px = snake_pos(j, W, H);
       image[3 * px] = (uint8_t)b; image[3 * px + 1] = (uint8_t)g; image[3 * px + 2] = (uint8_t)r;
     }
@@ -903,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double r
 
     uint32_t cb = 0, cg = 0, cr = 0;
     if (lp.do_color) {
-      if (!(lp.ablate & 1u)) leaf_colour(pv, index_of, s, e, lp.color_reduction, cb, cg, cr);
+      if (!(lp.ablate & 1u)) leaf_colour(pv, index_of, colour_pay, s, e, lp.color_reduction, cb, cg, cr);
       if (!(lp.ablate & 2u)) {
         bgr[3 * j] = (uint8_t)cb; bgr[3 * j + 1] = (uint8_t)cg; bgr[3 * j + 2] = (uint8_t)cr;
         if (lp.write_image) {
@@ -1109,11 +1243,18 @@ __global__ __launch_bounds__(64) void k_jpeg_fdct(const uint8_t* __restrict__ im
     if (tm) tm->stamp(name, stream);                         \
   } while (0)
 
+#ifdef PCC_KTIME
+extern "C" int pcc_debug_read_ktime(unsigned long long* out, size_t count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktime), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 size_t sync_area_bytes(uint32_t n, int passes) {
   const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
   size_t b = 64;                                   // tickets
   b += ((tiles * sizeof(uint64_t) + 15) / 16) * 16;  // leaf scan status
-  b += (size_t)passes * tiles * kMaxBins * sizeof(uint32_t);  // sort status
+  const size_t groups = (tiles + kLookBackGroup - 1) / kLookBackGroup;
+  b += (size_t)passes * (tiles + groups) * kMaxBins * sizeof(uint32_t);  // sort status: per tile, per group of tiles
   return b;
 }
 
@@ -1130,15 +1271,15 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("begin");
   hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes, reinterpret_cast<uint4*>(sync), sync_vec16);
   PCC_STAMP("k_chunk_boxes");
-  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, passes, a.state);
+  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, passes, (int)a.lp.do_color, a.state);
   PCC_STAMP("k_bbox_events");
-  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.state, a.keys_a, a.idx_a, a.hist_rows);
+  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows);
   PCC_STAMP("k_make_keys");
-  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / 64u), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot);
+  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / 64u), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0);
   PCC_STAMP("k_digit_totals");
   for (int pass = 0; pass < passes; ++pass) {
     hipLaunchKernelGGL(k_sort_pass, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
-                       n, pass, a.state, a.digit_tot, sort_status, tickets, s_tiles);
+                       n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles);
     PCC_STAMP("k_sort_pass");
   }
   hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Developer tool: phase timing inside k_sort_pass (library built with -DPCC_KTIME)."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as G
+pkg = G.load_package(); b, syn = pkg.binding, pkg.synthetic
+cfg = syn.CONFIGS["cfg2"]
+p = b.make_params(octree_bits=cfg["octree_bits"])
+ctx = b.Context(0); pts = syn.make_frame("cfg2"); dev = ctx.upload(pts)
+for _ in range(5):
+    ctx.hotpath_launch(dev, len(pts), p); hot = ctx.hotpath_finish(copy=False)
+buf = np.zeros(7 * 1024 * 8, dtype=np.uint64)
+lib = b.load_library()
+print("rc", lib.pcc_debug_read_ktime(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.size)))
+t = buf.reshape(7, 1024, 8).astype(np.int64)
+for ps in range(4):
+    x = t[ps, :245, :8]
+    t0 = x[:, 0].min()
+    rel = (x - t0) / 100.0
+    print("pass %d: stamps (median us): start %.2f tile %.2f ranked %.2f scanned %.2f | prewait1 %.2f partial %.2f prewait2 %.2f lookback-done %.2f" % ((ps,) + tuple(np.median(rel, axis=0))))
+    print("        stamps (max us):", np.round(rel.max(axis=0), 2))
+ctx.close()
