@@ -308,12 +308,14 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.tile_prefix0 = ctx->d_tile_prefix0.p; a.sync_area = ctx->d_sync.p;
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
   a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
-  a.image = ctx->d_image.p; a.simplified = ctx->d_simplified.p;
+  a.simplified = ctx->d_simplified.p;
   a.coefs = nullptr;
   if (a.lp.write_image && ctx->jpeg_on_gpu) {
     a.coefs = ctx->d_coefs.p;
     BaselineJpeg::quantiser(prm->jpeg_quality, a.jq.half, a.jq.magic);
   }
+  // the snake image itself only leaves the chip if somebody wants to look at it, or the host does the JPEG
+  a.image = (a.lp.write_image && (ctx->copy_image || !a.coefs)) ? ctx->d_image.p : nullptr;
   ctx->args = a;
   rc = enqueue(ctx);
   if (rc != PCC_OK) return rc;

@@ -973,161 +973,8 @@ __device__ __forceinline__ void leaf_colour(const PointView& pv, const IndexOf& 
   b = (s0 >> red) & 0xffu; g = (s1 >> red) & 0xffu; r = (s2 >> red) & 0xffu;
 }
 
-__global__ __launch_bounds__(kBlock) void k_leaf_finalize(PointView pv, double res, LeafParams lp,
-                                                          const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
-                                                          const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
-                                                          const FrameState* __restrict__ st,
-                                                          const uint32_t* __restrict__ leaf_start, const uint64_t* __restrict__ leaf_code,
-                                                          const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
-                                                          uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
-                                                          uint8_t* __restrict__ image, float4* __restrict__ simplified) {
-  const uint32_t L = st->n_leaves;
-  if (L == 0) return;
-  const uint32_t j0 = blockIdx.x * kBlock;
-  const uint32_t j = j0 + threadIdx.x;
-  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
-  const int ibits = st->ibits, D = st->depth;
-  const int lane = lane_id(), wave = wave_id();
-
-  // Who opened my parent?  The parent of the topmost node leaf j opens (level D-t-1) was opened by
-  // the nearest earlier leaf f with t(f) > t(j).  Inside the workgroup that is a ballot per level
-  // plus a count-leading-zeros; only leaves whose parent predates the block search globally.
-  __shared__ uint64_t s_mask[kBlock / 64][kMaxDepth + 2];
-  __shared__ uint8_t s_t[kBlock];
-  __shared__ uint32_t s_base[kBlock];
-  // The branch nodes opened by this block's leaves are one contiguous piece of the DFS stream:
-  // collect their child bits in LDS and flush whole dwords (one global atomic per dword, not per bit).
-  __shared__ uint32_t s_occ[kBlock * kMaxDepth / 4 + 2];
-  const int t = j < L ? (int)leaf_t[j] : 0;
-  const uint32_t base = j < L ? leaf_base[j] : 0u;
-  s_t[threadIdx.x] = (uint8_t)t;
-  s_base[threadIdx.x] = base;
-  for (int v = 1; v <= D; ++v) {
-    const uint64_t mk = __ballot(j < L && t >= v);
-    if (lane == 0) s_mask[wave][v] = mk;
-  }
-  for (uint32_t k = threadIdx.x; k < kBlock * kMaxDepth / 4 + 2; k += kBlock) s_occ[k] = 0u;
-  __syncthreads();
-  const uint32_t n_here = min((uint32_t)kBlock, L > j0 ? L - j0 : 0u);
-  const uint32_t seg0 = n_here ? (s_base[0] & ~3u) : 0u;  // dword-aligned start of the block's stream piece
-  const uint32_t seg1 = n_here ? s_base[n_here - 1] + s_t[n_here - 1] : 0u;
-
-  IndexOf index_of;
-  index_of.keys = keys;
-  const uint32_t* pay_sorted = (st->npasses & 1) ? idx_b : idx_a;
-  index_of.idx = st->payload == 1 ? pay_sorted : nullptr;
-  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
-  index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
-  const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
-
-  if (j >= L) {
-    // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
-    if (lp.write_image && j < W * H) {
-      uint32_t b, g, r;
-      leaf_colour(pv, index_of, colour_pay, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
-      const uint32_t px = snake_pos(j, W, H);
-      image[3 * px] = (uint8_t)b; image[3 * px + 1] = (uint8_t)g; image[3 * px + 2] = (uint8_t)r;
-    }
-  } else {
-    const uint32_t s = leaf_start[j], e = leaf_start[j + 1];
-    const uint64_t code = leaf_code[j];
-    const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
-    const uint64_t full = code | pfx;
-    const uint32_t key[3] = {compact3(full >> 2), compact3(full >> 1), compact3(full)};
-
-    uint32_t cb = 0, cg = 0, cr = 0;
-    if (lp.do_color) {
-      if (!(lp.ablate & 1u)) leaf_colour(pv, index_of, colour_pay, s, e, lp.color_reduction, cb, cg, cr);
-      if (!(lp.ablate & 2u)) {
-        bgr[3 * j] = (uint8_t)cb; bgr[3 * j + 1] = (uint8_t)cg; bgr[3 * j + 2] = (uint8_t)cr;
-        if (lp.write_image) {
-          const uint32_t px = snake_pos(j, W, H);
-          image[3 * px] = (uint8_t)cb; image[3 * px + 1] = (uint8_t)cg; image[3 * px + 2] = (uint8_t)cr;
-        }
-      }
-    }
-
-    // lower voxel corner (impl.hpp:1519-1521), then centre (impl.hpp:1560-1562) or centroid (:1566-1573)
-    double lc[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) lc[a] = __dadd_rn(__dmul_rn((double)key[a], res), st->mn[a]);
-    float c[3];
-    if (!lp.do_centroid) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) c[a] = (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
-    } else {
-      float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
-      for (uint32_t i = s; i < e; ++i) {
-        float x, y, z;
-        load_xyz(pv, index_of(i), x, y, z);
-        sx = __fadd_rn(sx, x); sy = __fadd_rn(sy, y); sz = __fadd_rn(sz, z);
-      }
-      const float cnt = (float)(e - s);
-      c[0] = __fdiv_rn(sx, cnt); c[1] = __fdiv_rn(sy, cnt); c[2] = __fdiv_rn(sz, cnt);
-      const double prec = (double)0.001f;  // PointCoding default precision (ptv2.h:89-91)
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
-        d = max(-127, min(127, d));
-        centroid[3 * j + a] = (uint8_t)d;
-      }
-    }
-    if (simplified && !(lp.ablate & 8u)) {
-      const uint32_t rgba = cb | (cg << 8) | (cr << 16) | 0xff000000u;
-      simplified[j] = make_float4(c[0], c[1], c[2], __uint_as_float(rgba));
-    }
-
-    // occupancy: the t(j) branch nodes this leaf opens sit at base(j).. in the stream; each gets the
-    // child bit on this leaf's path.  The topmost one is itself a new child of an older node.
-    if (!(lp.ablate & 4u)) {
-      for (int q = 0; q < t; ++q) {
-        const int level = D - t + q;
-        const uint32_t child = (uint32_t)(full >> (3 * (D - 1 - level))) & 7u;
-        const uint32_t lo = base + (uint32_t)q - seg0;
-        atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
-      }
-      if (j > 0) {
-        const int m = t, v = t + 1;  // t < D for every leaf but the first
-        const uint32_t child = (uint32_t)(full >> (3 * m)) & 7u;
-        int fl = -1;
-        uint64_t mk = s_mask[wave][v] & (lane ? (~0ull >> (64 - lane)) : 0ull);
-        if (mk) {
-          fl = wave * 64 + 63 - __clzll((long long)mk);
-        } else {
-          for (int w = wave - 1; w >= 0; --w) {
-            mk = s_mask[w][v];
-            if (mk) { fl = w * 64 + 63 - __clzll((long long)mk); break; }
-          }
-        }
-        if (fl >= 0) {  // parent opened inside this block: its byte lives in the LDS piece
-          const uint32_t lo = s_base[fl] + (uint32_t)((D - m - 1) - (D - (int)s_t[fl])) - seg0;
-          atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
-        } else {
-          const int sh = 3 * (m + 1);
-          const uint64_t pcode = sh >= 64 ? 0ull : ((code >> sh) << sh);
-          uint32_t lo = 0, hi = j0;  // first leaf f before this block with leaf_code[f] >= pcode
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (leaf_code[mid] < pcode) lo = mid + 1; else hi = mid;
-          }
-          or_byte(occ, leaf_base[lo] + (uint32_t)((D - m - 1) - (D - (int)leaf_t[lo])), 1u << child);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (seg1 > seg0) {
-    const uint32_t ndw = (seg1 - seg0 + 3u) >> 2;
-    unsigned int* dst = reinterpret_cast<unsigned int*>(occ + seg0);
-    for (uint32_t k = threadIdx.x; k < ndw; k += kBlock) {
-      const uint32_t v = s_occ[k];
-      if (v) atomicOr(dst + k, v);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// Stage 6: JPEG front end on the snake-mapped image (jpeg_io.hpp:259-314 drives libjpeg with
+// JPEG front-end helpers (jpeg_io.hpp:259-314 drives libjpeg with
 // JCS_RGB in, YCbCr 4:2:0, islow FDCT, quality-scaled Annex-K tables).  Everything up to the
 // quantised coefficients is exact integer arithmetic and embarrassingly parallel; only the Huffman
 // bit packing stays on the host.  One thread per 8x8 block, six blocks per 16x16 MCU
@@ -1162,49 +1009,251 @@ __device__ __forceinline__ void jpeg_fdct_1d(int& d0, int& d1, int& d2, int& d3,
 }
 
 
-__global__ __launch_bounds__(64) void k_jpeg_fdct(const uint8_t* __restrict__ image, const FrameState* __restrict__ st,
-                                                  JpegQuant q, int16_t* __restrict__ coefs) {
+__device__ const uint8_t kZigzagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                            41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                            30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ------------------------------------------------------------------------------------------
+// Stage 5+6: one workgroup per MCU ROW of the snake-mapped image.  In snake order (snake.h:46-71) the
+// 16 image rows of an MCU row are filled by ONE contiguous range of leaves (two 8-row block rows of
+// 2048 leaves; the last, partial block row holds 256 x (H mod 8)), so a workgroup owns <= 4096
+// consecutive leaves and everything they produce:
+//   per leaf   colour mean (P6), voxel centre / centroid (C2, C4), simplified-cloud point, the leaf's
+//              bits of the occupancy stream (P5; collected in an LDS window of the DFS stream)
+//   per tile   the 16 x 256 image window in LDS (never written to HBM unless the caller wants the image),
+//              libjpeg's front end on it (jpeg_io.hpp:259-314: RGB->YCbCr, h2v2 downsample, islow FDCT,
+//              quantisation) -> 96 blocks of 64 zigzag-ordered coefficients; only Huffman coding is left
+//              for the host.
+// All global writes are contiguous runs (bgr, simplified, coefficients, image rows).
+// ------------------------------------------------------------------------------------------
+constexpr int kFinThreads = 1024;
+constexpr int kFinRounds = 4;                          // leaves per thread
+constexpr int kFinTile = kFinThreads * kFinRounds;     // 4096 leaf positions
+constexpr int kFinSlots = kFinTile / 64;               // (wave, round) slots of 64 consecutive leaves
+constexpr int kOccWindow = 8192;                       // dwords of the DFS stream collected in LDS
+constexpr int kMaskStride = kMaxDepth + 1;
+
+__global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double res, LeafParams lp,
+                                                           const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                           const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
+                                                           const FrameState* __restrict__ st,
+                                                           const uint32_t* __restrict__ leaf_start, const uint64_t* __restrict__ leaf_code,
+                                                           const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
+                                                           uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
+                                                           uint8_t* __restrict__ image, float4* __restrict__ simplified,
+                                                           JpegQuant jq, int16_t* __restrict__ coefs) {
   const uint32_t L = st->n_leaves;
   if (L == 0) return;
-  const int W = 256, H = (int)(L / 256u + 1u);
-  const int mcus_x = W / 16, mcus_y = (H + 15) / 16;
-  const uint32_t gid = blockIdx.x * 64u + threadIdx.x;
-  const uint32_t mcu = gid / 6u, slot = gid % 6u;
-  if (mcu >= (uint32_t)(mcus_x * mcus_y)) return;
-  const int mx = (int)(mcu % (uint32_t)mcus_x), my = (int)(mcu / (uint32_t)mcus_x);
-  int16_t* out = coefs + (size_t)gid * 64;
-  const int y_hb = (H + 7) / 8, ch = (H + 1) / 2;
-  // compile-time table + full unrolling keeps the 64 samples in registers (no scratch indexing)
-  constexpr uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-  int s[64];
-  if (slot < 4) {
-    const int by = 2 * my + (int)(slot >> 1), bx = 2 * mx + (int)(slot & 1);
-    if (by >= y_hb) {  // dummy block row below the image: the host copies the DC of the previous block
+  const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
+  const uint32_t m = blockIdx.x;               // MCU row
+  if (16u * m >= H) return;
+  const uint32_t full = H / 8u, hl = H % 8u;
+  const uint32_t br0 = 2u * m;
+  const uint32_t cnt0 = br0 < full ? 2048u : 256u * hl;  // br0 <= full here
+  const uint32_t cnt1 = br0 + 1u < full ? 2048u : (br0 + 1u == full ? 256u * hl : 0u);
+  const uint32_t pos0 = 2048u * br0, npos = cnt0 + cnt1;   // leaf positions [pos0, pos0 + npos) fill this MCU row
+  const uint32_t nl = min(npos, L - pos0);                  // real leaves among them (pos0 <= L always)
+
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[16 * 768];
+  __shared__ __attribute__((aligned(16))) uint8_t s_bgr[3 * kFinTile];
+  // phase A: s_base | s_occ | s_mask | s_t ; phase B: the FDCT workspace
+  __shared__ __attribute__((aligned(16))) uint32_t s_scratch[kFinTile + kOccWindow + kFinSlots * kMaskStride * 2 + kFinTile / 4];
+  __shared__ uint32_t s_pad;
+  uint32_t* s_base = s_scratch;
+  uint32_t* s_occ = s_scratch + kFinTile;
+  uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
+  uint8_t* s_t = reinterpret_cast<uint8_t*>(s_mask + kFinSlots * kMaskStride);
+  int* s_ws = reinterpret_cast<int*>(s_scratch);
+  static_assert(sizeof(uint32_t) * (kFinTile + kOccWindow) >= sizeof(int) * 96 * 8 * 9, "FDCT workspace must fit");
+
+  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const int ibits = st->ibits, D = st->depth;
+  const int lane = lane_id(), wave = wave_id();
+  IndexOf index_of;
+  index_of.keys = keys;
+  const uint32_t* pay_sorted = (st->npasses & 1) ? idx_b : idx_a;
+  index_of.idx = st->payload == 1 ? pay_sorted : nullptr;
+  index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
+  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
+
+  // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
+  int t[kFinRounds];
+  uint32_t base[kFinRounds], ls[kFinRounds], le[kFinRounds];
+  uint64_t code[kFinRounds];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) reinterpret_cast<uint4*>(out)[k] = make_uint4(0, 0, 0, 0);
-      return;
+  for (int r = 0; r < kFinRounds; ++r) {
+    const uint32_t slot = (uint32_t)wave * kFinRounds + r, lj = slot * 64u + (uint32_t)lane, j = pos0 + lj;
+    const bool is_leaf = lj < nl;
+    t[r] = is_leaf ? (int)leaf_t[j] : 0;
+    base[r] = is_leaf ? leaf_base[j] : 0u;
+    code[r] = is_leaf ? leaf_code[j] : 0ull;
+    ls[r] = is_leaf ? leaf_start[j] : 0u;
+    le[r] = is_leaf ? leaf_start[j + 1] : 0u;
+    s_t[lj] = (uint8_t)t[r];
+    s_base[lj] = base[r];
+    for (int v = 1; v <= D; ++v) {
+      const uint64_t mk = __ballot(is_leaf && t[r] >= v);
+      if (lane == 0) s_mask[slot * kMaskStride + v] = mk;
     }
+  }
+  for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
+  if (threadIdx.x == 0 && lp.write_image && nl < npos) {  // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
+    uint32_t b, g, r;
+    leaf_colour(pv, index_of, colour_pay, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
+    s_pad = b | (g << 8) | (r << 16);
+  }
+  __syncthreads();
+  const uint32_t seg0 = nl ? (s_base[0] & ~3u) : 0u;  // dword-aligned start of the tile's piece of the DFS stream
+  const uint32_t seg1 = nl ? s_base[nl - 1] + s_t[nl - 1] : 0u;
+  const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
+
+  // ---- A2: per leaf ----
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const uint8_t* row = image + ((size_t)min(8 * by + r, H - 1) * W + 8 * bx) * 3;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int R = row[3 * c], G = row[3 * c + 1], B = row[3 * c + 2];
-        s[8 * r + c] = ((19595 * R + 38470 * G + 7471 * B + 32768) >> 16) - 128;
+  for (int r = 0; r < kFinRounds; ++r) {
+    const uint32_t slot = (uint32_t)wave * kFinRounds + r, lj = slot * 64u + (uint32_t)lane, j = pos0 + lj;
+    if (lj >= nl) {
+      if (lp.write_image && lj < npos) {
+        const uint32_t px = snake_pos(j, W, H) - 16u * m * W;
+        s_img[3 * px] = (uint8_t)s_pad; s_img[3 * px + 1] = (uint8_t)(s_pad >> 8); s_img[3 * px + 2] = (uint8_t)(s_pad >> 16);
+      }
+      continue;
+    }
+    const uint64_t fullcode = code[r] | pfx;
+    const uint32_t key[3] = {compact3(fullcode >> 2), compact3(fullcode >> 1), compact3(fullcode)};
+    uint32_t cb = 0, cg = 0, cr = 0;
+    if (lp.do_color) {
+      leaf_colour(pv, index_of, colour_pay, ls[r], le[r], lp.color_reduction, cb, cg, cr);
+      s_bgr[3 * lj] = (uint8_t)cb; s_bgr[3 * lj + 1] = (uint8_t)cg; s_bgr[3 * lj + 2] = (uint8_t)cr;
+      if (lp.write_image) {
+        const uint32_t px = snake_pos(j, W, H) - 16u * m * W;
+        s_img[3 * px] = (uint8_t)cb; s_img[3 * px + 1] = (uint8_t)cg; s_img[3 * px + 2] = (uint8_t)cr;
       }
     }
-  } else {
-    const bool is_cr = slot == 5;
+    // lower voxel corner (impl.hpp:1519-1521), then centre (impl.hpp:1560-1562) or centroid (:1566-1573)
+    double lc[3];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int crow = min(8 * my + r, ch - 1);  // component rows below the image repeat the last real one
-      const uint8_t* r0 = image + ((size_t)min(2 * crow, H - 1) * W + 16 * mx) * 3;
-      const uint8_t* r1 = image + ((size_t)min(2 * crow + 1, H - 1) * W + 16 * mx) * 3;
+    for (int a = 0; a < 3; ++a) lc[a] = __dadd_rn(__dmul_rn((double)key[a], res), st->mn[a]);
+    float c[3];
+    if (!lp.do_centroid) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) c[a] = (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
+    } else {
+      float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
+      for (uint32_t i = ls[r]; i < le[r]; ++i) {
+        float x, y, z;
+        load_xyz(pv, index_of(i), x, y, z);
+        sx = __fadd_rn(sx, x); sy = __fadd_rn(sy, y); sz = __fadd_rn(sz, z);
+      }
+      const float cntf = (float)(le[r] - ls[r]);
+      c[0] = __fdiv_rn(sx, cntf); c[1] = __fdiv_rn(sy, cntf); c[2] = __fdiv_rn(sz, cntf);
+      const double prec = (double)0.001f;  // PointCoding default precision (ptv2.h:89-91)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
+        d = max(-127, min(127, d));
+        centroid[3 * (size_t)j + a] = (uint8_t)d;
+      }
+    }
+    if (simplified) {
+      const uint32_t rgba = cb | (cg << 8) | (cr << 16) | 0xff000000u;
+      simplified[j] = make_float4(c[0], c[1], c[2], __uint_as_float(rgba));
+    }
+
+    // occupancy: the t(j) branch nodes this leaf opens sit at base(j).. in the stream; each gets the
+    // child bit on this leaf's path.  The topmost one is itself a new child of an older node: the node
+    // opened by the nearest earlier leaf f with t(f) > t(j) (ballot masks inside the tile, binary
+    // search over the leaf codes before it).
+    const int tt = t[r];
+    for (int q = 0; q < tt; ++q) {
+      const int level = D - tt + q;
+      const uint32_t child = (uint32_t)(fullcode >> (3 * (D - 1 - level))) & 7u;
+      const uint32_t lo = base[r] + (uint32_t)q - seg0;
+      if ((lo >> 2) < (uint32_t)kOccWindow) atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
+      else or_byte(occ, base[r] + (uint32_t)q, 1u << child);
+    }
+    if (j > 0) {
+      const int v = tt + 1;  // t < D for every leaf but the first
+      const uint32_t child = (uint32_t)(fullcode >> (3 * tt)) & 7u;
+      int fl = -1;
+      uint64_t mk = s_mask[slot * kMaskStride + v] & (lane ? (~0ull >> (64 - lane)) : 0ull);
+      if (mk) {
+        fl = (int)slot * 64 + 63 - __clzll((long long)mk);
+      } else {
+        for (int sl = (int)slot - 1; sl >= 0; --sl) {
+          mk = s_mask[sl * kMaskStride + v];
+          if (mk) { fl = sl * 64 + 63 - __clzll((long long)mk); break; }
+        }
+      }
+      uint32_t off;
+      if (fl >= 0) {
+        off = s_base[fl] + (uint32_t)((D - tt - 1) - (D - (int)s_t[fl]));
+      } else {
+        const int sh = 3 * (tt + 1);
+        const uint64_t pcode = sh >= 64 ? 0ull : ((code[r] >> sh) << sh);
+        uint32_t lo = 0, hi = pos0;  // first leaf f before this tile with leaf_code[f] >= pcode
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (leaf_code[mid] < pcode) lo = mid + 1; else hi = mid;
+        }
+        off = leaf_base[lo] + (uint32_t)((D - tt - 1) - (D - (int)leaf_t[lo]));
+      }
+      const uint32_t rel = off - seg0;
+      if (off >= seg0 && (rel >> 2) < (uint32_t)kOccWindow) atomicOr(&s_occ[rel >> 2], (1u << child) << (8u * (rel & 3u)));
+      else or_byte(occ, off, 1u << child);
+    }
+  }
+  __syncthreads();
+
+  // ---- A3: contiguous writes: DFS stream piece, bgr, image rows ----
+  if (seg1 > seg0) {
+    const uint32_t ndw = min((seg1 - seg0 + 3u) >> 2, (uint32_t)kOccWindow);
+    unsigned int* dst = reinterpret_cast<unsigned int*>(occ + seg0);
+    for (uint32_t k = threadIdx.x; k < ndw; k += kFinThreads) {
+      const uint32_t v = s_occ[k];
+      if (v) atomicOr(dst + k, v);  // neighbouring tiles share the boundary dwords and set parent bits here
+    }
+  }
+  if (lp.do_color && nl) {
+    const uint32_t nbytes = 3u * nl, ndw = nbytes >> 2;
+    uint8_t* dstb = bgr + 3 * (size_t)pos0;  // 3 * pos0 is a multiple of 4
+    for (uint32_t k = threadIdx.x; k < ndw; k += kFinThreads) reinterpret_cast<uint32_t*>(dstb)[k] = reinterpret_cast<const uint32_t*>(s_bgr)[k];
+    for (uint32_t k = 4u * ndw + threadIdx.x; k < nbytes; k += kFinThreads) dstb[k] = s_bgr[k];
+  }
+  if (lp.write_image && image) {
+    const uint32_t rows_here = min(16u, H - 16u * m), ndw = rows_here * 768u / 4u;
+    uint32_t* dsti = reinterpret_cast<uint32_t*>(image + (size_t)16u * m * 768u);
+    for (uint32_t k = threadIdx.x; k < ndw; k += kFinThreads) dsti[k] = reinterpret_cast<const uint32_t*>(s_img)[k];
+  }
+  if (!(lp.write_image && coefs)) return;
+  __syncthreads();  // the scratch area changes hands
+
+  // ---- B: JPEG front end on the 16-row window: thread = (8x8 block, line) ----
+  const int y_hb = (int)(H + 7u) / 8, ch = (int)(H + 1u) / 2, Hi = (int)H, row0 = 16 * (int)m;
+  const int blk = threadIdx.x >> 3, line = threadIdx.x & 7;
+  const int mx = blk / 6, slot6 = blk % 6;
+  const bool active = threadIdx.x < 96 * 8;
+  bool dummy = false;
+  if (active) {
+    int d0, d1, d2, d3, d4, d5, d6, d7;
+    int* dd[8] = {&d0, &d1, &d2, &d3, &d4, &d5, &d6, &d7};
+    if (slot6 < 4) {
+      const int by = 2 * (int)m + (slot6 >> 1), bx = 2 * mx + (slot6 & 1);
+      dummy = by >= y_hb;  // block row below the image: the host copies the DC of the previous block
+      const int y = min(8 * by + line, Hi - 1) - row0;
+      const uint8_t* rowp = s_img + (dummy ? 0 : y) * 768 + 24 * bx;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        int sum = (c & 1) ? 2 : 1;  // jcsample.c h2v2_downsample bias 1,2,1,2 (8*mx is even)
+        const int R = rowp[3 * c], G = rowp[3 * c + 1], B = rowp[3 * c + 2];
+        *dd[c] = ((19595 * R + 38470 * G + 7471 * B + 32768) >> 16) - 128;
+      }
+    } else {
+      const bool is_cr = slot6 == 5;
+      const int crow = min(8 * (int)m + line, ch - 1);  // component rows below the image repeat the last real one
+      const uint8_t* r0 = s_img + (min(2 * crow, Hi - 1) - row0) * 768 + 48 * mx;
+      const uint8_t* r1 = s_img + (min(2 * crow + 1, Hi - 1) - row0) * 768 + 48 * mx;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int sum = (c & 1) ? 2 : 1;  // jcsample.c h2v2_downsample bias 1,2,1,2
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const uint8_t* p = ((k & 2) ? r1 : r0) + 3 * (2 * c + (k & 1));
@@ -1212,27 +1261,34 @@ __global__ __launch_bounds__(64) void k_jpeg_fdct(const uint8_t* __restrict__ im
           sum += is_cr ? ((32768 * R - 27439 * G - 5329 * B + (128 << 16) + 32767) >> 16)
                        : ((-11059 * R - 21709 * G + 32768 * B + (128 << 16) + 32767) >> 16);
         }
-        s[8 * r + c] = (sum >> 2) - 128;
+        *dd[c] = (sum >> 2) - 128;
       }
     }
+    jpeg_fdct_1d<true>(d0, d1, d2, d3, d4, d5, d6, d7);
+    int* wr = s_ws + (blk * 8 + line) * 9;
+    wr[0] = d0; wr[1] = d1; wr[2] = d2; wr[3] = d3; wr[4] = d4; wr[5] = d5; wr[6] = d6; wr[7] = d7;
   }
+  __syncthreads();
+  if (active) {  // column `line` of the block
+    int* col = s_ws + blk * 72 + line;
+    int d0 = col[0], d1 = col[9], d2 = col[18], d3 = col[27], d4 = col[36], d5 = col[45], d6 = col[54], d7 = col[63];
+    jpeg_fdct_1d<false>(d0, d1, d2, d3, d4, d5, d6, d7);
+    const int comp = slot6 < 4 ? 0 : 1;
+    const int dv[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
-    jpeg_fdct_1d<true>(s[8 * r], s[8 * r + 1], s[8 * r + 2], s[8 * r + 3], s[8 * r + 4], s[8 * r + 5], s[8 * r + 6], s[8 * r + 7]);
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    jpeg_fdct_1d<false>(s[c], s[8 + c], s[16 + c], s[24 + c], s[32 + c], s[40 + c], s[48 + c], s[56 + c]);
-  // quantise: (|v| + 4q) / 8q with the sign restored; the reciprocal is exact for these magnitudes
-  const int comp = slot < 4 ? 0 : 1;
-#pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    const int v = s[i];
-    const uint32_t a = (uint32_t)(v < 0 ? -v : v) + q.half[comp][i];
-    const int r = (int)(((uint64_t)a * q.magic[comp][i]) >> 32);
-    s[i] = v < 0 ? -r : r;
+    for (int r = 0; r < 8; ++r) {  // quantise: (|v| + 4q) / 8q with the sign restored; exact reciprocal
+      const int v = dv[r], i = 8 * r + line;
+      const uint32_t a = (uint32_t)(v < 0 ? -v : v) + jq.half[comp][i];
+      const int qv = (int)(((uint64_t)a * jq.magic[comp][i]) >> 32);
+      col[9 * r] = dummy ? 0 : (v < 0 ? -qv : qv);
+    }
   }
-#pragma unroll
-  for (int k = 0; k < 64; ++k) out[k] = (int16_t)s[zz[k]];
+  __syncthreads();
+  int16_t* out = coefs + (size_t)m * 16 * 6 * 64;
+  for (int k = threadIdx.x; k < 96 * 64; k += kFinThreads) {
+    const int b = k >> 6, nat = kZigzagDev[k & 63];
+    out[k] = (int16_t)s_ws[b * 72 + (nat >> 3) * 9 + (nat & 7)];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1285,17 +1341,11 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
                      a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ);
   PCC_STAMP("k_leaf_scan");
-  const uint32_t fin_blocks = (n + 256u + kBlock - 1) / kBlock;  // leaves + up to 256 padding pixels
-  hipLaunchKernelGGL(k_leaf_finalize, dim3(fin_blocks), dim3(kBlock), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state,
-                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
-                     reinterpret_cast<float4*>(a.simplified));
-  PCC_STAMP("k_leaf_finalize");
-  if (a.lp.write_image && a.coefs) {
-    const uint32_t max_h = n / 256u + 1u;
-    const uint32_t max_blocks = 16u * ((max_h + 15u) / 16u) * 6u;  // 8x8 blocks of the tallest possible image
-    hipLaunchKernelGGL(k_jpeg_fdct, dim3((max_blocks + 63u) / 64u), dim3(64), 0, stream, a.image, a.state, a.jq, a.coefs);
-    PCC_STAMP("k_jpeg_fdct");
-  }
+  const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
+  hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+                     a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
+                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs);
+  PCC_STAMP("k_leaf_tile");
 }
 
 }  // namespace pcc
