@@ -470,13 +470,14 @@ constexpr uint64_t kInvalidKey = ~0ull;
 
 #ifdef PCC_KTIME  // developer build only: phase time stamps of k_sort_pass (shader clock), read by tools/ktime.py
 __device__ unsigned long long g_ktime[kMaxPasses * 1024 * 8];
-#define PCC_KT(slot)                                                                                   \
+#define PCC_KTR(row, slot)                                                                             \
   do {                                                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ktime[((size_t)pass * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ktime[((size_t)(row) * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
   } while (0)
 #else
-#define PCC_KT(slot) do { } while (0)
+#define PCC_KTR(row, slot) do { } while (0)
 #endif
+#define PCC_KT(slot) PCC_KTR(pass, slot)
 
 __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
@@ -1032,6 +1033,7 @@ constexpr int kFinTile = kFinThreads * kFinRounds;     // 4096 leaf positions
 constexpr int kFinSlots = kFinTile / 64;               // (wave, round) slots of 64 consecutive leaves
 constexpr int kOccWindow = 8192;                       // dwords of the DFS stream collected in LDS
 constexpr int kMaskStride = kMaxDepth + 1;
+constexpr int kColourStage = 6144;                     // colour words staged in LDS per tile (1.5 points per leaf)
 
 __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double res, LeafParams lp,
                                                            const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
@@ -1042,6 +1044,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
                                                            uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
                                                            uint8_t* __restrict__ image, float4* __restrict__ simplified,
                                                            JpegQuant jq, int16_t* __restrict__ coefs) {
+  PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
   if (L == 0) return;
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
@@ -1058,7 +1061,10 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[3 * kFinTile];
   // phase A: s_base | s_occ | s_mask | s_t ; phase B: the FDCT workspace
   __shared__ __attribute__((aligned(16))) uint32_t s_scratch[kFinTile + kOccWindow + kFinSlots * kMaskStride * 2 + kFinTile / 4];
+  __shared__ uint32_t s_col[kColourStage];  // the tile's sorted colour words, loaded as one contiguous run
   __shared__ uint32_t s_pad;
+  __shared__ unsigned long long s_slotbits[kMaxDepth + 2];  // per level v: which slots hold a leaf with t >= v
+  __shared__ uint32_t s_far[kMaxDepth + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
   uint32_t* s_base = s_scratch;
   uint32_t* s_occ = s_scratch + kFinTile;
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
@@ -1077,6 +1083,8 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
+  if (threadIdx.x < kMaxDepth + 2) s_slotbits[threadIdx.x] = 0ull;
+  __syncthreads();
   int t[kFinRounds];
   uint32_t base[kFinRounds], ls[kFinRounds], le[kFinRounds];
   uint64_t code[kFinRounds];
@@ -1093,16 +1101,51 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     s_base[lj] = base[r];
     for (int v = 1; v <= D; ++v) {
       const uint64_t mk = __ballot(is_leaf && t[r] >= v);
-      if (lane == 0) s_mask[slot * kMaskStride + v] = mk;
+      if (lane == 0) {
+        s_mask[slot * kMaskStride + v] = mk;
+        if (mk) atomicOr(&s_slotbits[v], 1ull << slot);
+      }
     }
   }
   for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
+  // the points of this tile's leaves are one contiguous run of the sorted arrays: stage their colour words
+  const uint32_t run0 = nl ? leaf_start[pos0] : 0u;
+  const uint32_t run1 = nl ? leaf_start[pos0 + nl] : 0u;
+  const bool staged = colour_pay != nullptr && lp.do_color;
+  if (staged)
+    for (uint32_t k = threadIdx.x; k < min(run1 - run0, (uint32_t)kColourStage); k += kFinThreads) s_col[k] = colour_pay[run0 + k];
+  // Parents that were opened before this tile: for every v the nearest earlier leaf f with t(f) >= v is
+  // the first leaf of the level-(D-v) ancestor of the tile's first leaf, i.e. lower_bound over the sorted
+  // leaf codes.  One wave per level, 64 probes per step (4 steps for a million leaves).
+  if (nl && pos0) {
+    const uint64_t code0 = leaf_code[pos0];
+    for (int v = wave + 1; v <= D; v += kFinThreads / 64) {
+      const int sh = 3 * v;
+      const uint64_t pcode = sh >= 64 ? 0ull : ((code0 >> sh) << sh);
+      uint32_t lo = 0, hi = pos0;
+      while (hi > lo) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t probe = lo + (uint32_t)lane * step;
+        const bool less = probe < hi && leaf_code[probe] < pcode;
+        const int cnt = __popcll(__ballot(less));  // the probes are ascending, so `less` holds for a prefix of the lanes
+        if (cnt == 0) {
+          hi = lo;
+        } else {
+          const uint32_t nlo = lo + (uint32_t)(cnt - 1) * step + 1u;
+          hi = min(lo + (uint32_t)cnt * step, hi);
+          lo = nlo;
+        }
+      }
+      if (lane == 0) s_far[v] = leaf_base[lo] + (uint32_t)leaf_t[lo] - (uint32_t)v;
+    }
+  }
   if (threadIdx.x == 0 && lp.write_image && nl < npos) {  // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
     uint32_t b, g, r;
     leaf_colour(pv, index_of, colour_pay, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
     s_pad = b | (g << 8) | (r << 16);
   }
   __syncthreads();
+  PCC_KTR(5, 1);
   const uint32_t seg0 = nl ? (s_base[0] & ~3u) : 0u;  // dword-aligned start of the tile's piece of the DFS stream
   const uint32_t seg1 = nl ? s_base[nl - 1] + s_t[nl - 1] : 0u;
   const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
@@ -1122,13 +1165,25 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     const uint32_t key[3] = {compact3(fullcode >> 2), compact3(fullcode >> 1), compact3(fullcode)};
     uint32_t cb = 0, cg = 0, cr = 0;
     if (lp.do_color) {
-      leaf_colour(pv, index_of, colour_pay, ls[r], le[r], lp.color_reduction, cb, cg, cr);
+      if (staged && le[r] - run0 <= (uint32_t)kColourStage) {  // the usual case: sum straight out of LDS
+        uint32_t s0 = 0, s1 = 0, s2 = 0;
+        for (uint32_t i = ls[r] - run0; i < le[r] - run0; ++i) {
+          const uint32_t w = s_col[i];
+          s0 += w & 0xffu; s1 += (w >> 8) & 0xffu; s2 += (w >> 16) & 0xffu;
+        }
+        const uint32_t cnt = le[r] - ls[r];
+        if (cnt > 1) { s0 /= cnt; s1 /= cnt; s2 /= cnt; }
+        cb = (s0 >> lp.color_reduction) & 0xffu; cg = (s1 >> lp.color_reduction) & 0xffu; cr = (s2 >> lp.color_reduction) & 0xffu;
+      } else {
+        leaf_colour(pv, index_of, colour_pay, ls[r], le[r], lp.color_reduction, cb, cg, cr);
+      }
       s_bgr[3 * lj] = (uint8_t)cb; s_bgr[3 * lj + 1] = (uint8_t)cg; s_bgr[3 * lj + 2] = (uint8_t)cr;
       if (lp.write_image) {
         const uint32_t px = snake_pos(j, W, H) - 16u * m * W;
         s_img[3 * px] = (uint8_t)cb; s_img[3 * px + 1] = (uint8_t)cg; s_img[3 * px + 2] = (uint8_t)cr;
       }
     }
+    if (r == 0) PCC_KTR(5, 2);
     // lower voxel corner (impl.hpp:1519-1521), then centre (impl.hpp:1560-1562) or centroid (:1566-1573)
     double lc[3];
 #pragma unroll
@@ -1159,6 +1214,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       simplified[j] = make_float4(c[0], c[1], c[2], __uint_as_float(rgba));
     }
 
+    if (r == 0) PCC_KTR(5, 3);
     // occupancy: the t(j) branch nodes this leaf opens sit at base(j).. in the stream; each gets the
     // child bit on this leaf's path.  The topmost one is itself a new child of an older node: the node
     // opened by the nearest earlier leaf f with t(f) > t(j) (ballot masks inside the tile, binary
@@ -1178,31 +1234,28 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       uint64_t mk = s_mask[slot * kMaskStride + v] & (lane ? (~0ull >> (64 - lane)) : 0ull);
       if (mk) {
         fl = (int)slot * 64 + 63 - __clzll((long long)mk);
-      } else {
-        for (int sl = (int)slot - 1; sl >= 0; --sl) {
+      } else {  // the nearest earlier slot that holds such a leaf, if any
+        const uint64_t sb = s_slotbits[v] & (slot ? (~0ull >> (64 - slot)) : 0ull);
+        if (sb) {
+          const int sl = 63 - __clzll((long long)sb);
           mk = s_mask[sl * kMaskStride + v];
-          if (mk) { fl = sl * 64 + 63 - __clzll((long long)mk); break; }
+          fl = sl * 64 + 63 - __clzll((long long)mk);
         }
       }
       uint32_t off;
       if (fl >= 0) {
         off = s_base[fl] + (uint32_t)((D - tt - 1) - (D - (int)s_t[fl]));
       } else {
-        const int sh = 3 * (tt + 1);
-        const uint64_t pcode = sh >= 64 ? 0ull : ((code[r] >> sh) << sh);
-        uint32_t lo = 0, hi = pos0;  // first leaf f before this tile with leaf_code[f] >= pcode
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (leaf_code[mid] < pcode) lo = mid + 1; else hi = mid;
-        }
-        off = leaf_base[lo] + (uint32_t)((D - tt - 1) - (D - (int)leaf_t[lo]));
+        off = s_far[v];  // opened before this tile
       }
       const uint32_t rel = off - seg0;
       if (off >= seg0 && (rel >> 2) < (uint32_t)kOccWindow) atomicOr(&s_occ[rel >> 2], (1u << child) << (8u * (rel & 3u)));
       else or_byte(occ, off, 1u << child);
     }
+    if (r == 0) PCC_KTR(5, 4);
   }
   __syncthreads();
+  PCC_KTR(5, 5);
 
   // ---- A3: contiguous writes: DFS stream piece, bgr, image rows ----
   if (seg1 > seg0) {
@@ -1240,24 +1293,37 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       const int by = 2 * (int)m + (slot6 >> 1), bx = 2 * mx + (slot6 & 1);
       dummy = by >= y_hb;  // block row below the image: the host copies the DC of the previous block
       const int y = min(8 * by + line, Hi - 1) - row0;
-      const uint8_t* rowp = s_img + (dummy ? 0 : y) * 768 + 24 * bx;
+      // 8 pixels = 24 bytes = 6 aligned dwords of the window row
+      const uint32_t* rowp = reinterpret_cast<const uint32_t*>(s_img + (dummy ? 0 : y) * 768 + 24 * bx);
+      uint32_t w[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] = rowp[k];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const int R = rowp[3 * c], G = rowp[3 * c + 1], B = rowp[3 * c + 2];
+        const int R = (w[(3 * c) >> 2] >> (8 * ((3 * c) & 3))) & 0xff;
+        const int G = (w[(3 * c + 1) >> 2] >> (8 * ((3 * c + 1) & 3))) & 0xff;
+        const int B = (w[(3 * c + 2) >> 2] >> (8 * ((3 * c + 2) & 3))) & 0xff;
         *dd[c] = ((19595 * R + 38470 * G + 7471 * B + 32768) >> 16) - 128;
       }
     } else {
       const bool is_cr = slot6 == 5;
       const int crow = min(8 * (int)m + line, ch - 1);  // component rows below the image repeat the last real one
-      const uint8_t* r0 = s_img + (min(2 * crow, Hi - 1) - row0) * 768 + 48 * mx;
-      const uint8_t* r1 = s_img + (min(2 * crow + 1, Hi - 1) - row0) * 768 + 48 * mx;
+      // 16 pixels = 48 bytes = 12 aligned dwords of each of the two window rows
+      const uint32_t* r0 = reinterpret_cast<const uint32_t*>(s_img + (min(2 * crow, Hi - 1) - row0) * 768 + 48 * mx);
+      const uint32_t* r1 = reinterpret_cast<const uint32_t*>(s_img + (min(2 * crow + 1, Hi - 1) - row0) * 768 + 48 * mx);
+      uint32_t w0[12], w1[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { w0[k] = r0[k]; w1[k] = r1[k]; }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         int sum = (c & 1) ? 2 : 1;  // jcsample.c h2v2_downsample bias 1,2,1,2
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint8_t* p = ((k & 2) ? r1 : r0) + 3 * (2 * c + (k & 1));
-          const int R = p[0], G = p[1], B = p[2];
+          const uint32_t* ww = (k & 2) ? w1 : w0;
+          const int o = 3 * (2 * c + (k & 1));
+          const int R = (ww[o >> 2] >> (8 * (o & 3))) & 0xff;
+          const int G = (ww[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 0xff;
+          const int B = (ww[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 0xff;
           sum += is_cr ? ((32768 * R - 27439 * G - 5329 * B + (128 << 16) + 32767) >> 16)
                        : ((-11059 * R - 21709 * G + 32768 * B + (128 << 16) + 32767) >> 16);
         }
@@ -1289,6 +1355,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     const int b = k >> 6, nat = kZigzagDev[k & 63];
     out[k] = (int16_t)s_ws[b * 72 + (nat >> 3) * 9 + (nat & 7)];
   }
+  PCC_KTR(5, 6);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,4 +21,8 @@ for ps in range(4):
     rel = (x - t0) / 100.0
     print("pass %d: stamps (median us): start %.2f tile %.2f ranked %.2f scanned %.2f | prewait1 %.2f partial %.2f prewait2 %.2f lookback-done %.2f" % ((ps,) + tuple(np.median(rel, axis=0))))
     print("        stamps (max us):", np.round(rel.max(axis=0), 2))
+x = t[5, :231, :7]
+rel = (x - x[:, 0].min()) / 100.0
+print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end:", np.round(np.median(rel, axis=0), 2))
+print("            stamps (max us):", np.round(rel.max(axis=0), 2))
 ctx.close()
