@@ -224,8 +224,9 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
                                                         FrameState* __restrict__ st) {
   __shared__ float s_p[3][kTile];
   __shared__ int s_red;
+  __shared__ int s_red2[2][kBlock / 64];
   __shared__ double s_mn[3], s_mx[3];
-  __shared__ int s_depth, s_nev, s_err;
+  __shared__ int s_depth;
   __shared__ int ev_index[kMaxEpochs], ev_lowered[kMaxEpochs], ev_depth_before[kMaxEpochs];
   __shared__ double ev_mn[kMaxEpochs][3];
   __shared__ float s_g[6][kBlock / 64];
@@ -289,119 +290,117 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     for (int a = 0; a < 3; ++a) { s_mn[a] = mn[a]; s_mx[a] = mx[a]; ev_mn[0][a] = mn[a]; }
     s_depth = depth;
     ev_index[0] = i0; ev_lowered[0] = 0; ev_depth_before[0] = 0;
-    s_nev = 1;
-    s_err = kErrNone;
   }
   __syncthreads();
 
   // ---- C: walk forward; only chunks whose AABB violates the current box are opened ----
-  int cur = i0 + 1;
-  int loaded = -1;
-  while (cur < (int)n) {
-    const double mn0 = s_mn[0], mn1 = s_mn[1], mn2 = s_mn[2];
-    const double mx0 = s_mx[0], mx1 = s_mx[1], mx2 = s_mx[2];
+  // Every thread keeps the same copy of the box in registers and replays the growth itself, so one
+  // growth event costs a single barrier (the one inside the block-wide minimum).
+  double mn[3] = {s_mn[0], s_mn[1], s_mn[2]}, mx[3] = {s_mx[0], s_mx[1], s_mx[2]};
+  int depth = s_depth, nev = 1, err = kErrNone;
+  int cur = i0 + 1, loaded = -1, parity = 0;
+  float px[kItems], py[kItems], pz[kItems];
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) px[k] = py[k] = pz[k] = __builtin_nanf("");
+  auto block_min1 = [&](int v) {  // one barrier; the result buffers alternate so that a fast wave cannot overwrite a pending read
+    v = wave_min_i(v);
+    if (lane_id() == 0) s_red2[parity][wave_id()] = v;
+    __syncthreads();
+    const int r = min(min(s_red2[parity][0], s_red2[parity][1]), min(s_red2[parity][2], s_red2[parity][3]));
+    parity ^= 1;
+    return r;
+  };
+  while (cur < (int)n && err == kErrNone) {
     const int c0 = cur / kTile;
-    int cmin;
-    if (c0 == loaded) {
-      cmin = loaded;  // keep draining the chunk that is already staged in LDS: no global access at all
-    } else {
+    if (c0 != loaded) {
       int cand = 0x7fffffff;
       for (int c = c0 + (int)threadIdx.x; c < (int)n_chunks; c += kBlock) {
         const ChunkBox b = boxes[c];
         if (b.n_finite > 0) {
-          const bool viol = ((double)b.mn[0] < mn0) | ((double)b.mn[1] < mn1) | ((double)b.mn[2] < mn2) |
-                            ((double)b.mx[0] >= mx0) | ((double)b.mx[1] >= mx1) | ((double)b.mx[2] >= mx2);
+          const bool viol = ((double)b.mn[0] < mn[0]) | ((double)b.mn[1] < mn[1]) | ((double)b.mn[2] < mn[2]) |
+                            ((double)b.mx[0] >= mx[0]) | ((double)b.mx[1] >= mx[1]) | ((double)b.mx[2] >= mx[2]);
           if (viol) { cand = c; break; }  // ascending per thread: the first hit is this thread's minimum
         }
       }
-      cmin = block_min_int(cand, &s_red);
+      const int cmin = block_min1(cand);
       if (cmin == 0x7fffffff) break;  // everything that is left fits
-    }
-    if (cmin != loaded) {
-      __syncthreads();
 #pragma unroll
       for (int k = 0; k < kItems; ++k) {
         const int e = k * kBlock + (int)threadIdx.x;
         const uint32_t i = (uint32_t)cmin * kTile + (uint32_t)e;
-        float x = __builtin_nanf(""), y = x, z = x;
+        float x = __builtin_nanf(""), y = x, z = x;  // NaN never violates: non-finite points are skipped
         if (i < n) {
           load_xyz(pv, i, x, y, z);
           if (!finite3(x, y, z)) { x = y = z = __builtin_nanf(""); }
         }
-        s_p[0][e] = x; s_p[1][e] = y; s_p[2][e] = z;
+        px[k] = x; py[k] = y; pz[k] = z;
+        s_p[0][e] = x; s_p[1][e] = y; s_p[2][e] = z;  // read back (by everybody) once the first violator is known
       }
       loaded = cmin;
-      __syncthreads();
     }
-    const int start_e = max(cur - cmin * kTile, 0);
+    const int start_e = max(cur - loaded * kTile, 0);
     int ce = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
       const int e = k * kBlock + (int)threadIdx.x;
-      if (e >= start_e && ce == 0x7fffffff) {
-        const double x = (double)s_p[0][e], y = (double)s_p[1][e], z = (double)s_p[2][e];
-        const bool viol = (x < mn0) | (y < mn1) | (z < mn2) | (x >= mx0) | (y >= mx1) | (z >= mx2);
-        if (viol) ce = e;
-      }
+      const double x = (double)px[k], y = (double)py[k], z = (double)pz[k];
+      const bool viol = (x < mn[0]) | (y < mn[1]) | (z < mn[2]) | (x >= mx[0]) | (y >= mx[1]) | (z >= mx[2]);
+      if (viol && e >= start_e && ce == 0x7fffffff) ce = e;
     }
-    const int emin = block_min_int(ce, &s_red);
-    if (emin == 0x7fffffff) {  // cannot happen for an exact AABB; stay safe
-      cur = (cmin + 1) * kTile;
+    const int emin = block_min1(ce);  // the barrier inside also orders the s_p writes above
+    if (emin == 0x7fffffff) {  // nothing (left) in this chunk: go on with the chunks behind it
+      cur = (loaded + 1) * kTile;
       continue;
     }
-    if (threadIdx.x == 0) {
-      // grow until the point fits (adoptBoundingBoxToPoint, bounding_box_defined_ branch)
-      const double p[3] = {(double)s_p[0][emin], (double)s_p[1][emin], (double)s_p[2][emin]};
-      double mn[3] = {s_mn[0], s_mn[1], s_mn[2]}, mx[3] = {s_mx[0], s_mx[1], s_mx[2]};
-      int depth = s_depth, nev = s_nev;
-      for (;;) {
-        bool lo[3], up[3], any = false;
-        for (int a = 0; a < 3; ++a) { lo[a] = p[a] < mn[a]; up[a] = p[a] >= mx[a]; any |= lo[a] | up[a]; }
-        if (!any) break;
-        if (nev >= kMaxEpochs || depth >= 31) { s_err = kErrEpochs; break; }
-        double side = __dmul_rn((double)(1u << depth), res);
-        int lowered = 0;
-        for (int a = 0; a < 3; ++a)
-          if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
+    // grow until the point fits (adoptBoundingBoxToPoint, bounding_box_defined_ branch)
+    const double p[3] = {(double)s_p[0][emin], (double)s_p[1][emin], (double)s_p[2][emin]};
+    for (;;) {
+      bool up[3], any = false;
+      for (int a = 0; a < 3; ++a) { up[a] = p[a] >= mx[a]; any |= (p[a] < mn[a]) | up[a]; }
+      if (!any) break;
+      if (nev >= kMaxEpochs || depth >= 31) { err = kErrEpochs; break; }
+      double side = __dmul_rn((double)(1u << depth), res);
+      int lowered = 0;
+      for (int a = 0; a < 3; ++a)
+        if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
+      if (threadIdx.x == 0) {
         ev_depth_before[nev] = depth;
-        ++depth;
-        side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
-        for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
-        ev_index[nev] = cmin * kTile + emin;
+        ev_index[nev] = loaded * kTile + emin;
         ev_lowered[nev] = lowered;
         for (int a = 0; a < 3; ++a) ev_mn[nev][a] = mn[a];
-        ++nev;
       }
-      for (int a = 0; a < 3; ++a) { s_mn[a] = mn[a]; s_mx[a] = mx[a]; }
-      s_depth = depth; s_nev = nev;
+      ++depth;
+      side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
+      for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
+      ++nev;
     }
-    __syncthreads();
-    if (s_err != kErrNone) break;
-    cur = cmin * kTile + emin + 1;
+    cur = loaded * kTile + emin + 1;
   }
-  __syncthreads();
 
   // ---- D: epoch table, sort geometry ----
   if (threadIdx.x == 0) {
-    const int nev = s_nev, depth = s_depth;
+    // an epoch = a run of point indices with one box origin; the key offset of an epoch is the sum of the
+    // re-rootings that came after it: walk the events backwards with a running sum
     int ne = 0;
-    for (int k = 0; k < nev; ++k) {
-      if (k + 1 < nev && ev_index[k + 1] == ev_index[k]) continue;  // same point grew the box again
-      unsigned shift[3] = {0, 0, 0};
-      for (int j = k + 1; j < nev; ++j)
-        for (int a = 0; a < 3; ++a)
-          if (ev_lowered[j] & (1 << a)) shift[a] += 1u << ev_depth_before[j];
-      st->ep_index[ne] = ev_index[k];
-      for (int a = 0; a < 3; ++a) { st->ep_mn[ne][a] = ev_mn[k][a]; st->ep_shift[ne][a] = shift[a]; }
-      ++ne;
+    for (int k = 0; k < nev; ++k)
+      if (!(k + 1 < nev && ev_index[k + 1] == ev_index[k])) ++ne;  // the same point may grow the box several times
+    unsigned shift[3] = {0, 0, 0};
+    int w = ne;
+    for (int k = nev - 1; k >= 0; --k) {
+      if (!(k + 1 < nev && ev_index[k + 1] == ev_index[k])) {
+        --w;
+        st->ep_index[w] = ev_index[k];
+        for (int a = 0; a < 3; ++a) { st->ep_mn[w][a] = ev_mn[k][a]; st->ep_shift[w][a] = shift[a]; }
+      }
+      for (int a = 0; a < 3; ++a)
+        if (ev_lowered[k] & (1 << a)) shift[a] += 1u << ev_depth_before[k];
     }
     st->n_epochs = ne;
     st->n_growth_events = nev - 1;
     st->depth = depth;
     st->first_finite = i0;
     st->n_finite = s_nfin;
-    for (int a = 0; a < 3; ++a) { st->mn[a] = s_mn[a]; st->mx[a] = s_mx[a]; }
-    int err = s_err;
+    for (int a = 0; a < 3; ++a) { st->mn[a] = mn[a]; st->mx[a] = mx[a]; s_mn[a] = mn[a]; }
     if (depth > kMaxDepth) err = kErrDepth;
 
     // varying key bits from the global AABB under the final origin, +-1 voxel of slack
