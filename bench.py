@@ -2,11 +2,11 @@
 """Headline benchmark: encoded Mpoints/s for 1M-point XYZRGB frames, octree depth 10, intra-only.
 
 A "step" is one complete encodePointCloud-equivalent of one frame whose points already sit in
-HBM: GPU hot path (bounding box, keys, sort, leaves, occupancy stream, colour image), device->host
-hand-over, then the host entropy stage (JPEG + static range coder) down to the final bitstream.
-Frames of the GOP are sharded one per GPU (rank r takes frames r, r+N, ...) with no collective on
-the data path; inside a rank, `workers` host threads each own one pcc_ctx so that the serial host
-stage of one frame overlaps the GPU stage of the next.
+HBM: GPU hot path (bounding box, keys, sort, leaves, occupancy stream, colour image + JPEG front
+end), device->host hand-over, then the host entropy stage (JPEG Huffman + static range coder) down
+to the final bitstream.  Frames of the GOP are sharded one per GPU (rank r takes frames r, r+N, ...)
+with no collective on the data path; inside a rank the native pipeline (pcc_pipeline, C++ threads,
+one pcc_ctx each) overlaps the serial host stage of one frame with the GPU stage of the others.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -19,9 +19,7 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -34,32 +32,32 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="cfg2", help="cfg2 (headline), cfg2u, cfg1, cfg4")
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="cfg2", help="cfg2 (headline), cfg2u, cfg1, cfg3, cfg4")
     ap.add_argument("--workers", type=int, default=0, help="host threads (= contexts) per GPU; 0 = auto")
     ap.add_argument("--distinct-frames", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline sample (0 = auto)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
+                    help="per-kernel HBM bytes per launch from a separate rocprofv3 --pmc run (tools/pmc_traffic.py)")
     return ap.parse_args()
 
 
 # must-move bytes of each kernel per launch, as a function of the frame ("Kernels")
-def kernel_algorithmic_bytes(name, n, L, B, stride, with_color, image_bytes):
+def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
+    pay = 4 if with_color else 0           # the colour word rides through the sort as payload
     if name == "k_chunk_boxes":
         return 16 * n                      # x,y,z(,w) of every point
     if name == "k_make_keys":
-        return 16 * n + 8 * n              # read xyz, write one packed key
-    if name == "k_radix_hist":
-        return 8 * n
-    if name == "k_radix_scatter":
-        return 16 * n                      # read key, write key
-    if name == "k_leaf_partials":
-        return 8 * n
-    if name == "k_leaf_emit":
-        return 8 * n + 17 * L              # read keys; write start, code, base, t per leaf
-    if name == "k_leaf_finalize":
-        return (4 * n if with_color else 0) + 8 * n + 17 * L + (3 * L + image_bytes if with_color else 0) + 16 * L + B
+        return (16 + pay) * n + (8 + pay) * n   # read xyz (+ colour word), write key (+ payload)
+    if name == "k_sort_pass":
+        return 2 * (8 + pay) * n           # read key + payload, write key + payload
+    if name == "k_leaf_scan":
+        return 8 * n + 17 * L + B          # read keys; write start, code, base, t per leaf; zero the DFS stream
+    if name == "k_leaf_tile":
+        coefs = image_bytes                # 1.5 int16 coefficients per pixel = 3 bytes per pixel
+        return 17 * L + pay * n + (3 * L + coefs if with_color else 0) + 16 * L + B
     return 0
 
 
@@ -86,102 +84,105 @@ def main():
     b, syn = pkg.binding, pkg.synthetic
 
     cfg = syn.CONFIGS[args.workload]
-    params = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"],
-                           color_coding_type=cfg["color_coding_type"], jpeg_quality=cfg["jpeg_quality"],
-                           keep_centroid=cfg["keep_centroid"])
+    kw = dict(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
+              jpeg_quality=cfg["jpeg_quality"], keep_centroid=cfg["keep_centroid"])
+    params = b.make_params(frame_id=1, **kw)
     n_points = cfg["n"]
-    workers = args.workers or max(1, min(16, (os.cpu_count() or 8) // max(world, 1)))
+    workers = args.workers or max(1, min(24, (os.cpu_count() or 8) // max(world, 1)))
 
     # ---- frames of this rank, resident in HBM before the clock starts ----
-    ctxs = [b.Context(local_rank) for _ in range(workers)]
+    pipe = b.Pipeline(local_rank, workers)
+    ctx0 = pipe.context(0)
+    for w in range(pipe.workers):
+        pipe.context(w).set_option("copy_image", 0)  # the host stage only needs the quantised JPEG coefficients
     n_distinct = max(1, args.distinct_frames)
     host_frames = [syn.make_frame(args.workload, frame=rank * n_distinct + f) for f in range(n_distinct)]
-    dev_frames = [ctxs[0].upload(f) for f in host_frames]
-    for c in ctxs:
-        c.set_profiling(True)
-        c.set_option("copy_image", 0)   # the host stage only needs the quantised JPEG coefficients
-
-    lock = threading.Lock()
-    ktimes = {}     # kernel name -> [sum ms, launches]
-    stats = {}
-    tls = threading.local()
-    ctx_pool = list(ctxs)
-
-    def encode(step, record):
-        c = getattr(tls, "ctx", None)
-        if c is None:
-            with lock:
-                c = tls.ctx = ctx_pool.pop()
-        f = step % n_distinct
-        p = b.Params.from_buffer_copy(params)
-        p.frame_id = step + 1
-        c.hotpath_launch(dev_frames[f], n_points, p)
-        hot = c.hotpath_finish(copy=False)
-        nbytes, perf = c.entropy_encode(hot.raw, p, copy=False)
-        if record:
-            kt = c.kernel_times()
-            with lock:
-                for name, ms in kt:
-                    e = ktimes.setdefault(name, [0.0, 0])
-                    e[0] += ms
-                    e[1] += 1
-                stats.setdefault("gpu_ms", []).append(hot.gpu_ms)
-                stats[f] = (hot.n_leaves, hot.n_branches, hot.depth, nbytes, hot.image_w * hot.image_h * 3)
-        return nbytes
+    dev_frames = [ctx0.upload(f) for f in host_frames]
 
     def sync_all():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    pool = ThreadPoolExecutor(max_workers=workers)
-    list(pool.map(lambda s: encode(s, False), range(max(args.warmup, workers))))  # also binds one ctx per thread
+    # one frame through a plain context call: L, B, depth for the report (and a first warm-up)
+    ctx0.hotpath_launch(dev_frames[0], n_points, params)
+    hot0 = ctx0.hotpath_finish(copy=False)
+    L, B, depth = hot0.n_leaves, hot0.n_branches, hot0.depth
+    image_bytes = hot0.image_w * hot0.image_h * 3
 
+    warm = max(args.warmup, pipe.workers)
+    pipe.encode([dev_frames[s % n_distinct] for s in range(warm)], [n_points] * warm, params, copy=False)
+
+    # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
+    # without taxing every stream
+    ctx0.set_profiling(True)
+    seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
     sync_all()
     t0 = time.perf_counter()
-    sizes = list(pool.map(lambda s: encode(s, True), range(args.steps)))
+    res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    stats = pipe.stats()
+    ktimes, profiled = pipe.kernel_times()
+    ctx0.set_profiling(False)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    pool.shutdown()
+    nbytes = res[0][0]
+
+    # GPU side alone (kernels + device->host hand-over, no host entropy stage), same streams: the capacity
+    # the host stage has to keep up with
+    g_steps = max(4 * pipe.workers, 64)
+    gseq = [dev_frames[s % n_distinct] for s in range(g_steps)]
+    pipe.gpu_stage_only(gseq[:pipe.workers], [n_points] * pipe.workers, params)
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    pipe.gpu_stage_only(gseq, [n_points] * g_steps, params)
+    gpu_only_fps = g_steps / (time.perf_counter() - tg)
 
     total_points = n_points * args.steps * world
     value = total_points / elapsed / 1e6
 
     # ---- roofline of the dominant kernel (HIP-event durations from inside the timed region) ----
-    L, B, depth, nbytes, image_bytes = stats[0]
-    per_kernel = {k: (v[0] / v[1], v[1]) for k, v in ktimes.items() if v[1]}
-    launches_per_frame = {k: v[1] / args.steps for k, v in ktimes.items()}
-    frame_ms = {k: per_kernel[k][0] * launches_per_frame[k] for k in per_kernel}
-    dominant = max(frame_ms, key=frame_ms.get)
-    dom_ms = per_kernel[dominant][0]
+    profiled = max(1, profiled)
+    per_kernel = {k: v[0] / v[1] for k, v in ktimes.items() if v[1] and not k.startswith("begin")}
+    launches_per_frame = {k: ktimes[k][1] / profiled for k in per_kernel}
+    frame_ms = {k: per_kernel[k] * launches_per_frame[k] for k in per_kernel}
     with_color = cfg["color_bits"] > 0
-    dom_bytes = kernel_algorithmic_bytes(dominant, n_points, L, B, 32, with_color, image_bytes)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    seq_ms = float(np.mean(stats["gpu_ms"]))
-    path_bytes = 32 * n_points + L * (3 if with_color else 0) + B + 16 * L  # SURVEY.md 8(d), with output_ cloud
-    roofline = {
-        "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-        "kernel_avg_ms": round(dom_ms, 5), "kernel_bytes_per_launch": int(dom_bytes),
-        "kernel_launches_per_frame": round(launches_per_frame[dominant], 2),
-        "path_bytes_per_frame": int(path_bytes), "path_gpu_ms": round(seq_ms, 4),
-        "path_achieved": round(path_bytes / (seq_ms * 1e-3) / 1e9, 2) if seq_ms > 0 else 0.0,
-        "path_frac": round(path_bytes / (seq_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if seq_ms > 0 else 0.0,
-    }
+    roofline = None
+    if frame_ms:
+        dominant = max(frame_ms, key=frame_ms.get)
+        dom_ms = per_kernel[dominant]
+        dom_bytes = kernel_algorithmic_bytes(dominant, n_points, L, B, with_color, image_bytes)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        seq_ms = float(sum(frame_ms.values()))  # kernel sequence of one frame (one stream among `workers`)
+        path_bytes = 32 * n_points + L * (3 if with_color else 0) + B + 16 * L  # SURVEY.md 8(d), with output_ cloud
+        traffic = None
+        try:
+            with open(args.traffic_json) as fh:
+                tj = json.load(fh)
+            if tj.get("workload") == args.workload:
+                traffic = tj.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+            "kernel_avg_ms": round(dom_ms, 5), "kernel_bytes_per_launch": int(dom_bytes),
+            "kernel_launches_per_frame": round(launches_per_frame[dominant], 2), "profiled_frames": profiled,
+            "path_bytes_per_frame": int(path_bytes), "path_gpu_ms": round(seq_ms, 4),
+            "path_achieved": round(path_bytes / (seq_ms * 1e-3) / 1e9, 2) if seq_ms > 0 else 0.0,
+            "path_frac": round(path_bytes / (seq_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if seq_ms > 0 else 0.0,
+        }
 
     # ---- CPU baseline: the pointer-octree oracle, single thread, bounded sample ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        po = O.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"],
-                           color_coding_type=cfg["color_coding_type"], jpeg_quality=cfg["jpeg_quality"],
-                           keep_centroid=cfg["keep_centroid"])
+        po = O.make_params(**kw)
         tw = time.perf_counter()
         O.encode_intra(host_frames[0], po, keep=False)          # warm-up + cost probe
         one = time.perf_counter() - tw
@@ -204,19 +205,26 @@ def main():
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 keys / u8 streams (fp64 key quantisation)", "data": "synthetic",
-            "config": {"workload": "%s: %d-point sphere-shell XYZRGB frame, octree_bits=%d, colour JPEG snake q%d, "
-                                   "intra-only" % (args.workload, n_points, cfg["octree_bits"], cfg["jpeg_quality"]),
-                       "frames_per_gpu": args.steps, "host_threads_per_gpu": workers, "L": int(L), "B": int(B),
+            "config": {"workload": "%s: %d-point %s XYZRGB frame, octree_bits=%d, %s, intra-only" %
+                                   (args.workload, n_points, "sphere-shell" if cfg["gen"] == "sphere" else "uniform-volume",
+                                    cfg["octree_bits"],
+                                    "colour JPEG snake q%d" % cfg["jpeg_quality"] if with_color else "geometry only"),
+                       "frames_per_gpu": args.steps, "host_threads_per_gpu": pipe.workers, "L": int(L), "B": int(B),
                        "depth": int(depth), "bitstream_bytes": int(nbytes),
                        "sharding": "frame f -> gpu f mod N, no collectives"},
-            "gpu_hot_path_mpoints_per_s": round(n_points / (seq_ms * 1e-3) / 1e6, 1) if seq_ms > 0 else None,
+            "gpu_only_mpoints_per_s": round(gpu_only_fps * n_points / 1e6, 1),
+            "host_ms_per_frame": {"launch_call": round(stats["launch_us"] / 1e3, 3),
+                                  "finish_call": round(stats["finish_us"] / 1e3, 3),
+                                  "entropy_call": round(stats["entropy_us"] / 1e3, 3),
+                                  "occupancy_range_coder": round(stats["occupancy_coder_us"] / 1e3, 3),
+                                  "jpeg_huffman": round(stats["jpeg_us"] / 1e3, 3),
+                                  "colour_range_coder": round(stats["colour_coder_us"] / 1e3, 3)},
             "roofline": roofline,
             "kernels_ms_per_frame": {k: round(v, 5) for k, v in sorted(frame_ms.items(), key=lambda kv: -kv[1])},
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    for c in ctxs:
-        c.close()
+    pipe.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -29,8 +29,12 @@ EXPORTS = [
     "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_entropy_encode", "pcc_get_output_cloud", "pcc_decode_intra",
-    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_set_profiling",
+    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_host_times",
+    "pcc_set_profiling",
     "pcc_set_option",
+    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_context",
+    "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_kernel_times",
+    "pcc_pipeline_last_error",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
 ]
@@ -59,6 +63,7 @@ class HotResult(C.Structure):
         ("n_points_in", C.c_uint64), ("n_leaves", C.c_uint64), ("n_branches", C.c_uint64),
         ("occupancy", C.c_void_p), ("bgr", C.c_void_p), ("centroid", C.c_void_p), ("image", C.c_void_p),
         ("image_w", C.c_uint32), ("image_h", C.c_uint32), ("gpu_ms", C.c_float), ("jpeg_coefs", C.c_void_p),
+        ("jpeg_tiles", C.c_void_p), ("jpeg_tile_words", C.c_uint32), ("jpeg_n_tiles", C.c_uint32),
     ]
 
 
@@ -107,8 +112,22 @@ def load_library():
     lib.pcc_device_free.argtypes = [vp, vp]
     lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
     lib.pcc_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+    lib.pcc_get_host_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_set_profiling.argtypes = [vp, i32]
     lib.pcc_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.pcc_pipeline_create.restype = vp
+    lib.pcc_pipeline_create.argtypes = [i32, i32]
+    lib.pcc_pipeline_destroy.argtypes = [vp]
+    lib.pcc_pipeline_destroy.restype = None
+    lib.pcc_pipeline_workers.argtypes = [vp]
+    lib.pcc_pipeline_context.restype = vp
+    lib.pcc_pipeline_context.argtypes = [vp, i32]
+    lib.pcc_pipeline_encode.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_pipeline_gpu_stage_only.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params)]
+    lib.pcc_pipeline_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.pcc_pipeline_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.pcc_pipeline_last_error.restype = C.c_char_p
+    lib.pcc_pipeline_last_error.argtypes = [vp]
     lib.pcc_host_range_encode.restype = sz
     lib.pcc_host_range_encode.argtypes = [vp, sz, vp, sz]
     lib.pcc_host_range_decode.restype = sz
@@ -260,10 +279,88 @@ class Context:
     def set_profiling(self, on):
         self._check(self.lib.pcc_set_profiling(self.h, 1 if on else 0))
 
+    def host_times(self):
+        """(occupancy coder, JPEG, colour coder, whole stage) of the last entropy_encode, microseconds."""
+        buf = (C.c_double * 4)()
+        self._check(self.lib.pcc_get_host_times(self.h, buf))
+        return tuple(buf)
+
     def kernel_times(self):
         kt = KernelTimes()
         self._check(self.lib.pcc_get_kernel_times(self.h, C.byref(kt)))
         return [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
+
+
+class _BorrowedContext(Context):
+    """A pcc_ctx owned by a pipeline (never destroyed from here)."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.h, self._dev_allocs = lib, handle, []
+
+    def close(self):
+        self.h = None
+
+
+class Pipeline:
+    """pcc_pipeline: `workers` host threads + contexts on one GPU encoding a sequence of frames."""
+
+    def __init__(self, device=0, workers=8):
+        self.lib = load_library()
+        self.h = self.lib.pcc_pipeline_create(device, workers)
+        if not self.h:
+            raise RuntimeError("pcc_pipeline_create(%r) failed: no usable MI355X/HIP device -- the hot path has no "
+                               "CPU fallback" % (device,))
+        self.workers = self.lib.pcc_pipeline_workers(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.pcc_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def context(self, worker):
+        return _BorrowedContext(self.lib, self.lib.pcc_pipeline_context(self.h, worker))
+
+    def _arrays(self, dev_frames, counts):
+        k = len(dev_frames)
+        fr = (C.c_void_p * k)(*[p.value if isinstance(p, C.c_void_p) else p for p in dev_frames])
+        cn = (C.c_size_t * k)(*counts)
+        return k, fr, cn
+
+    def encode(self, dev_frames, counts, params, stride=32, rgb_offset=16, copy=True):
+        """Frames f = 0.. get frame_id = params.frame_id + f.  Returns [(bytes or length, perf)] in frame order."""
+        k, fr, cn = self._arrays(dev_frames, counts)
+        out = (Bitstream * k)()
+        rc = self.lib.pcc_pipeline_encode(self.h, fr, cn, k, stride, rgb_offset, C.byref(params), out)
+        if rc != PCC_OK:
+            raise PccError(rc, self.lib.pcc_pipeline_last_error(self.h).decode())
+        return [((_bytes_at(b.data, b.len) if copy else b.len), [int(x) for x in b.perf]) for b in out]
+
+    def gpu_stage_only(self, dev_frames, counts, params, stride=32, rgb_offset=16):
+        k, fr, cn = self._arrays(dev_frames, counts)
+        rc = self.lib.pcc_pipeline_gpu_stage_only(self.h, fr, cn, k, stride, rgb_offset, C.byref(params))
+        if rc != PCC_OK:
+            raise PccError(rc, self.lib.pcc_pipeline_last_error(self.h).decode())
+
+    def kernel_times(self):
+        """{kernel name: (total ms, launches)} and the number of profiled frames of the last call."""
+        kt = KernelTimes()
+        launches = (C.c_int32 * 64)()
+        frames = C.c_int32()
+        self.lib.pcc_pipeline_kernel_times(self.h, C.byref(kt), launches, C.byref(frames))
+        return {kt.name[i].decode(): (float(kt.ms[i]), int(launches[i])) for i in range(kt.count)}, int(frames.value)
+
+    def stats(self):
+        buf = (C.c_double * 8)()
+        self.lib.pcc_pipeline_stats(self.h, buf)
+        keys = ("launch_us", "finish_us", "entropy_us", "occupancy_coder_us", "jpeg_us", "colour_coder_us",
+                "host_stage_us", "frames")
+        return dict(zip(keys, buf))
 
 
 MANUAL_CONFIGURATION = "MANUAL_CONFIGURATION"

@@ -66,6 +66,8 @@ struct pcc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_wait = nullptr;  // blocking-sync event: a host thread that waits for the GPU sleeps instead of
+                                 // spinning, so its core is free for the entropy stage of another frame
   std::string err;
   bool profiling = false;
   KernelTimer timer;
@@ -80,16 +82,22 @@ struct pcc_ctx {
   DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image, d_sync;
   DevBuf<float> d_simplified;  // 4 floats per leaf
   DevBuf<int16_t> d_coefs;     // JPEG coefficients of the snake image
+  DevBuf<uint32_t> d_jpeg_tiles;  // per-MCU-row Huffman records
+  DevBuf<JpegHuffTables> d_huff;
+  bool huff_uploaded = false;
 
   // host landing buffers
   PinnedBuf<FrameState> h_state;
   PinnedBuf<uint8_t> h_occ, h_bgr, h_centroid, h_image;
   PinnedBuf<float> h_simplified;
   PinnedBuf<int16_t> h_coefs;
-  bool jpeg_on_gpu = true, copy_image = true;
+  PinnedBuf<uint32_t> h_jpeg_tiles;
+  int jpeg_on_gpu = 2;  // 0 host JPEG, 1 coefficients from the GPU, 2 Huffman-coded MCU rows from the GPU
+  bool copy_image = true;
   std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
   std::vector<pcc_point_xyzrgb> dec_points;  // decodePointCloud()
   Bytes bitstream;
+  double host_us[4] = {0, 0, 0, 0};  // last entropy stage: occupancy coder, JPEG, colour coder, total
 
   // frame in flight
   HotPathArgs args{};          // what was enqueued (kept so that a frame that needs more sort passes can be re-run)
@@ -145,14 +153,29 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_image.ensure(3 * 256 * (n / 256 + 1) + 16));
   PCC_HIP(ctx->d_simplified.ensure(4 * n));
   PCC_HIP(ctx->d_coefs.ensure((size_t)16 * ((n / 256 + 1 + 15) / 16) * 6 * 64 + 64));
+  PCC_HIP(ctx->d_jpeg_tiles.ensure(((n / 256 + 1 + 15) / 16) * (size_t)kJpegTileWords));
+  PCC_HIP(ctx->d_huff.ensure(1));
+  if (!ctx->huff_uploaded) {
+    JpegHuffTables t;
+    BaselineJpeg::huffman_tables(t.dc, t.ac);
+    PCC_HIP(hipMemcpy(ctx->d_huff.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    ctx->huff_uploaded = true;
+  }
   PCC_HIP(ctx->h_state.ensure(1));
+  return PCC_OK;
+}
+
+// wait for everything enqueued on the context's stream so far, sleeping (not spinning) meanwhile
+int wait_stream(pcc_ctx* ctx) {
+  PCC_HIP(hipEventRecord(ctx->ev_wait, ctx->stream));
+  PCC_HIP(hipEventSynchronize(ctx->ev_wait));
   return PCC_OK;
 }
 
 // the kernel sequence of one frame + the FrameState read-back, all asynchronous on the context's stream
 int enqueue(pcc_ctx* ctx) {
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
-  if (ctx->profiling) ctx->timer.reset();
+  if (ctx->profiling) ctx->timer.reset(); else ctx->times.clear();
   launch_hot_path(ctx->args, ctx->stream, ctx->profiling ? &ctx->timer : nullptr);
   PCC_HIP(hipGetLastError());
   PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
@@ -173,7 +196,8 @@ pcc_ctx* pcc_create(int device) {
   pcc_ctx* c = new pcc_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
+      hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -198,10 +222,12 @@ void pcc_destroy(pcc_ctx* c) {
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
+  c->d_jpeg_tiles.release(); c->d_huff.release(); c->h_jpeg_tiles.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
   c->h_simplified.release();
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+  if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -216,7 +242,7 @@ int pcc_set_profiling(pcc_ctx* ctx, int enabled) {
 
 int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return PCC_ERR_ARG;
-  if (!strcmp(name, "jpeg_on_gpu")) ctx->jpeg_on_gpu = value != 0;
+  if (!strcmp(name, "jpeg_on_gpu")) ctx->jpeg_on_gpu = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "copy_image")) ctx->copy_image = value != 0;
   else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
@@ -229,6 +255,12 @@ int pcc_get_kernel_times(pcc_ctx* ctx, pcc_kernel_times* out) {
     out->name[i] = ctx->times[i].first;
     out->ms[i] = ctx->times[i].second;
   }
+  return PCC_OK;
+}
+
+int pcc_get_host_times(pcc_ctx* ctx, double out_us[4]) {
+  if (!ctx || !out_us) return PCC_ERR_ARG;
+  for (int i = 0; i < 4; ++i) out_us[i] = ctx->host_us[i];
   return PCC_OK;
 }
 
@@ -316,6 +348,8 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   }
   // the snake image itself only leaves the chip if somebody wants to look at it, or the host does the JPEG
   a.image = (a.lp.write_image && (ctx->copy_image || !a.coefs)) ? ctx->d_image.p : nullptr;
+  a.jpeg_tiles = (a.coefs && ctx->jpeg_on_gpu >= 2) ? ctx->d_jpeg_tiles.p : nullptr;
+  a.huff = ctx->d_huff.p;
   ctx->args = a;
   rc = enqueue(ctx);
   if (rc != PCC_OK) return rc;
@@ -331,14 +365,14 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   memset(out, 0, sizeof(*out));
   if (ctx->n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
   PCC_HIP(hipSetDevice(ctx->device));
-  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   const FrameState& st = *ctx->h_state.p;
   if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
     // deeper tree than the frames before: run the frame again with every pass enqueued
     ctx->args.max_passes = kMaxPasses;
     const int rc = enqueue(ctx);
     if (rc != PCC_OK) return rc;
-    PCC_HIP(hipStreamSynchronize(ctx->stream));
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   }
   if (st.n_epochs != 0 && st.error == kErrNone) ctx->pass_hint = st.npasses;
   float ms = 0.f;
@@ -365,14 +399,20 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     PCC_HIP(ctx->h_bgr.ensure(3 * L + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_bgr.p, ctx->d_bgr.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
   }
-  const bool coefs = image && ctx->jpeg_on_gpu;
+  const bool coefs = image && ctx->jpeg_on_gpu >= 1;
+  const bool tiles = image && ctx->jpeg_on_gpu >= 2;
   const bool want_image = image && (ctx->copy_image || !coefs);
   const size_t n_coefs = (size_t)16 * ((H + 15) / 16) * 6 * 64;
+  const size_t n_tiles = (H + 15) / 16;
   if (want_image) {
     PCC_HIP(ctx->h_image.ensure((size_t)3 * W * H + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_image.p, ctx->d_image.p, (size_t)3 * W * H, hipMemcpyDeviceToHost, ctx->stream));
   }
-  if (coefs) {
+  if (tiles) {  // the Huffman-coded MCU rows; the coefficients only follow if a row did not fit its record
+    PCC_HIP(ctx->h_jpeg_tiles.ensure(n_tiles * kJpegTileWords));
+    PCC_HIP(hipMemcpyAsync(ctx->h_jpeg_tiles.p, ctx->d_jpeg_tiles.p, n_tiles * kJpegTileWords * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, ctx->stream));
+  } else if (coefs) {
     PCC_HIP(ctx->h_coefs.ensure(n_coefs + 64));
     PCC_HIP(hipMemcpyAsync(ctx->h_coefs.p, ctx->d_coefs.p, n_coefs * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
   }
@@ -380,7 +420,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     PCC_HIP(ctx->h_centroid.ensure(3 * L + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_centroid.p, ctx->d_centroid.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
   }
-  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
 
   for (int a = 0; a < 3; ++a) { out->bbox[a] = st.mn[a]; out->bbox[3 + a] = st.mx[a]; }
   out->depth = (uint32_t)st.depth;
@@ -392,7 +432,20 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->bgr = want_bgr ? ctx->h_bgr.p : nullptr;
   out->centroid = prm.do_voxel_centroid ? ctx->h_centroid.p : nullptr;
   out->image = want_image ? ctx->h_image.p : nullptr;
-  out->jpeg_coefs = coefs ? ctx->h_coefs.p : nullptr;
+  bool tiles_ok = tiles;
+  if (tiles) {
+    for (size_t m = 0; m < n_tiles; ++m)
+      if (ctx->h_jpeg_tiles.p[m * kJpegTileWords + 3] != 0) tiles_ok = false;
+    if (!tiles_ok) {  // rare: a very busy image; fall back to the coefficients for this frame
+      PCC_HIP(ctx->h_coefs.ensure(n_coefs + 64));
+      PCC_HIP(hipMemcpyAsync(ctx->h_coefs.p, ctx->d_coefs.p, n_coefs * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
+      { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    }
+  }
+  out->jpeg_coefs = (coefs && !tiles_ok) ? ctx->h_coefs.p : nullptr;
+  out->jpeg_tiles = tiles_ok ? ctx->h_jpeg_tiles.p : nullptr;
+  out->jpeg_tile_words = kJpegTileWords;
+  out->jpeg_n_tiles = (uint32_t)n_tiles;
   out->image_w = image ? W : 0;
   out->image_h = image ? H : 0;
   ctx->last_L = L;
@@ -403,7 +456,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
 
 int pcc_entropy_encode(pcc_ctx* ctx, const pcc_hot_result* hot, const pcc_params* prm, pcc_bitstream* out) {
   if (!ctx || !hot || !prm || !out) return PCC_ERR_ARG;
-  entropy_encode_frame(*hot, *prm, ctx->bitstream, out->perf);
+  entropy_encode_frame(*hot, *prm, ctx->bitstream, out->perf, ctx->host_us);
   out->data = ctx->bitstream.data();
   out->len = ctx->bitstream.size();
   return PCC_OK;
@@ -442,7 +495,7 @@ int pcc_get_output_cloud(pcc_ctx* ctx, const pcc_point_xyzrgb** points, size_t* 
   const size_t L = ctx->last_L;
   PCC_HIP(ctx->h_simplified.ensure(4 * L + 4));
   PCC_HIP(hipMemcpyAsync(ctx->h_simplified.p, ctx->d_simplified.p, 16 * L, hipMemcpyDeviceToHost, ctx->stream));
-  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   ctx->out_cloud.resize(L);
   const bool color = ctx->params.do_color_encoding != 0;
   for (size_t i = 0; i < L; ++i) {  // a default-constructed PointXYZRGB with x,y,z,r,g,b overwritten (impl.hpp:1515,1554-1576)

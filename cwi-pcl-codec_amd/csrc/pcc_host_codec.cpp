@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 namespace pcc {
 
@@ -80,21 +81,34 @@ size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
     range = by_total.div(range);
     low += freq[ch] * range;
     range *= freq[ch + 1] - freq[ch];
-    if (pos + 8 > cap) {  // a symbol emits at most 4 bytes
+    if (pos + 16 > cap) {  // a symbol emits at most 4 bytes (+ 4 bytes of store slack)
       out.resize(start + cap * 2);
       p = out.data() + start;
       cap = out.size() - start;
     }
-    // emit while the top byte is settled, or the range underflowed (then it is clamped to the
-    // distance to the next 2^16 boundary: range = -int(low) & (bottom - 1))
-    for (;;) {
-      if ((low ^ (low + range)) >= kTop) {
-        if (range >= kBottom) break;
-        range = (0u - low) & (kBottom - 1);
+    // PCL's loop emits one byte per turn while the top byte is settled ((low ^ (low + range)) < 2^24).
+    // Shifting low and range left by 8 shifts that XOR by 8 as well, so the number of settled bytes is
+    // the number of leading zero BYTES of the XOR: emit them in one step, without a branch.
+    const uint32_t x = low ^ (low + range);
+    const unsigned k = x ? ((unsigned)__builtin_clz(x) >> 3) : 4u;
+    const uint32_t be = __builtin_bswap32(low);
+    memcpy(p + pos, &be, 4);  // only the first k bytes count
+    pos += k;
+    low = (uint32_t)((uint64_t)low << (8 * k));
+    range = (uint32_t)((uint64_t)range << (8 * k));
+    // rare: the range underflowed while the top byte is still open; then it is clamped to the distance to
+    // the next 2^16 boundary (range = -int(low) & (bottom - 1)) and the loop goes on as PCL writes it
+    if (__builtin_expect(range < kBottom, 0)) {
+      range = (0u - low) & (kBottom - 1);
+      for (;;) {
+        p[pos++] = (uint8_t)(low >> 24);
+        range <<= 8;
+        low <<= 8;
+        if ((low ^ (low + range)) >= kTop) {
+          if (range >= kBottom) break;
+          range = (0u - low) & (kBottom - 1);
+        }
       }
-      p[pos++] = (uint8_t)(low >> 24);
-      range <<= 8;
-      low <<= 8;
     }
   }
   for (int i = 0; i < 4; ++i) {
@@ -438,6 +452,60 @@ void BaselineJpeg::quantiser(int quality, uint16_t half[2][64], uint32_t magic[2
     half[0][i] = ql.half[i]; magic[0][i] = ql.magic[i];
     half[1][i] = qc.half[i]; magic[1][i] = qc.magic[i];
   }
+}
+
+void BaselineJpeg::huffman_tables(uint32_t dc[2][12], uint32_t ac[2][256]) {
+  static const HuffEnc dcl(kDcLuma), acl(kAcLuma), dcc(kDcChroma), acc(kAcChroma);
+  for (int i = 0; i < 12; ++i) {
+    dc[0][i] = ((uint32_t)dcl.len[i] << 16) | dcl.code[i];
+    dc[1][i] = ((uint32_t)dcc.len[i] << 16) | dcc.code[i];
+  }
+  for (int i = 0; i < 256; ++i) {
+    ac[0][i] = ((uint32_t)acl.len[i] << 16) | acl.code[i];
+    ac[1][i] = ((uint32_t)acc.len[i] << 16) | acc.code[i];
+  }
+}
+
+bool BaselineJpeg::encode_tiles(const uint32_t* tiles, uint32_t tile_words, uint32_t n_tiles, int w, int h, int quality,
+                                Bytes& out) {
+  for (uint32_t m = 0; m < n_tiles; ++m)
+    if (tiles[(size_t)m * tile_words + 3] != 0) return false;
+  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
+  static const HuffEnc dcl(kDcLuma), dcc(kDcChroma);
+  put_headers(out, w, h, ql, qc);
+  BitSink bs(out);
+  bs.start();
+  // bits [from, to) of a row's string (MSB first inside each u32), at most 24 at a time
+  auto append = [&](const uint32_t* words, uint32_t from, uint32_t to) {
+    uint32_t p = from;
+    while (p < to) {
+      const uint32_t off = p & 31u, take = std::min(std::min(to - p, 32u - off), 24u);
+      bs.put(words[p >> 5] >> (32u - off - take), (int)take);
+      p += take;
+    }
+  };
+  auto put_dc = [&](int diff, const HuffEnc& t) {  // jchuff.c encode_one_block, DC part
+    const int mag = diff < 0 ? -diff : diff, low = diff < 0 ? diff - 1 : diff;
+    const int nb = bit_length((uint32_t)mag);
+    bs.put(t.code[nb], t.len[nb]);
+    if (nb) bs.put((uint32_t)low, nb);
+  };
+  int last_dc[3] = {0, 0, 0};
+  for (uint32_t m = 0; m < n_tiles; ++m) {
+    const uint32_t* rec = tiles + (size_t)m * tile_words;
+    const uint32_t* bits = rec + 16;
+    const uint32_t total = rec[0], b1 = rec[1], b2 = rec[2];
+    put_dc((int)rec[4] - last_dc[0], dcl);
+    append(bits, 0, b1);
+    put_dc((int)rec[5] - last_dc[1], dcc);
+    append(bits, b1, b2);
+    put_dc((int)rec[6] - last_dc[2], dcc);
+    append(bits, b2, total);
+    last_dc[0] = (int)rec[7]; last_dc[1] = (int)rec[8]; last_dc[2] = (int)rec[9];
+  }
+  bs.flush();
+  be16(out, 0xFFD9);
+  return true;
 }
 
 void BaselineJpeg::encode_coefs(const int16_t* coefs, int w, int h, int quality, Bytes& out) {
@@ -817,7 +885,12 @@ const char kV2Id[] = "<PCL-OCT-CODECV2-COMPRESSED>";
 const char kV1Id[] = "<PCL-OCT-COMPRESSED>";
 }  // namespace
 
-void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3]) {
+void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3],
+                          double* times_us) {
+  typedef std::chrono::steady_clock Clock;
+  auto us_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::micro>(Clock::now() - t0).count(); };
+  const Clock::time_point t_begin = Clock::now();
+  double t_occ = 0, t_jpeg = 0, t_col = 0;
   out.clear();
   const bool with_color = prm.do_color_encoding != 0;
   const size_t L = (size_t)hot.n_leaves;
@@ -842,7 +915,9 @@ void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Byte
 
   // --- occupancy bytes ---
   put_le<uint64_t>(out, hot.n_branches);
+  Clock::time_point t0 = Clock::now();
   uint64_t point_len = StaticRangeCoder::encode(hot.occupancy, (size_t)hot.n_branches, out);
+  t_occ = us_since(t0);
   perf[0] = point_len;
   if (prm.do_voxel_centroid) {
     put_le<uint32_t>(out, (uint32_t)(3 * L));
@@ -854,8 +929,13 @@ void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Byte
     Bytes payload;
     const uint8_t* src = hot.bgr;
     size_t src_len = 3 * L;
+    t0 = Clock::now();
     if (prm.color_coding_type == 1) {  // one 256-wide snake-mapped image (jpegcc.h:187-226)
-      if (hot.jpeg_coefs)
+      if (hot.jpeg_tiles &&
+          BaselineJpeg::encode_tiles(hot.jpeg_tiles, hot.jpeg_tile_words, hot.jpeg_n_tiles, (int)hot.image_w, (int)hot.image_h,
+                                     prm.jpeg_quality, payload)) {
+        // stitched from the GPU's per-row bit strings
+      } else if (hot.jpeg_coefs)
         BaselineJpeg::encode_coefs(hot.jpeg_coefs, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
       else
         BaselineJpeg::encode_rgb(hot.image, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
@@ -877,9 +957,13 @@ void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Byte
       src = payload.data();
       src_len = payload.size();
     }
+    t_jpeg = us_since(t0);
     put_le<uint64_t>(out, (uint64_t)src_len);
+    t0 = Clock::now();
     perf[2] = StaticRangeCoder::encode(src, src_len, out);
+    t_col = us_since(t0);
   }
+  if (times_us) { times_us[0] = t_occ; times_us[1] = t_jpeg; times_us[2] = t_col; times_us[3] = us_since(t_begin); }
 }
 
 // =============================================================================================

@@ -31,6 +31,11 @@ class BaselineJpeg {
   // headers + Huffman coding only.  Blocks of dummy rows below the image carry zeros; their DC is
   // taken from the preceding block here (jccoefct.c).
   static void encode_coefs(const int16_t* coefs, int w, int h, int quality, Bytes& out);
+  // Same file from the per-MCU-row bit strings of the GPU Huffman stage (layout: pcc_hot_result.jpeg_tiles).
+  // Returns false if a row did not fit its record (then the caller Huffman-codes the coefficients instead).
+  static bool encode_tiles(const uint32_t* tiles, uint32_t tile_words, uint32_t n_tiles, int w, int h, int quality, Bytes& out);
+  // The Huffman tables of jpeg_set_defaults as (length << 16 | code): dc[component][size], ac[component][run << 4 | size]
+  static void huffman_tables(uint32_t dc[2][12], uint32_t ac[2][256]);
   // The quantiser the GPU front end needs for `quality` (natural order; see pcc_kernels.h JpegQuant)
   static void quantiser(int quality, uint16_t half[2][64], uint32_t magic[2][64]);
   static bool decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h);
@@ -40,7 +45,9 @@ class BaselineJpeg {
 uint32_t snake_position(uint32_t i, uint32_t w, uint32_t h);
 
 // writeFrameHeader + entropyEncoding (impl.hpp:1472-1486, 1682-1760)
-void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3]);
+// `times_us` (optional, 4 doubles): occupancy range coder, JPEG (Huffman or full), colour range coder, whole stage
+void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3],
+                          double* times_us = nullptr);
 
 // decodePointCloud (impl.hpp:224-310); returns PCC_OK or PCC_ERR_STREAM
 int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info);

@@ -33,6 +33,19 @@ struct JpegQuant {
   uint32_t magic[2][64];
 };
 
+// Per-MCU-row record of the GPU Huffman stage (u32 words; bits are MSB-first inside each word):
+//   [0] total bits   [1] bit offset of the first MCU's Cb block   [2] ... of its Cr block   [3] 1 = did not fit
+//   [4..6] DC of the first Y / Cb / Cr block of the row (their DC codes are left out: they depend on the row
+//   before and are inserted by the host)   [7..9] DC of the last Y / Cb / Cr block   [16..] the bits
+constexpr int kJpegTileWords = 512;
+constexpr int kJpegTileHeader = 16;
+constexpr int kJpegTileBits = (kJpegTileWords - kJpegTileHeader) * 32;
+// Huffman tables as (length << 16 | code): DC [component][size 0..11], AC [component][run << 4 | size]
+struct JpegHuffTables {
+  uint32_t dc[2][12];
+  uint32_t ac[2][256];
+};
+
 struct HotPathArgs {
   PointView pv;
   uint32_t n;
@@ -62,6 +75,8 @@ struct HotPathArgs {
   void* simplified;  // float4 per leaf (x, y, z, rgba bits)
   int16_t* coefs;    // quantised JPEG coefficients, 6 x 64 per MCU in zigzag order (null: JPEG on the host)
   JpegQuant jq;
+  uint32_t* jpeg_tiles;          // per-MCU-row Huffman records (null: Huffman coding on the host)
+  const JpegHuffTables* huff;    // device copy of the standard tables
 };
 
 // Optional per-kernel timing: one HIP event after every launch, on the launch stream.

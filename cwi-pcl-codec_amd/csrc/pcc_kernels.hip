@@ -150,6 +150,17 @@ __device__ __forceinline__ uint64_t poll_u64(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef PCC_KTIME  // developer build only: phase time stamps of k_sort_pass (shader clock), read by tools/ktime.py
+__device__ unsigned long long g_ktime[(7 + 2) * 1024 * 8];
+#define PCC_KTR(row, slot)                                                                             \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ktime[((size_t)(row) * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define PCC_KTR(row, slot) do { } while (0)
+#endif
+#define PCC_KT(slot) PCC_KTR(pass, slot)
+
 // ------------------------------------------------------------------------------------------
 // Stage 0: per-chunk bounding boxes (first read of the cloud: 16 of every 32 bytes per point)
 // ------------------------------------------------------------------------------------------
@@ -232,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
   __shared__ float s_g[6][kBlock / 64];
   __shared__ unsigned s_nfin;
 
+  PCC_KTR(6, 0);
   const double eps = (double)FLT_EPSILON;  // PCL: const float minValue = numeric_limits<float>::epsilon()
 
   // ---- A: first finite point, finite count, global AABB (from the chunk boxes) ----
@@ -266,6 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     return;
   }
 
+  PCC_KTR(6, 1);
   // ---- B: box from the first point (adoptBoundingBoxToPoint, empty-tree branch + getKeyBitSize) ----
   if (threadIdx.x == 0) {
     float p[3];
@@ -293,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
   }
   __syncthreads();
 
+  PCC_KTR(6, 2);
   // ---- C: walk forward; only chunks whose AABB violates the current box are opened ----
   // Every thread keeps the same copy of the box in registers and replays the growth itself, so one
   // growth event costs a single barrier (the one inside the block-wide minimum).
@@ -337,6 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
         s_p[0][e] = x; s_p[1][e] = y; s_p[2][e] = z;  // read back (by everybody) once the first violator is known
       }
       loaded = cmin;
+      PCC_KTR(6, 3);
     }
     const int start_e = max(cur - loaded * kTile, 0);
     int ce = 0x7fffffff;
@@ -377,6 +392,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     cur = loaded * kTile + emin + 1;
   }
 
+  PCC_KTR(6, 4);
   // ---- D: epoch table, sort geometry ----
   if (threadIdx.x == 0) {
     // an epoch = a run of point indices with one box origin; the key offset of an epoch is the sum of the
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     st->n_leaves = 0;
     st->n_branches = 0;
   }
+  PCC_KTR(6, 5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,16 +484,6 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
 // ------------------------------------------------------------------------------------------
 constexpr uint64_t kInvalidKey = ~0ull;
 
-#ifdef PCC_KTIME  // developer build only: phase time stamps of k_sort_pass (shader clock), read by tools/ktime.py
-__device__ unsigned long long g_ktime[kMaxPasses * 1024 * 8];
-#define PCC_KTR(row, slot)                                                                             \
-  do {                                                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ktime[((size_t)(row) * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
-  } while (0)
-#else
-#define PCC_KTR(row, slot) do { } while (0)
-#endif
-#define PCC_KT(slot) PCC_KTR(pass, slot)
 
 __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
@@ -1042,7 +1049,8 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
                                                            const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
                                                            uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
                                                            uint8_t* __restrict__ image, float4* __restrict__ simplified,
-                                                           JpegQuant jq, int16_t* __restrict__ coefs) {
+                                                           JpegQuant jq, int16_t* __restrict__ coefs,
+                                                           uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff) {
   PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
   if (L == 0) return;
@@ -1062,6 +1070,9 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   __shared__ __attribute__((aligned(16))) uint32_t s_scratch[kFinTile + kOccWindow + kFinSlots * kMaskStride * 2 + kFinTile / 4];
   __shared__ uint32_t s_col[kColourStage];  // the tile's sorted colour words, loaded as one contiguous run
   __shared__ uint32_t s_pad;
+  __shared__ uint32_t s_hbits[kJpegTileWords];  // header + Huffman bits of this MCU row
+  __shared__ uint32_t s_hdc[2 * 12], s_hac[2 * 256];
+  __shared__ uint32_t s_blen[96], s_boff[96];
   __shared__ unsigned long long s_slotbits[kMaxDepth + 2];  // per level v: which slots hold a leaf with t >= v
   __shared__ uint32_t s_far[kMaxDepth + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
   uint32_t* s_base = s_scratch;
@@ -1354,6 +1365,112 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     const int b = k >> 6, nat = kZigzagDev[k & 63];
     out[k] = (int16_t)s_ws[b * 72 + (nat >> 3) * 9 + (nat & 7)];
   }
+  if (!jpeg_tiles) return;
+
+  // ---- C: Huffman coding of the 96 blocks (jchuff.c encode_one_block), one wave per block, lane = zigzag
+  // index.  The row's bit string is assembled in LDS; the DC codes of the first Y, Cb and Cr block depend on
+  // the MCU row before and are left to the host, which stitches the rows together.
+  for (int k = threadIdx.x; k < kJpegTileWords; k += kFinThreads) s_hbits[k] = 0u;
+  for (int k = threadIdx.x; k < 24; k += kFinThreads) s_hdc[k] = (&huff->dc[0][0])[k];
+  for (int k = threadIdx.x; k < 512; k += kFinThreads) s_hac[k] = (&huff->ac[0][0])[k];
+  __syncthreads();
+  constexpr int kBlocksPerWave = 96 / (kFinThreads / 64);  // 6
+  uint64_t hb[kBlocksPerWave];
+  uint32_t hlen[kBlocksPerWave], ho[kBlocksPerWave];
+  // effective DC of a block: a dummy block below the image carries the DC of the block before its row (Y01)
+  auto eff_dc = [&](int b) {
+    const int bmx = b / 6, bs = b % 6;
+    const bool dmy = bs >= 2 && bs < 4 && (2 * (int)m + 1) >= y_hb;
+    return s_ws[(dmy ? bmx * 6 + 1 : b) * 72];
+  };
+#pragma unroll
+  for (int i = 0; i < kBlocksPerWave; ++i) {
+    const int b = wave + i * (kFinThreads / 64);
+    const int bmx = b / 6, bs = b % 6, comp = bs < 4 ? 0 : 1;
+    const bool dmy = bs >= 2 && bs < 4 && (2 * (int)m + 1) >= y_hb;
+    const int nat = kZigzagDev[lane];
+    const int v = (lane == 0 || dmy) ? 0 : s_ws[b * 72 + (nat >> 3) * 9 + (nat & 7)];
+    const uint64_t nzmask = __ballot(v != 0);
+    uint64_t bits = 0;
+    uint32_t len = 0;
+    if (lane == 0) {
+      const bool first_of_chain = bmx == 0 && (bs == 0 || bs >= 4);
+      if (!first_of_chain) {
+        const int pb = bs == 0 ? (bmx - 1) * 6 + 3 : (bs < 4 ? b - 1 : (bmx - 1) * 6 + bs);
+        const int diff = eff_dc(b) - eff_dc(pb);
+        const uint32_t a = (uint32_t)(diff < 0 ? -diff : diff);
+        const uint32_t nb = a ? 32u - (uint32_t)__clz((int)a) : 0u;
+        const uint32_t val = (uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << nb) - 1u);
+        const uint32_t e = s_hdc[comp * 12 + nb];
+        bits = ((uint64_t)(e & 0xffffu) << nb) | val;
+        len = (e >> 16) + nb;
+      }
+    } else if (v != 0) {
+      const uint64_t lower = nzmask & ((1ull << lane) - 1ull);
+      const int prev = lower ? 63 - __clzll((long long)lower) : 0;
+      const int run = lane - prev - 1;
+      const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+      const uint32_t nb = 32u - (uint32_t)__clz((int)a);
+      const uint32_t val = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << nb) - 1u);
+      const uint32_t zrl = s_hac[comp * 256 + 0xF0];
+      for (int z = 0; z < (run >> 4); ++z) { bits = (bits << (zrl >> 16)) | (zrl & 0xffffu); len += zrl >> 16; }
+      const uint32_t e = s_hac[comp * 256 + (((uint32_t)run & 15u) << 4 | nb)];
+      bits = (bits << (e >> 16)) | (e & 0xffffu);
+      bits = (bits << nb) | val;
+      len += (e >> 16) + nb;
+    }
+    const int last = nzmask ? 63 - __clzll((long long)nzmask) : 0;
+    if (last < 63 && lane == last) {  // end of block
+      const uint32_t e = s_hac[comp * 256];
+      bits = (bits << (e >> 16)) | (e & 0xffffu);
+      len += e >> 16;
+    }
+    const uint32_t incl = wave_incl_scan_u32(len);
+    hb[i] = bits; hlen[i] = len; ho[i] = incl - len;
+    if (lane == 63) s_blen[b] = incl;
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan of the 96 block lengths
+    const uint32_t l0 = s_blen[lane], l1 = lane < 32 ? s_blen[64 + lane] : 0u;
+    const uint32_t i0 = wave_incl_scan_u32(l0);
+    const uint32_t t0 = __shfl(i0, 63);
+    const uint32_t i1 = wave_incl_scan_u32(l1);
+    s_boff[lane] = i0 - l0;
+    if (lane < 32) s_boff[64 + lane] = t0 + i1 - l1;
+    if (lane == 31) {
+      const uint32_t total = t0 + i1;
+      s_hbits[0] = total;
+      s_hbits[3] = total > (uint32_t)kJpegTileBits ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  const bool fits = s_hbits[3] == 0u;
+#pragma unroll
+  for (int i = 0; i < kBlocksPerWave; ++i) {
+    const int b = wave + i * (kFinThreads / 64);
+    uint32_t n = hlen[i];
+    if (n && fits) {
+      uint32_t p = s_boff[b] + ho[i];
+      const uint64_t v = hb[i];
+      while (n) {  // at most three words
+        const uint32_t off = p & 31u, take = min(n, 32u - off);
+        const uint32_t chunk = (uint32_t)(v >> (n - take)) & (take == 32u ? ~0u : ((1u << take) - 1u));
+        atomicOr(&s_hbits[kJpegTileHeader + (p >> 5)], chunk << (32u - off - take));
+        n -= take; p += take;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    s_hbits[1] = s_boff[4]; s_hbits[2] = s_boff[5];
+    s_hbits[4] = (uint32_t)eff_dc(0); s_hbits[5] = (uint32_t)eff_dc(4); s_hbits[6] = (uint32_t)eff_dc(5);
+    s_hbits[7] = (uint32_t)eff_dc(93); s_hbits[8] = (uint32_t)eff_dc(94); s_hbits[9] = (uint32_t)eff_dc(95);
+  }
+  __syncthreads();
+  {
+    const uint32_t words = kJpegTileHeader + (fits ? (s_hbits[0] + 31u) / 32u : 0u);
+    uint32_t* rec = jpeg_tiles + (size_t)m * kJpegTileWords;
+    for (uint32_t k = threadIdx.x; k < words; k += kFinThreads) rec[k] = s_hbits[k];
+  }
   PCC_KTR(5, 6);
 }
 
@@ -1410,7 +1527,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
-                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs);
+                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff);
   PCC_STAMP("k_leaf_tile");
 }
 

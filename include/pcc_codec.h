@@ -82,6 +82,12 @@ typedef struct pcc_hot_result {
   /* JPEG front end done on the GPU for the snake image: quantised coefficients, 6 blocks of 64 per
    * 16x16 MCU (Y00 Y01 Y10 Y11 Cb Cr) in zigzag order; NULL if the host has to start from `image`. */
   const int16_t *jpeg_coefs;
+  /* JPEG Huffman coding done on the GPU as well: one record of `jpeg_tile_words` u32 per MCU row (16 image
+   * rows): [0] bits, [1],[2] bit offsets of the first MCU's Cb / Cr block, [3] overflow flag, [4..6] DC of the
+   * row's first Y/Cb/Cr block (their DC codes are inserted by the host), [7..9] DC of the last ones, [16..]
+   * the bit string, MSB first inside each u32.  NULL if the host Huffman-codes `jpeg_coefs` (or `image`). */
+  const uint32_t *jpeg_tiles;
+  uint32_t jpeg_tile_words, jpeg_n_tiles;
 } pcc_hot_result;
 
 typedef struct pcc_bitstream {
@@ -149,14 +155,44 @@ int pcc_device_alloc(pcc_ctx *ctx, size_t bytes, void **dev_ptr);
 int pcc_device_free(pcc_ctx *ctx, void *dev_ptr);
 int pcc_device_upload(pcc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int pcc_get_kernel_times(pcc_ctx *ctx, pcc_kernel_times *out);
+/* wall time of the last pcc_entropy_encode on this context, microseconds: occupancy range coder, JPEG
+ * stage, colour range coder, whole stage */
+int pcc_get_host_times(pcc_ctx *ctx, double out_us[4]);
 /* enable per-kernel HIP-event timing (off by default: events between launches cost a little) */
 int pcc_set_profiling(pcc_ctx *ctx, int enabled);
 /* context knobs (do not change any output byte):
- *   "jpeg_on_gpu" (default 1): colour conversion, 4:2:0 downsample, FDCT and quantisation of the snake image on
- *                 the GPU, so that the host only Huffman-codes;  0: the host starts from the image.
+ *   "jpeg_on_gpu" (default 2): 2 = the whole JPEG stage but the file headers runs on the GPU (colour conversion,
+ *                 4:2:0 downsample, FDCT, quantisation, Huffman coding per MCU row; the host stitches the rows
+ *                 together);  1 = up to the quantised coefficients, the host Huffman-codes;  0 = the host starts
+ *                 from the image.
  *   "copy_image"  (default 1): bring the snake-mapped image itself back in pcc_hot_result.image (needed only
  *                 for inspection when jpeg_on_gpu is 1). */
 int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
+
+/* ---- a sequence of frames on one GPU (the app's frame loop, eval.hpp:818-835) ----
+ * A pipeline owns `n_workers` host threads, each with its own pcc_ctx, so that the serial host stage of one
+ * frame overlaps the GPU stage of the others.  Frames are independent I-frames (impl.hpp:89-90,126-130);
+ * frame f gets frame_id = params->frame_id + f (frame_ID_ is the only state the reference carries from frame
+ * to frame, impl.hpp:133), so the bitstreams equal those of the reference's serial loop.  The calls block
+ * until every frame is done; `out[f]` stays valid until the next call on the pipeline. */
+typedef struct pcc_pipeline pcc_pipeline;
+pcc_pipeline *pcc_pipeline_create(int device, int n_workers);
+void pcc_pipeline_destroy(pcc_pipeline *p);
+int pcc_pipeline_workers(pcc_pipeline *p);
+pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int worker); /* for pcc_set_option / pcc_set_profiling / kernel times */
+int pcc_pipeline_encode(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
+                        size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
+/* the GPU stage alone (kernels + device->host hand-over), for capacity measurements */
+int pcc_pipeline_gpu_stage_only(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
+                                size_t stride, size_t rgb_offset, const pcc_params *params);
+/* per-frame means of the last call, microseconds: launch, finish, entropy call wall time; then the four values of
+ * pcc_get_host_times; out_us[7] = frames processed */
+int pcc_pipeline_stats(pcc_pipeline *p, double out_us[8]);
+/* HIP-event kernel times of the last call, summed over the frames that ran on a context with profiling
+ * enabled: sums->ms[i] = total milliseconds of kernel sums->name[i], launches[i] = number of launches
+ * (arrays of PCC_MAX_KERNEL_TIMES), *frames = profiled frames */
+int pcc_pipeline_kernel_times(pcc_pipeline *p, pcc_kernel_times *sums, int32_t *launches, int32_t *frames);
+const char *pcc_pipeline_last_error(pcc_pipeline *p);
 
 /* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
 /* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).

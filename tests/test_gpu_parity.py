@@ -325,19 +325,40 @@ def test_cpp_shim_example_runs(pkg):
     assert "decoded voxels" in r.stdout
 
 
-@pytest.mark.parametrize("L", [200, 2048, 4000, 70001])
-def test_jpeg_front_end_on_gpu_equals_host_jpeg(pkg, oracle, L):
-    """k_jpeg_fdct + host Huffman must give the bytes of the all-host JPEG (and of libjpeg-turbo, via the oracle)."""
+@pytest.mark.parametrize("L", [1, 255, 256, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 9000, 40000])
+def test_jpeg_stage_on_gpu_equals_host_jpeg(pkg, oracle, L):
+    """The JPEG stage may run on the host (0), up to the quantised coefficients on the GPU (1) or including the
+    Huffman coding on the GPU (2): always the bytes of libjpeg-turbo (via the oracle)."""
     g = np.arange(L, dtype=np.float32)
     xyz = np.stack([(g % 128) / 128.0, ((g // 128) % 128) / 128.0, (g // 16384) / 128.0], 1) + 1.0 / 512
     pts = cloud(pkg, xyz, seed=L)
     for q in (85, 30):
         kw = dict(octree_bits=7, color_coding_type=1, jpeg_quality=q)
         want = oracle.encode_intra(pts, oracle.make_params(**kw), keep=False)
-        for on_gpu, copy_image in ((1, 0), (0, 1)):
+        for on_gpu, copy_image in ((2, 0), (1, 0), (0, 1)):
             c = pkg.binding.Context(0)
             c.set_option("jpeg_on_gpu", on_gpu)
             c.set_option("copy_image", copy_image)
             stream, perf = c.encode_intra_host(pts, pkg.binding.make_params(**kw))
             c.close()
             assert stream == want.bitstream, (L, q, on_gpu)
+
+
+def test_jpeg_huffman_rows_that_do_not_fit_fall_back_to_coefficients(pkg, oracle):
+    """White-noise colours at quality 100: an MCU row needs more bits than its record holds, the frame is then
+    Huffman-coded on the host from the coefficients -- same bytes."""
+    L = 20000
+    g = np.arange(L, dtype=np.float32)
+    xyz = np.stack([(g % 128) / 128.0, ((g // 128) % 128) / 128.0, (g // 16384) / 128.0], 1) + 1.0 / 512
+    pts = cloud(pkg, xyz, seed=7)
+    kw = dict(octree_bits=7, color_coding_type=1, jpeg_quality=100)
+    want = oracle.encode_intra(pts, oracle.make_params(**kw), keep=False)
+    c = pkg.binding.Context(0)
+    c.set_option("copy_image", 0)
+    dev = c.upload(pts)
+    c.hotpath_launch(dev, len(pts), pkg.binding.make_params(**kw))
+    hot = c.hotpath_finish(copy=False)
+    assert not hot.raw.jpeg_tiles and hot.raw.jpeg_coefs   # the fallback was taken
+    stream, perf = c.entropy_encode(hot.raw, pkg.binding.make_params(**kw))
+    c.close()
+    assert stream == want.bitstream

@@ -11,10 +11,10 @@ p = b.make_params(octree_bits=cfg["octree_bits"])
 ctx = b.Context(0); pts = syn.make_frame("cfg2"); dev = ctx.upload(pts)
 for _ in range(5):
     ctx.hotpath_launch(dev, len(pts), p); hot = ctx.hotpath_finish(copy=False)
-buf = np.zeros(7 * 1024 * 8, dtype=np.uint64)
+buf = np.zeros(9 * 1024 * 8, dtype=np.uint64)
 lib = b.load_library()
 print("rc", lib.pcc_debug_read_ktime(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.size)))
-t = buf.reshape(7, 1024, 8).astype(np.int64)
+t = buf.reshape(9, 1024, 8).astype(np.int64)
 for ps in range(4):
     x = t[ps, :245, :8]
     t0 = x[:, 0].min()
@@ -25,4 +25,6 @@ x = t[5, :231, :7]
 rel = (x - x[:, 0].min()) / 100.0
 print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end:", np.round(np.median(rel, axis=0), 2))
 print("            stamps (max us):", np.round(rel.max(axis=0), 2))
+x = t[6, 0, :6]
+print("k_bbox_events stamps (us): start, A done, B done, first chunk loaded, events done, end:", np.round((x - x[0]) / 100.0, 2))
 ctx.close()
