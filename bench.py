@@ -61,6 +61,18 @@ def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
     return 0
 
 
+def default_workers(world):
+    """Entropy threads per GPU: the CPUs this process may really use (cgroup quota, affinity), shared by the ranks."""
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cpus = min(cpus, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(32, cpus // max(world, 1)))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -88,12 +100,12 @@ def main():
               jpeg_quality=cfg["jpeg_quality"], keep_centroid=cfg["keep_centroid"])
     params = b.make_params(frame_id=1, **kw)
     n_points = cfg["n"]
-    workers = args.workers or max(1, min(24, (os.cpu_count() or 8) // max(world, 1)))
+    workers = args.workers or default_workers(world)
 
     # ---- frames of this rank, resident in HBM before the clock starts ----
     pipe = b.Pipeline(local_rank, workers)
     ctx0 = pipe.context(0)
-    for w in range(pipe.workers):
+    for w in range(pipe.n_contexts):
         pipe.context(w).set_option("copy_image", 0)  # the host stage only needs the quantised JPEG coefficients
     n_distinct = max(1, args.distinct_frames)
     host_frames = [syn.make_frame(args.workload, frame=rank * n_distinct + f) for f in range(n_distinct)]
@@ -110,7 +122,7 @@ def main():
     L, B, depth = hot0.n_leaves, hot0.n_branches, hot0.depth
     image_bytes = hot0.image_w * hot0.image_h * 3
 
-    warm = max(args.warmup, pipe.workers)
+    warm = max(args.warmup, pipe.n_contexts)
     pipe.encode([dev_frames[s % n_distinct] for s in range(warm)], [n_points] * warm, params, copy=False)
 
     # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
@@ -135,9 +147,9 @@ def main():
 
     # GPU side alone (kernels + device->host hand-over, no host entropy stage), same streams: the capacity
     # the host stage has to keep up with
-    g_steps = max(4 * pipe.workers, 64)
+    g_steps = max(4 * pipe.n_contexts, 64)
     gseq = [dev_frames[s % n_distinct] for s in range(g_steps)]
-    pipe.gpu_stage_only(gseq[:pipe.workers], [n_points] * pipe.workers, params)
+    pipe.gpu_stage_only(gseq[:pipe.n_contexts], [n_points] * pipe.n_contexts, params)
     torch.cuda.synchronize()
     tg = time.perf_counter()
     pipe.gpu_stage_only(gseq, [n_points] * g_steps, params)

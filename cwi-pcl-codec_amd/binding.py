@@ -28,11 +28,12 @@ ERR_NAMES = {-1: "PCC_ERR_ARG", -2: "PCC_ERR_HIP", -3: "PCC_ERR_EMPTY", -4: "PCC
 EXPORTS = [
     "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_hotpath_launch", "pcc_hotpath_finish",
-    "pcc_entropy_encode", "pcc_get_output_cloud", "pcc_decode_intra",
+    "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra",
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
-    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_context",
+    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_contexts",
+    "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
@@ -106,6 +107,10 @@ def load_library():
     lib.pcc_hotpath_launch.argtypes = [vp, vp, sz, sz, sz, C.POINTER(Params)]
     lib.pcc_hotpath_finish.argtypes = [vp, C.POINTER(HotResult)]
     lib.pcc_entropy_encode.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_entropy_encode2.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream),
+                                        vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_entropy_encode_many.argtypes = [i32, C.POINTER(vp), C.POINTER(C.POINTER(HotResult)), C.POINTER(C.POINTER(Params)),
+                                            C.POINTER(C.POINTER(Bitstream))]
     lib.pcc_get_output_cloud.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     lib.pcc_decode_intra.argtypes = [vp, vp, sz, C.POINTER(Cloud)]
     lib.pcc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -120,6 +125,7 @@ def load_library():
     lib.pcc_pipeline_destroy.argtypes = [vp]
     lib.pcc_pipeline_destroy.restype = None
     lib.pcc_pipeline_workers.argtypes = [vp]
+    lib.pcc_pipeline_contexts.argtypes = [vp]
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
     lib.pcc_pipeline_encode.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
@@ -245,6 +251,27 @@ class Context:
         self._check(self.lib.pcc_entropy_encode(self.h, C.byref(hot), C.byref(params), C.byref(bs)))
         return (_bytes_at(bs.data, bs.len) if copy else bs.len), [int(x) for x in bs.perf]
 
+    def entropy_encode2(self, hot_a: HotResult, params_a, other, hot_b: HotResult, params_b):
+        """Two frames at once (the other frame's bitstream is stored in context `other`)."""
+        a, b = Bitstream(), Bitstream()
+        self._check(self.lib.pcc_entropy_encode2(self.h, C.byref(hot_a), C.byref(params_a), C.byref(a),
+                                                 other.h, C.byref(hot_b), C.byref(params_b), C.byref(b)))
+        return ((_bytes_at(a.data, a.len), [int(x) for x in a.perf]), (_bytes_at(b.data, b.len), [int(x) for x in b.perf]))
+
+    @staticmethod
+    def entropy_encode_many(ctxs, hots, params):
+        """Up to four frames at once: [(bytes, perf)] in the order given (frame i's bitstream lives in ctxs[i])."""
+        n = len(ctxs)
+        lib = ctxs[0].lib
+        outs = [Bitstream() for _ in range(n)]
+        rc = lib.pcc_entropy_encode_many(
+            n, (C.c_void_p * n)(*[c.h for c in ctxs]),
+            (C.POINTER(HotResult) * n)(*[C.pointer(h) for h in hots]),
+            (C.POINTER(Params) * n)(*[C.pointer(p) for p in params]),
+            (C.POINTER(Bitstream) * n)(*[C.pointer(o) for o in outs]))
+        ctxs[0]._check(rc)
+        return [(_bytes_at(o.data, o.len), [int(x) for x in o.perf]) for o in outs]
+
     def encode_intra_host(self, points: np.ndarray, params, stride=32, rgb_offset=16):
         points = np.ascontiguousarray(points)
         bs = Bitstream()
@@ -311,6 +338,7 @@ class Pipeline:
             raise RuntimeError("pcc_pipeline_create(%r) failed: no usable MI355X/HIP device -- the hot path has no "
                                "CPU fallback" % (device,))
         self.workers = self.lib.pcc_pipeline_workers(self.h)
+        self.n_contexts = self.lib.pcc_pipeline_contexts(self.h)
 
     def close(self):
         if self.h:
@@ -323,8 +351,9 @@ class Pipeline:
         except Exception:
             pass
 
-    def context(self, worker):
-        return _BorrowedContext(self.lib, self.lib.pcc_pipeline_context(self.h, worker))
+    def context(self, index):
+        """Context `index` of n_contexts (two per worker)."""
+        return _BorrowedContext(self.lib, self.lib.pcc_pipeline_context(self.h, index))
 
     def _arrays(self, dev_frames, counts):
         k = len(dev_frames)

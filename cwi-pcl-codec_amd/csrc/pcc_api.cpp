@@ -462,6 +462,32 @@ int pcc_entropy_encode(pcc_ctx* ctx, const pcc_hot_result* hot, const pcc_params
   return PCC_OK;
 }
 
+int pcc_entropy_encode_many(int n, pcc_ctx* const ctx[], const pcc_hot_result* const hot[], const pcc_params* const prm[],
+                            pcc_bitstream* const out[]) {
+  if (n < 1 || n > PCC_MAX_FRAMES_AT_ONCE || !ctx || !hot || !prm || !out) return PCC_ERR_ARG;
+  Bytes* o[PCC_MAX_FRAMES_AT_ONCE];
+  uint64_t* pf[PCC_MAX_FRAMES_AT_ONCE];
+  double* t[PCC_MAX_FRAMES_AT_ONCE];
+  for (int i = 0; i < n; ++i) {
+    if (!ctx[i] || !hot[i] || !prm[i] || !out[i]) return PCC_ERR_ARG;
+    for (int k = 0; k < i; ++k)
+      if (ctx[k] == ctx[i]) return PCC_ERR_ARG;  // every frame's bitstream lives in its own context
+    o[i] = &ctx[i]->bitstream; pf[i] = out[i]->perf; t[i] = ctx[i]->host_us;
+  }
+  entropy_encode_frames(n, hot, prm, o, pf, t);
+  for (int i = 0; i < n; ++i) { out[i]->data = ctx[i]->bitstream.data(); out[i]->len = ctx[i]->bitstream.size(); }
+  return PCC_OK;
+}
+
+int pcc_entropy_encode2(pcc_ctx* ctx_a, const pcc_hot_result* hot_a, const pcc_params* prm_a, pcc_bitstream* out_a,
+                        pcc_ctx* ctx_b, const pcc_hot_result* hot_b, const pcc_params* prm_b, pcc_bitstream* out_b) {
+  pcc_ctx* c[2] = {ctx_a, ctx_b};
+  const pcc_hot_result* h[2] = {hot_a, hot_b};
+  const pcc_params* p[2] = {prm_a, prm_b};
+  pcc_bitstream* o[2] = {out_a, out_b};
+  return pcc_entropy_encode_many(2, c, h, p, o);
+}
+
 int pcc_encode_intra_device(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset,
                             const pcc_params* prm, pcc_bitstream* out) {
   if (!ctx || !out) return PCC_ERR_ARG;

@@ -64,59 +64,180 @@ struct InvariantDiv32 {
 };
 }  // namespace
 
-size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
+namespace {
+// One coder: the state of pcl::StaticRangeCoder::encodeCharVectorToStream between two symbols.
+struct RcStream {
   uint32_t freq[257];
-  cumulative_table(in, n, freq);
-  const size_t start = out.size();
-  out.resize(start + sizeof(freq) + n + n / 2 + 64);  // grown below if the payload turns out larger
-  uint8_t* p = out.data() + start;
-  memcpy(p, freq, sizeof(freq));
-  size_t pos = sizeof(freq);
-  size_t cap = out.size() - start;
-
-  const InvariantDiv32 by_total(freq[256]);  // 256 <= total < 2^16
+  uint64_t fw[256];     // freq[s] | (freq[s + 1] - freq[s]) << 32: one load per symbol
+  uint64_t magic = 0;   // InvariantDiv32(total)
   uint32_t low = 0, range = ~0u;
-  for (size_t i = 0; i < n; ++i) {
-    const unsigned ch = in[i];
-    range = by_total.div(range);
-    low += freq[ch] * range;
-    range *= freq[ch + 1] - freq[ch];
-    if (pos + 16 > cap) {  // a symbol emits at most 4 bytes (+ 4 bytes of store slack)
-      out.resize(start + cap * 2);
-      p = out.data() + start;
-      cap = out.size() - start;
-    }
-    // PCL's loop emits one byte per turn while the top byte is settled ((low ^ (low + range)) < 2^24).
-    // Shifting low and range left by 8 shifts that XOR by 8 as well, so the number of settled bytes is
-    // the number of leading zero BYTES of the XOR: emit them in one step, without a branch.
-    const uint32_t x = low ^ (low + range);
-    const unsigned k = x ? ((unsigned)__builtin_clz(x) >> 3) : 4u;
-    const uint32_t be = __builtin_bswap32(low);
-    memcpy(p + pos, &be, 4);  // only the first k bytes count
-    pos += k;
-    low = (uint32_t)((uint64_t)low << (8 * k));
-    range = (uint32_t)((uint64_t)range << (8 * k));
-    // rare: the range underflowed while the top byte is still open; then it is clamped to the distance to
-    // the next 2^16 boundary (range = -int(low) & (bottom - 1)) and the loop goes on as PCL writes it
-    if (__builtin_expect(range < kBottom, 0)) {
-      range = (0u - low) & (kBottom - 1);
-      for (;;) {
-        p[pos++] = (uint8_t)(low >> 24);
-        range <<= 8;
-        low <<= 8;
-        if ((low ^ (low + range)) >= kTop) {
-          if (range >= kBottom) break;
-          range = (0u - low) & (kBottom - 1);
-        }
-      }
+  Bytes* out = nullptr;
+  size_t start = 0;     // where this stream's table begins in *out
+  size_t pos = 0;       // payload bytes written behind the table
+  size_t cap = 0;       // payload bytes available
+  const uint8_t* in = nullptr;
+  size_t n = 0;
+
+  uint8_t* payload() { return out->data() + start + sizeof(freq); }
+  void begin(const uint8_t* src, size_t count, Bytes& dst) {
+    in = src; n = count; out = &dst;
+    cumulative_table(src, count, freq);
+    for (int s = 0; s < 256; ++s) fw[s] = (uint64_t)freq[s] | ((uint64_t)(freq[s + 1] - freq[s]) << 32);
+    magic = InvariantDiv32(freq[256]).magic;  // 256 <= total < 2^16
+    start = dst.size();
+    cap = count + count / 2 + 2048;  // grows on demand: a static order-0 coder cannot expand its input much
+    dst.resize(start + sizeof(freq) + cap);
+    memcpy(dst.data() + start, freq, sizeof(freq));
+    pos = 0; low = 0; range = ~0u;
+  }
+  void ensure(size_t more) {  // room for `more` payload bytes
+    if (pos + more > cap) {
+      cap = 2 * cap + more;
+      out->resize(start + sizeof(freq) + cap);
     }
   }
-  for (int i = 0; i < 4; ++i) {
-    p[pos++] = (uint8_t)(low >> 24);
-    low <<= 8;
+  size_t finish() {
+    uint8_t* p = payload();
+    for (int i = 0; i < 4; ++i) {  // "flush remaining data"
+      p[pos++] = (uint8_t)(low >> 24);
+      low <<= 8;
+    }
+    out->resize(start + sizeof(freq) + pos);
+    return sizeof(freq) + pos;
   }
-  out.resize(start + pos);
-  return pos;
+};
+
+// One symbol of stream S (state in the scalars low##S, range##S, p##S).
+// PCL's loop emits one byte per turn while the top byte is settled ((low ^ (low + range)) < 2^24).  Shifting low
+// and range left by 8 shifts that XOR by 8 as well, so the number of settled bytes is the number of leading zero
+// BYTES of the XOR: they are emitted in one step without a branch (4 bytes are stored, k of them count; the XOR
+// cannot be 0 because range > 0).  Rare: the range underflows while the top byte is still open; then it is
+// clamped to the distance to the next 2^16 boundary (range = -int(low) & (bottom - 1)) and the loop goes on as
+// PCL writes it.
+#define PCC_RC_STEP(S)                                                                              \
+  {                                                                                                 \
+    const uint64_t fw = fw##S[in##S[i]];                                                            \
+    range##S = (uint32_t)(((unsigned __int128)magic##S * range##S) >> 64); /* range /= total */     \
+    low##S += (uint32_t)fw * range##S;                                                              \
+    range##S *= (uint32_t)(fw >> 32);                                                               \
+    const uint32_t x = low##S ^ (low##S + range##S);                                                \
+    const unsigned k = (unsigned)__builtin_clz(x | 1u) >> 3;                                        \
+    const uint32_t be = __builtin_bswap32(low##S);                                                  \
+    memcpy(p##S, &be, 4);                                                                           \
+    p##S += k;                                                                                      \
+    low##S = (uint32_t)((uint64_t)low##S << (8 * k));                                               \
+    range##S = (uint32_t)((uint64_t)range##S << (8 * k));                                           \
+    if (__builtin_expect(range##S < kBottom, 0)) {                                                  \
+      range##S = (0u - low##S) & (kBottom - 1);                                                     \
+      for (;;) {                                                                                    \
+        *p##S++ = (uint8_t)(low##S >> 24);                                                          \
+        range##S <<= 8;                                                                             \
+        low##S <<= 8;                                                                               \
+        if ((low##S ^ (low##S + range##S)) >= kTop) {                                               \
+          if (range##S >= kBottom) break;                                                           \
+          range##S = (0u - low##S) & (kBottom - 1);                                                 \
+        }                                                                                           \
+      }                                                                                             \
+    }                                                                                               \
+  }
+#define PCC_RC_LOAD(S, st)                                                                          \
+  const uint8_t* in##S = (st)->in;                                                                  \
+  const uint64_t* fw##S = (st)->fw;                                                                 \
+  const uint64_t magic##S = (st)->magic;                                                            \
+  uint32_t low##S = (st)->low, range##S = (st)->range;                                              \
+  uint8_t* p##S = (st)->payload() + (st)->pos;
+#define PCC_RC_STORE(S, st)                                                                         \
+  (st)->low = low##S; (st)->range = range##S; (st)->pos = (size_t)(p##S - (st)->payload());
+
+constexpr size_t kRcBlock = 256;                      // symbols between two capacity checks
+constexpr size_t kRcBlockBytes = 4 * kRcBlock + 16;   // a symbol emits at most 4 bytes (+ store slack)
+
+// symbols [i0, i1) of 1..4 streams in one loop: every symbol is a chain of dependent multiplies, shifts and a
+// count-leading-zeros (about a dozen cycles), so one coder leaves most of the core idle; several independent
+// coders in the same loop fill it.  The bytes of each stream do not depend on how many run together.
+void rc_run1(RcStream* a, size_t i0, size_t i1) {
+  for (size_t b = i0; b < i1; b += kRcBlock) {
+    const size_t e = std::min(b + kRcBlock, i1);
+    a->ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, a)
+    for (size_t i = b; i < e; ++i) PCC_RC_STEP(0)
+    PCC_RC_STORE(0, a)
+  }
+}
+void rc_run2(RcStream* a, RcStream* b2, size_t i0, size_t i1) {
+  for (size_t b = i0; b < i1; b += kRcBlock) {
+    const size_t e = std::min(b + kRcBlock, i1);
+    a->ensure(kRcBlockBytes); b2->ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, a) PCC_RC_LOAD(1, b2)
+    for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) }
+    PCC_RC_STORE(0, a) PCC_RC_STORE(1, b2)
+  }
+}
+void rc_run3(RcStream* a, RcStream* b2, RcStream* c, size_t i0, size_t i1) {
+  for (size_t b = i0; b < i1; b += kRcBlock) {
+    const size_t e = std::min(b + kRcBlock, i1);
+    a->ensure(kRcBlockBytes); b2->ensure(kRcBlockBytes); c->ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, a) PCC_RC_LOAD(1, b2) PCC_RC_LOAD(2, c)
+    for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) PCC_RC_STEP(2) }
+    PCC_RC_STORE(0, a) PCC_RC_STORE(1, b2) PCC_RC_STORE(2, c)
+  }
+}
+void rc_run4(RcStream* a, RcStream* b2, RcStream* c, RcStream* d, size_t i0, size_t i1) {
+  for (size_t b = i0; b < i1; b += kRcBlock) {
+    const size_t e = std::min(b + kRcBlock, i1);
+    a->ensure(kRcBlockBytes); b2->ensure(kRcBlockBytes); c->ensure(kRcBlockBytes); d->ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, a) PCC_RC_LOAD(1, b2) PCC_RC_LOAD(2, c) PCC_RC_LOAD(3, d)
+    for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) PCC_RC_STEP(2) PCC_RC_STEP(3) }
+    PCC_RC_STORE(0, a) PCC_RC_STORE(1, b2) PCC_RC_STORE(2, c) PCC_RC_STORE(3, d)
+  }
+}
+}  // namespace
+
+void StaticRangeCoder::encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[]) {
+  RcStream st[kMaxStreams];
+  RcStream* order[kMaxStreams];
+  if (count > kMaxStreams) count = kMaxStreams;
+  for (int i = 0; i < count; ++i) {
+    st[i].begin(in[i], n[i], *out[i]);
+    order[i] = &st[i];
+  }
+  // longest first: all streams run together up to the length of the shortest, then one fewer, ...
+  std::sort(order, order + count, [](const RcStream* x, const RcStream* y) { return x->n > y->n; });
+  size_t done = 0;
+  for (int live = count; live > 0; --live) {
+    const size_t upto = order[live - 1]->n;  // the shortest stream still running ends here
+    if (upto > done) {
+      if (live == 4) rc_run4(order[0], order[1], order[2], order[3], done, upto);
+      else if (live == 3) rc_run3(order[0], order[1], order[2], done, upto);
+      else if (live == 2) rc_run2(order[0], order[1], done, upto);
+      else rc_run1(order[0], done, upto);
+      done = upto;
+    }
+  }
+  for (int i = 0; i < count; ++i) {
+    st[i].ensure(8);
+    got[i] = st[i].finish();
+  }
+}
+
+size_t StaticRangeCoder::encode(const uint8_t* in, size_t n, Bytes& out) {
+  const uint8_t* src[1] = {in};
+  const size_t len[1] = {n};
+  Bytes* dst[1] = {&out};
+  size_t got[1];
+  encode_many(1, src, len, dst, got);
+  return got[0];
+}
+
+void StaticRangeCoder::encode2(const uint8_t* in_a, size_t n_a, Bytes& out_a, size_t& len_a,
+                               const uint8_t* in_b, size_t n_b, Bytes& out_b, size_t& len_b) {
+  const uint8_t* src[2] = {in_a, in_b};
+  const size_t len[2] = {n_a, n_b};
+  Bytes* dst[2] = {&out_a, &out_b};
+  size_t got[2];
+  encode_many(2, src, len, dst, got);
+  len_a = got[0];
+  len_b = got[1];
 }
 
 size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n) {
@@ -885,23 +1006,17 @@ const char kV2Id[] = "<PCL-OCT-CODECV2-COMPRESSED>";
 const char kV1Id[] = "<PCL-OCT-COMPRESSED>";
 }  // namespace
 
-void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3],
-                          double* times_us) {
-  typedef std::chrono::steady_clock Clock;
-  auto us_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::micro>(Clock::now() - t0).count(); };
-  const Clock::time_point t_begin = Clock::now();
-  double t_occ = 0, t_jpeg = 0, t_col = 0;
+namespace {
+void write_frame_header(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out) {
   out.clear();
-  const bool with_color = prm.do_color_encoding != 0;
-  const size_t L = (size_t)hot.n_leaves;
-  // --- 140-byte header ---
+  // --- 140-byte header (impl.hpp:1472-1486 + the PCL base header it calls) ---
   out.insert(out.end(), kV2Id, kV2Id + 28);
   out.insert(out.end(), kV1Id, kV1Id + 20);
   put_le<uint32_t>(out, prm.frame_id);
   put_le<uint8_t>(out, 1);  // i_frame_
   put_le<uint8_t>(out, 1);  // do_voxel_grid_enDecoding_
-  put_le<uint8_t>(out, with_color ? 1 : 0);
-  put_le<uint64_t>(out, (uint64_t)L);
+  put_le<uint8_t>(out, prm.do_color_encoding ? 1 : 0);
+  put_le<uint64_t>(out, (uint64_t)hot.n_leaves);
   put_le<double>(out, prm.octree_resolution);
   put_le<uint8_t>(out, (uint8_t)prm.color_bit_resolution);
   put_le<double>(out, (double)(float)prm.point_resolution);
@@ -912,58 +1027,125 @@ void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Byte
   put_le<uint32_t>(out, (uint32_t)prm.color_coding_type);
   put_le<int32_t>(out, prm.macroblock_size);
   put_le<uint8_t>(out, prm.do_icp_color_offset ? 1 : 0);
+}
 
-  // --- occupancy bytes ---
-  put_le<uint64_t>(out, hot.n_branches);
-  Clock::time_point t0 = Clock::now();
-  uint64_t point_len = StaticRangeCoder::encode(hot.occupancy, (size_t)hot.n_branches, out);
-  t_occ = us_since(t0);
-  perf[0] = point_len;
-  if (prm.do_voxel_centroid) {
-    put_le<uint32_t>(out, (uint32_t)(3 * L));
-    point_len += StaticRangeCoder::encode(hot.centroid, 3 * L, out);
-  }
-  perf[1] = point_len - perf[0];
-  perf[2] = 0;
-  if (with_color) {
-    Bytes payload;
-    const uint8_t* src = hot.bgr;
-    size_t src_len = 3 * L;
-    t0 = Clock::now();
-    if (prm.color_coding_type == 1) {  // one 256-wide snake-mapped image (jpegcc.h:187-226)
-      if (hot.jpeg_tiles &&
-          BaselineJpeg::encode_tiles(hot.jpeg_tiles, hot.jpeg_tile_words, hot.jpeg_n_tiles, (int)hot.image_w, (int)hot.image_h,
-                                     prm.jpeg_quality, payload)) {
-        // stitched from the GPU's per-row bit strings
-      } else if (hot.jpeg_coefs)
-        BaselineJpeg::encode_coefs(hot.jpeg_coefs, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
-      else
-        BaselineJpeg::encode_rgb(hot.image, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
-      src = payload.data();
-      src_len = payload.size();
-    } else if (prm.color_coding_type == 2) {  // 2048x1 lines (jpegcc.h:244-317)
-      const size_t lines = L / 2048;
-      const uint32_t count = lines ? (uint32_t)lines : 1u;
-      put_le<uint32_t>(payload, count);
-      Bytes one;
-      for (uint32_t i = 0; i < count; ++i) {
-        const size_t start = (size_t)2048 * i;
-        const size_t width = lines == 0 ? L : (i + 1 != count ? 2048 : L - start);
-        one.clear();
-        BaselineJpeg::encode_rgb(hot.bgr + 3 * start, (int)width, 1, prm.jpeg_quality, one);
-        put_le<uint32_t>(payload, (uint32_t)one.size());
-        payload.insert(payload.end(), one.begin(), one.end());
-      }
-      src = payload.data();
-      src_len = payload.size();
+// what the colour range coder gets (jpegcc.h:115-139): raw b,g,r bytes, or the JPEG file(s) made of them
+void colour_payload(const pcc_hot_result& hot, const pcc_params& prm, Bytes& payload, const uint8_t*& src, size_t& src_len) {
+  const size_t L = (size_t)hot.n_leaves;
+  src = hot.bgr;
+  src_len = 3 * L;
+  if (prm.color_coding_type == 1) {  // one 256-wide snake-mapped image (jpegcc.h:187-226)
+    if (hot.jpeg_tiles &&
+        BaselineJpeg::encode_tiles(hot.jpeg_tiles, hot.jpeg_tile_words, hot.jpeg_n_tiles, (int)hot.image_w, (int)hot.image_h,
+                                   prm.jpeg_quality, payload)) {
+      // stitched from the GPU's per-row bit strings
+    } else if (hot.jpeg_coefs) {
+      BaselineJpeg::encode_coefs(hot.jpeg_coefs, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
+    } else {
+      BaselineJpeg::encode_rgb(hot.image, (int)hot.image_w, (int)hot.image_h, prm.jpeg_quality, payload);
     }
-    t_jpeg = us_since(t0);
-    put_le<uint64_t>(out, (uint64_t)src_len);
-    t0 = Clock::now();
-    perf[2] = StaticRangeCoder::encode(src, src_len, out);
-    t_col = us_since(t0);
+    src = payload.data();
+    src_len = payload.size();
+  } else if (prm.color_coding_type == 2) {  // 2048x1 lines (jpegcc.h:244-317)
+    const size_t lines = L / 2048;
+    const uint32_t count = lines ? (uint32_t)lines : 1u;
+    put_le<uint32_t>(payload, count);
+    Bytes one;
+    for (uint32_t i = 0; i < count; ++i) {
+      const size_t start = (size_t)2048 * i;
+      const size_t width = lines == 0 ? L : (i + 1 != count ? 2048 : L - start);
+      one.clear();
+      BaselineJpeg::encode_rgb(hot.bgr + 3 * start, (int)width, 1, prm.jpeg_quality, one);
+      put_le<uint32_t>(payload, (uint32_t)one.size());
+      payload.insert(payload.end(), one.begin(), one.end());
+    }
+    src = payload.data();
+    src_len = payload.size();
   }
-  if (times_us) { times_us[0] = t_occ; times_us[1] = t_jpeg; times_us[2] = t_col; times_us[3] = us_since(t_begin); }
+}
+}  // namespace
+
+// Up to four frames at a time: every range-coder stage codes the streams of all frames in one loop
+// (StaticRangeCoder::encode_many): same bytes, a fraction of the time per frame.
+void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_params* const prm[], Bytes* const out[],
+                           uint64_t* const perf[], double* const times_us[]) {
+  typedef std::chrono::steady_clock Clock;
+  auto us_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::micro>(Clock::now() - t0).count(); };
+  const Clock::time_point t_begin = Clock::now();
+  constexpr int kMax = StaticRangeCoder::kMaxStreams;
+  if (n > kMax) n = kMax;
+  double t_occ = 0, t_jpeg = 0, t_col = 0;
+  bool use[kMax];
+  const uint8_t* src[kMax];
+  size_t len[kMax];
+  uint64_t got[kMax];
+  // a range-coder stage over the frames that take part in it
+  auto stage = [&]() {
+    const uint8_t* s2[kMax];
+    size_t l2[kMax], g2[kMax];
+    Bytes* o2[kMax];
+    int idx[kMax], m = 0;
+    for (int i = 0; i < n; ++i) {
+      got[i] = 0;
+      if (use[i]) { s2[m] = src[i]; l2[m] = len[i]; o2[m] = out[i]; idx[m] = i; ++m; }
+    }
+    if (m) StaticRangeCoder::encode_many(m, s2, l2, o2, g2);
+    for (int k = 0; k < m; ++k) got[idx[k]] = g2[k];
+  };
+
+  // --- header, occupancy bytes (impl.hpp:1692-1697) ---
+  for (int i = 0; i < n; ++i) {
+    write_frame_header(*hot[i], *prm[i], *out[i]);
+    put_le<uint64_t>(*out[i], hot[i]->n_branches);
+    use[i] = true; src[i] = hot[i]->occupancy; len[i] = (size_t)hot[i]->n_branches;
+  }
+  Clock::time_point t0 = Clock::now();
+  stage();
+  t_occ = us_since(t0);
+  for (int i = 0; i < n; ++i) perf[i][0] = got[i];
+
+  // --- centroid bytes (impl.hpp:1700-1710) ---
+  for (int i = 0; i < n; ++i) {
+    use[i] = prm[i]->do_voxel_centroid != 0;
+    if (use[i]) {
+      put_le<uint32_t>(*out[i], (uint32_t)(3 * hot[i]->n_leaves));
+      src[i] = hot[i]->centroid; len[i] = (size_t)(3 * hot[i]->n_leaves);
+    }
+  }
+  stage();
+  for (int i = 0; i < n; ++i) perf[i][1] = got[i];
+
+  // --- colour (impl.hpp:1713-1723) ---
+  Bytes payload[kMax];
+  t0 = Clock::now();
+  for (int i = 0; i < n; ++i) {
+    use[i] = prm[i]->do_color_encoding != 0;
+    if (use[i]) {
+      colour_payload(*hot[i], *prm[i], payload[i], src[i], len[i]);
+      put_le<uint64_t>(*out[i], (uint64_t)len[i]);
+    }
+  }
+  t_jpeg = us_since(t0);
+  t0 = Clock::now();
+  stage();
+  t_col = us_since(t0);
+  for (int i = 0; i < n; ++i) perf[i][2] = got[i];
+
+  const double total = us_since(t_begin);
+  for (int i = 0; i < n; ++i)
+    if (times_us && times_us[i]) {  // per frame: a stage shared by several frames counts in equal parts
+      times_us[i][0] = t_occ / n; times_us[i][1] = t_jpeg / n; times_us[i][2] = t_col / n; times_us[i][3] = total / n;
+    }
+}
+
+void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3],
+                          double* times_us) {
+  const pcc_hot_result* h[1] = {&hot};
+  const pcc_params* p[1] = {&prm};
+  Bytes* o[1] = {&out};
+  uint64_t* pf[1] = {perf};
+  double* t[1] = {times_us};
+  entropy_encode_frames(1, h, p, o, pf, t);
 }
 
 // =============================================================================================

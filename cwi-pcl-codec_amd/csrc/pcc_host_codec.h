@@ -19,6 +19,13 @@ class StaticRangeCoder {
  public:
   // appends 1028-byte table + payload + 4 flush bytes to `out`; returns bytes appended
   static size_t encode(const uint8_t* in, size_t n, Bytes& out);
+  // up to kMaxStreams independent streams coded in one loop (same bytes as separate encode() calls; see the
+  // .cpp); the output vectors must be distinct; got[i] = bytes appended to *out[i]
+  static constexpr int kMaxStreams = 4;
+  static void encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[]);
+  // two streams
+  static void encode2(const uint8_t* in_a, size_t n_a, Bytes& out_a, size_t& len_a,
+                      const uint8_t* in_b, size_t n_b, Bytes& out_b, size_t& len_b);
   // returns bytes consumed, 0 on a truncated stream
   static size_t decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n);
 };
@@ -48,6 +55,10 @@ uint32_t snake_position(uint32_t i, uint32_t w, uint32_t h);
 // `times_us` (optional, 4 doubles): occupancy range coder, JPEG (Huffman or full), colour range coder, whole stage
 void entropy_encode_frame(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out, uint64_t perf[3],
                           double* times_us = nullptr);
+
+// the same for n = 1..4 frames at once: the range-coder stages of all frames share one loop
+void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_params* const prm[], Bytes* const out[],
+                           uint64_t* const perf[], double* const times_us[]);
 
 // decodePointCloud (impl.hpp:224-310); returns PCC_OK or PCC_ERR_STREAM
 int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info);

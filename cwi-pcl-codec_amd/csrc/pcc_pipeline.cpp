@@ -1,18 +1,26 @@
-// pcc_pipeline.cpp -- multi-frame encoder on one GPU: a pool of host threads, each with its own
-// pcc_ctx (HIP stream + HBM arena + pinned landing buffers), so that the serial host stage of one frame
-// (JPEG Huffman + static range coder) overlaps the GPU stage of the others.
+// pcc_pipeline.cpp -- multi-frame encoder on one GPU.  Two kinds of host threads around a ring of pcc_ctx
+// (each a HIP stream + HBM arena + pinned landing buffers):
+//   GPU-stage threads   take a free context and the next frame, enqueue the kernels, sleep until the
+//                       occupancy stream / JPEG rows have landed in the context's pinned buffers, and hand
+//                       the context to the ready queue;
+//   entropy threads     take one or (preferably) two ready contexts and run the serial host stage (static
+//                       range coder, JPEG stitching); two frames share one loop (pcc_entropy_encode2), which
+//                       costs about the time of one.  Then the contexts go back to the free list.
+// So the GPU always has a few frames in flight, and every core that the host stage can get codes symbols.
 //
 // The reference encodes the frames of a sequence one after the other on one thread (eval.hpp:818-835).
 // Frames are independent I-frames (impl.hpp:89-90,126-130); the only thing that ties them together is the
 // header field frame_ID_ (impl.hpp:133), which is assigned here by sequence index, so the bitstreams are
 // the ones the serial loop would have produced.
 //
-// Built on the public C ABI only (pcc_hotpath_launch / pcc_hotpath_finish / pcc_entropy_encode).
+// Built on the public C ABI only (pcc_hotpath_launch / pcc_hotpath_finish / pcc_entropy_encode[2]).
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -31,19 +39,30 @@ struct Job {  // one pcc_pipeline_encode call
   pcc_params params{};
   int mode = 0;  // 0 full encode, 1 GPU stage only (launch + finish)
 };
+
+struct Ready {  // a context whose GPU stage is done
+  pcc_ctx* ctx;
+  size_t frame;
+  pcc_params prm;
+  pcc_hot_result hot;
+};
 }  // namespace
 
 struct pcc_pipeline {
   int device = 0;
+  int n_entropy = 0, n_gpu = 0;
   std::vector<pcc_ctx*> ctxs;
   std::vector<std::thread> threads;
-  std::mutex mu;
-  std::condition_variable cv_work, cv_done;
+  std::mutex mu;  // guards everything below up to `stat_mu`
+  std::condition_variable cv_work, cv_done, cv_free, cv_ready;
   uint64_t generation = 0;   // bumped for every job
   bool stopping = false;
-  int busy = 0;              // workers still inside the current job
+  int busy = 0;              // threads still inside the current job
   Job job;
-  std::atomic<size_t> next{0};
+  size_t next_frame = 0;     // next frame to hand to a GPU-stage thread
+  size_t gpu_done = 0;       // frames whose GPU stage is over (ready, failed or dropped)
+  std::vector<pcc_ctx*> free_ctx;
+  std::deque<Ready> ready;
   // results of the current / last job
   std::vector<std::vector<uint8_t>> streams;
   std::vector<pcc_bitstream> results;
@@ -59,76 +78,142 @@ struct pcc_pipeline {
   std::vector<int> k_launches;
   size_t k_frames = 0;
 
-  void worker(int w) {
-    pcc_ctx* ctx = ctxs[(size_t)w];
+  void note_error(pcc_ctx* c, int rc) {
+    if (rc == PCC_OK || rc == PCC_ERR_EMPTY) return;
+    std::lock_guard<std::mutex> lk(stat_mu);
+    if (err.empty()) err = pcc_last_error(c);
+  }
+
+  // wait for the next job; false when the pipeline shuts down
+  bool next_job(uint64_t& seen) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_work.wait(lk, [&] { return stopping || generation != seen; });
+    if (stopping) return false;
+    seen = generation;
+    return true;
+  }
+  void job_done() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (--busy == 0) cv_done.notify_all();
+  }
+
+  void gpu_thread() {
     uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_work.wait(lk, [&] { return stopping || generation != seen; });
-        if (stopping) return;
-        seen = generation;
-      }
-      double tl = 0, tf = 0, te = 0, hu[4] = {0, 0, 0, 0};
-      size_t done = 0;
+    while (next_job(seen)) {
+      double tl = 0, tf = 0;
       for (;;) {
-        const size_t f = next.fetch_add(1);
-        if (f >= job.n_frames) break;
-        pcc_params prm = job.params;
-        prm.frame_id = job.params.frame_id + (uint32_t)f;  // frame_ID_ by sequence index
+        Ready r;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          if (next_frame >= job.n_frames) break;
+          cv_free.wait(lk, [&] { return !free_ctx.empty(); });
+          if (next_frame >= job.n_frames) break;
+          r.frame = next_frame++;
+          r.ctx = free_ctx.back();
+          free_ctx.pop_back();
+        }
+        r.prm = job.params;
+        r.prm.frame_id = job.params.frame_id + (uint32_t)r.frame;  // frame_ID_ by sequence index
         Clock::time_point t0 = Clock::now();
-        int rc = pcc_hotpath_launch(ctx, job.frames[f], job.counts[f], job.stride, job.rgb_offset, &prm);
+        int rc = pcc_hotpath_launch(r.ctx, job.frames[r.frame], job.counts[r.frame], job.stride, job.rgb_offset, &r.prm);
         tl += us_since(t0);
-        pcc_hot_result hot;
         if (rc == PCC_OK) {
           t0 = Clock::now();
-          rc = pcc_hotpath_finish(ctx, &hot);
+          rc = pcc_hotpath_finish(r.ctx, &r.hot);
           tf += us_since(t0);
-          pcc_kernel_times kt;
-          if (rc == PCC_OK && pcc_get_kernel_times(ctx, &kt) == PCC_OK && kt.count > 0) {
-            std::lock_guard<std::mutex> lk(stat_mu);
-            for (int i = 0; i < kt.count; ++i) {
-              size_t k = 0;
-              while (k < k_name.size() && strcmp(k_name[k], kt.name[i]) != 0) ++k;
-              if (k == k_name.size()) { k_name.push_back(kt.name[i]); k_ms.push_back(0.0); k_launches.push_back(0); }
-              k_ms[k] += kt.ms[i];
-              ++k_launches[k];
-            }
-            ++k_frames;
-          }
         }
-        pcc_bitstream bs;
-        memset(&bs, 0, sizeof(bs));
-        if (rc == PCC_OK && job.mode == 0) {
-          t0 = Clock::now();
-          rc = pcc_entropy_encode(ctx, &hot, &prm, &bs);
-          te += us_since(t0);
-          double h[4];
-          if (pcc_get_host_times(ctx, h) == PCC_OK)
-            for (int i = 0; i < 4; ++i) hu[i] += h[i];
-          if (rc == PCC_OK) {
-            streams[f].assign(bs.data, bs.data + bs.len);  // the context's buffer is reused by its next frame
-            results[f] = bs;
-            results[f].data = streams[f].data();
-          }
-        }
-        status[f] = rc;
-        if (rc != PCC_OK && rc != PCC_ERR_EMPTY) {
+        pcc_kernel_times kt;
+        if (rc == PCC_OK && pcc_get_kernel_times(r.ctx, &kt) == PCC_OK && kt.count > 0) {
           std::lock_guard<std::mutex> lk(stat_mu);
-          if (err.empty()) err = pcc_last_error(ctx);
+          for (int q = 0; q < kt.count; ++q) {
+            size_t k = 0;
+            while (k < k_name.size() && strcmp(k_name[k], kt.name[q]) != 0) ++k;
+            if (k == k_name.size()) { k_name.push_back(kt.name[q]); k_ms.push_back(0.0); k_launches.push_back(0); }
+            k_ms[k] += kt.ms[q];
+            ++k_launches[k];
+          }
+          ++k_frames;
         }
-        ++done;
+        note_error(r.ctx, rc);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          status[r.frame] = rc;
+          ++gpu_done;
+          if (rc == PCC_OK && job.mode == 0) {
+            ready.push_back(r);
+          } else {  // nothing for the host stage to do: the context is free again
+            free_ctx.push_back(r.ctx);
+            cv_free.notify_one();
+          }
+        }
+        cv_ready.notify_all();
       }
       {
         std::lock_guard<std::mutex> lk(stat_mu);
-        t_launch += tl; t_finish += tf; t_entropy += te;
+        t_launch += tl; t_finish += tf;
+      }
+      cv_ready.notify_all();
+      job_done();
+    }
+  }
+
+  void entropy_thread() {
+    uint64_t seen = 0;
+    while (next_job(seen)) {
+      double te = 0, hu[4] = {0, 0, 0, 0};
+      size_t done = 0;
+      for (;;) {
+        constexpr int kAtOnce = PCC_MAX_FRAMES_AT_ONCE;
+        Ready r[kAtOnce];
+        int nr = 0;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv_ready.wait(lk, [&] { return !ready.empty() || gpu_done >= job.n_frames; });
+          // take what is there, but leave the other entropy threads their share
+          const size_t share = (ready.size() + (size_t)n_entropy - 1) / (size_t)n_entropy;
+          while (nr < kAtOnce && !ready.empty() && (nr < 2 || (size_t)nr < share)) { r[nr++] = ready.front(); ready.pop_front(); }
+          if (nr == 0) break;  // every frame went through the GPU stage and the queue is empty
+        }
+        pcc_bitstream bs[kAtOnce];
+        memset(bs, 0, sizeof(bs));
+        int rc[kAtOnce];
+        pcc_ctx* c[kAtOnce];
+        const pcc_hot_result* h[kAtOnce];
+        const pcc_params* pp[kAtOnce];
+        pcc_bitstream* o[kAtOnce];
+        for (int i = 0; i < nr; ++i) { c[i] = r[i].ctx; h[i] = &r[i].hot; pp[i] = &r[i].prm; o[i] = &bs[i]; }
+        Clock::time_point t0 = Clock::now();
+        const int rc_all = pcc_entropy_encode_many(nr, c, h, pp, o);
+        for (int i = 0; i < nr; ++i) rc[i] = rc_all;
+        te += us_since(t0);
+        for (int i = 0; i < nr; ++i) {
+          if (rc[i] == PCC_OK) {
+            double hh[4];
+            if (pcc_get_host_times(r[i].ctx, hh) == PCC_OK)
+              for (int q = 0; q < 4; ++q) hu[q] += hh[q];
+            streams[r[i].frame].assign(bs[i].data, bs[i].data + bs[i].len);  // the context's buffer is reused by its next frame
+            results[r[i].frame] = bs[i];
+            results[r[i].frame].data = streams[r[i].frame].data();
+          }
+          note_error(r[i].ctx, rc[i]);
+          ++done;
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          for (int i = 0; i < nr; ++i) {
+            if (rc[i] != PCC_OK) status[r[i].frame] = rc[i];
+            free_ctx.push_back(r[i].ctx);
+          }
+        }
+        cv_free.notify_all();
+      }
+      {
+        std::lock_guard<std::mutex> lk(stat_mu);
+        t_entropy += te;
         for (int i = 0; i < 4; ++i) host_us[i] += hu[i];
         frames_done += done;
       }
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (--busy == 0) cv_done.notify_all();
-      }
+      job_done();
     }
   }
 };
@@ -139,7 +224,15 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   if (n_workers < 1) n_workers = 1;
   pcc_pipeline* p = new pcc_pipeline();
   p->device = device;
-  for (int w = 0; w < n_workers; ++w) {
+  p->n_entropy = n_workers;
+  p->n_gpu = n_workers < 6 ? n_workers : 6;  // frames in flight on the GPU: a handful saturates it
+  if (const char* e = getenv("PCC_PIPELINE_GPU_THREADS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) p->n_gpu = v;
+  }
+  // an entropy thread holds up to four contexts (usually two), a GPU-stage thread one, plus some in the queue
+  const int n_ctx = 3 * p->n_entropy + 2 * p->n_gpu;
+  for (int w = 0; w < n_ctx; ++w) {
     pcc_ctx* c = pcc_create(device);
     if (!c) {  // no usable GPU: there is no CPU fallback
       for (pcc_ctx* k : p->ctxs) pcc_destroy(k);
@@ -148,7 +241,8 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     }
     p->ctxs.push_back(c);
   }
-  for (int w = 0; w < n_workers; ++w) p->threads.emplace_back([p, w] { p->worker(w); });
+  for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p] { p->gpu_thread(); });
+  for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p] { p->entropy_thread(); });
   return p;
 }
 
@@ -164,11 +258,12 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   delete p;
 }
 
-int pcc_pipeline_workers(pcc_pipeline* p) { return p ? (int)p->ctxs.size() : 0; }
+int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }
+int pcc_pipeline_contexts(pcc_pipeline* p) { return p ? (int)p->ctxs.size() : 0; }
 
-pcc_ctx* pcc_pipeline_context(pcc_pipeline* p, int worker) {
-  if (!p || worker < 0 || worker >= (int)p->ctxs.size()) return nullptr;
-  return p->ctxs[(size_t)worker];
+pcc_ctx* pcc_pipeline_context(pcc_pipeline* p, int index) {
+  if (!p || index < 0 || index >= (int)p->ctxs.size()) return nullptr;
+  return p->ctxs[(size_t)index];
 }
 
 static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t* n_points, size_t n_frames, size_t stride,
@@ -186,7 +281,10 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->host_us[0] = p->host_us[1] = p->host_us[2] = p->host_us[3] = 0;
     p->frames_done = 0;
     p->k_name.clear(); p->k_ms.clear(); p->k_launches.clear(); p->k_frames = 0;
-    p->next.store(0);
+    p->next_frame = 0;
+    p->gpu_done = 0;
+    p->ready.clear();
+    p->free_ctx = p->ctxs;
     p->busy = (int)p->threads.size();
     ++p->generation;
   }

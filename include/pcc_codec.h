@@ -143,6 +143,15 @@ int pcc_hotpath_finish(pcc_ctx *ctx, pcc_hot_result *out);
 int pcc_entropy_encode(pcc_ctx *ctx_for_output, const pcc_hot_result *hot, const pcc_params *params,
                        pcc_bitstream *out);
 
+/* The same for several frames at once (different contexts): the serial range-coder loops of the frames are
+ * interleaved in one loop, which costs a fraction of the time per frame (each symbol is a chain of dependent
+ * operations that leaves most of a core idle).  Bytes identical to separate pcc_entropy_encode calls. */
+#define PCC_MAX_FRAMES_AT_ONCE 4
+int pcc_entropy_encode_many(int n, pcc_ctx *const ctx[], const pcc_hot_result *const hot[], const pcc_params *const prm[],
+                            pcc_bitstream *const out[]);
+int pcc_entropy_encode2(pcc_ctx *ctx_a, const pcc_hot_result *hot_a, const pcc_params *prm_a, pcc_bitstream *out_a,
+                        pcc_ctx *ctx_b, const pcc_hot_result *hot_b, const pcc_params *prm_b, pcc_bitstream *out_b);
+
 /* getOutputCloud() (eval.hpp:862): the simplified cloud of the last encode, L points (impl.hpp:1576). */
 int pcc_get_output_cloud(pcc_ctx *ctx, const pcc_point_xyzrgb **points, size_t *n);
 
@@ -170,8 +179,8 @@ int pcc_set_profiling(pcc_ctx *ctx, int enabled);
 int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 
 /* ---- a sequence of frames on one GPU (the app's frame loop, eval.hpp:818-835) ----
- * A pipeline owns `n_workers` host threads, each with its own pcc_ctx, so that the serial host stage of one
- * frame overlaps the GPU stage of the others.  Frames are independent I-frames (impl.hpp:89-90,126-130);
+ * A pipeline owns a ring of pcc_ctx, a few GPU-stage threads that keep frames in flight on the GPU, and
+ * `n_workers` entropy threads that run the serial host stage, two frames at a time (pcc_entropy_encode2).  Frames are independent I-frames (impl.hpp:89-90,126-130);
  * frame f gets frame_id = params->frame_id + f (frame_ID_ is the only state the reference carries from frame
  * to frame, impl.hpp:133), so the bitstreams equal those of the reference's serial loop.  The calls block
  * until every frame is done; `out[f]` stays valid until the next call on the pipeline. */
@@ -179,7 +188,8 @@ typedef struct pcc_pipeline pcc_pipeline;
 pcc_pipeline *pcc_pipeline_create(int device, int n_workers);
 void pcc_pipeline_destroy(pcc_pipeline *p);
 int pcc_pipeline_workers(pcc_pipeline *p);
-pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int worker); /* for pcc_set_option / pcc_set_profiling / kernel times */
+int pcc_pipeline_contexts(pcc_pipeline *p);
+pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option / pcc_set_profiling / kernel times */
 int pcc_pipeline_encode(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
                         size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
 /* the GPU stage alone (kernels + device->host hand-over), for capacity measurements */

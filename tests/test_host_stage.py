@@ -119,6 +119,42 @@ def test_entropy_stage_and_decoder_match_oracle(pkg, oracle, mode, centroid):
     assert info["params"]["frame_id"] == 3 and info["params"]["color_coding_type"] == mode
 
 
+@pytest.mark.parametrize("modes", [(1, 1), (0, 2), (3, 1)])
+def test_two_frames_at_once_give_the_same_bytes(pkg, oracle, modes):
+    """pcc_entropy_encode2 interleaves the range-coder loops of two frames: the bytes must not change
+    (different sizes, colour modes and centroid settings in one pair)."""
+    hosts = [pkg.binding.Context(None), pkg.binding.Context(None)]
+    hrs, prms, wants, keeps = [], [], [], []
+    for i, mode in enumerate(modes):
+        pts = pkg.synthetic.sphere_shell(4000 + 3000 * i, 0x51 + i)
+        kw = dict(octree_bits=6 + i, color_bits=7 if mode == 0 else 8, color_coding_type=mode, keep_centroid=i,
+                  jpeg_quality=75, frame_id=5 + i)
+        r = oracle.encode_intra(pts, oracle.make_params(**kw))
+        hr, keep = _hot_from_oracle(pkg, r)
+        hrs.append(hr); prms.append(pkg.binding.make_params(**kw)); wants.append(r); keeps.append(keep)
+    (sa, pa), (sb, pb) = hosts[0].entropy_encode2(hrs[0], prms[0], hosts[1], hrs[1], prms[1])
+    assert sa == wants[0].bitstream and pa == wants[0].perf
+    assert sb == wants[1].bitstream and pb == wants[1].perf
+
+
+def test_four_frames_at_once_give_the_same_bytes(pkg, oracle):
+    """pcc_entropy_encode_many with 3 and 4 frames of different sizes and settings."""
+    b = pkg.binding
+    hosts = [b.Context(None) for _ in range(4)]
+    hrs, prms, wants, keeps = [], [], [], []
+    for i, (mode, cen) in enumerate([(1, 0), (0, 1), (1, 1), (2, 0)]):
+        pts = pkg.synthetic.sphere_shell(2500 + 2100 * i, 0x61 + i)
+        kw = dict(octree_bits=5 + (i % 3), color_bits=6 if mode == 0 else 8, color_coding_type=mode, keep_centroid=cen,
+                  jpeg_quality=60 + 10 * i, frame_id=9 + i)
+        r = oracle.encode_intra(pts, oracle.make_params(**kw))
+        hr, keep = _hot_from_oracle(pkg, r)
+        hrs.append(hr); prms.append(b.make_params(**kw)); wants.append(r); keeps.append(keep)
+    for n in (3, 4):
+        got = b.Context.entropy_encode_many(hosts[:n], hrs[:n], prms[:n])
+        for i in range(n):
+            assert got[i][0] == wants[i].bitstream and got[i][1] == wants[i].perf, (n, i)
+
+
 def test_decoder_rejects_garbage(pkg):
     host = pkg.binding.Context(None)
     for bad in (b"", b"hello", b"<PCL-OCT-CODECV2-COMPRESSED><PCL-OCT-COMPRESSED>\x00"):
