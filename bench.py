@@ -126,8 +126,9 @@ def main():
     pipe.encode([dev_frames[s % n_distinct] for s in range(warm)], [n_points] * warm, params, copy=False)
 
     # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
-    # without taxing every stream
-    ctx0.set_profiling(True)
+    # without taxing every stream (the free list is a stack: its top context takes part in every round)
+    prof_ctx = pipe.context(pipe.n_contexts - 1)
+    prof_ctx.set_profiling(True)
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
     sync_all()
     t0 = time.perf_counter()
@@ -137,7 +138,7 @@ def main():
     elapsed = t1 - t0
     stats = pipe.stats()
     ktimes, profiled = pipe.kernel_times()
-    ctx0.set_profiling(False)
+    prof_ctx.set_profiling(False)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -13,3 +13,6 @@ python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; ca
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/kernel_stats.txt && cat $OUT/kernel_stats.txt
 find $OUT/prof -name '*.db' -size +20M -delete
+# single-stream latency + its kernel trace, and the HBM-traffic counters (separate --pmc passes)
+bash tools/prof_latency.sh $TAG/lat > $OUT/latency_stats.txt 2>&1; tail -14 $OUT/latency_stats.txt
+bash tools/pmc_run.sh $TAG/pmc > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log

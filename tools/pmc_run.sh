@@ -1,0 +1,12 @@
+#!/bin/bash
+# HBM traffic per kernel: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE do not fit one pass) over
+# the single-stream latency probe.  Usage (through gpurun): bash tools/pmc_run.sh <tag> [workload]
+TAG=${1:-pmc}; WL=${2:-cfg2}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT; export TMPDIR=/tmp
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $GRAFT_REPO_ROOT/tools/gpu_latency.py $WL 6 > $OUT/$C.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+find $OUT -name '*.csv' | head; python tools/pmc_traffic.py $OUT $WL
