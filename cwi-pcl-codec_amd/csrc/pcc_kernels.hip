@@ -605,6 +605,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   uint64_t* s_keys = s_raw;
   uint32_t* s_pay = reinterpret_cast<uint32_t*>(s_raw + kSortTile);
   __shared__ uint16_t s_cnt[NW][kMaxBins];  // per-wave running digit counts, then wave start ranks
+  __shared__ uint32_t s_hist[kMaxBins];     // digit counts of the tile
   __shared__ uint32_t s_gofs[kMaxBins];     // global position of a digit's first key minus its position in s_keys
   __shared__ uint16_t s_dstart[kMaxBins];   // position of a digit's first key in s_keys
   __shared__ uint32_t s_scan[NW];
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   if (ticketed && threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += kSortThreads) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins; k += kSortThreads) s_match[k] = 0ull;
+  for (int k = threadIdx.x; k < kMaxBins; k += kSortThreads) s_hist[k] = 0u;
   __syncthreads();
   const uint32_t tile = ticketed ? s_tile : blockIdx.x;
   PCC_KT(1);
@@ -638,10 +640,12 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   uint32_t* gstatus = status + (size_t)n_tiles_max * kMaxBins;                                // one per (group, digit)
   const int lane = lane_id(), wave = wave_id();
   const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const uint32_t g = tile / kLookBackGroup, q = tile % kLookBackGroup;
+  const bool closes_group = q == kLookBackGroup - 1;
+  const uint32_t d_me = threadIdx.x;  // thread = digit in the per-digit steps
+  uint32_t spins = 0;
 
-  // Tile order = (wave, round, lane): every wave ranks its own 512 consecutive keys against
-  // wave-private counters, so no workgroup barrier is needed inside the ranking loop (the LDS
-  // operations of one wave complete in issue order).
+  // Tile order = (wave, round, lane): every wave owns consecutive keys, read as rows of 64.
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
   uint64_t key[kSortItems];
   uint32_t pay[kSortItems];
@@ -652,103 +656,143 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
     key[r] = i < count ? in[i] : kInvalidKey;
     pay[r] = (with_payload && i < count) ? pay_in[i] : 0u;
   }
-  // global start of every digit = exclusive scan of the digit totals (thread = digit)
-  uint32_t gsum;
-  const uint32_t dtot = threadIdx.x < nbins ? digit_tot[(size_t)pass * kMaxBins + threadIdx.x] : 0u;
-  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
-  // Peers = lanes of this wave whose key has the same digit.  Every lane ORs its lane bit into the
-  // (wave, digit) mask in LDS and reads the mask back: three LDS operations instead of one ballot
-  // and a handful of 64-bit VALU operations per digit bit.  The first peer clears the mask again and
-  // advances the wave's digit counter (LDS operations of one wave execute in program order).
-  uint64_t* wmatch = s_match + (size_t)wave * kMaxBins;
+  // ---- the tile's digit counts first, so that later tiles learn them as early as possible ----
+  // (the digit of the row's first key is counted with one ballot: the most significant digit of a clustered
+  // cloud has few values, and 64 lanes adding to one LDS word would serialise)
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const bool valid = key[r] != kInvalidKey;
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-    if (valid) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
-    const uint64_t peers = valid ? wmatch[d] : 0ull;
-    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-    const uint32_t prior = s_cnt[wave][d];
-    if (valid && rank == 0) {
-      wmatch[d] = 0ull;
-      s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
+    const uint64_t vm = __ballot(valid);
+    if (vm) {
+      const int first = __ffsll((long long)vm) - 1;
+      const uint32_t d0 = __shfl(d, first);
+      const uint64_t same = __ballot(valid && d == d0);
+      if (lane == first) atomicAdd(&s_hist[d0], (uint32_t)__popcll(same));
+      else if (valid && d != d0) atomicAdd(&s_hist[d], 1u);
     }
-    lrank[r] = (uint16_t)(prior + rank);
   }
-  __syncthreads();
-  PCC_KT(2);
-  const uint32_t d_me = threadIdx.x;  // thread = digit
-  uint32_t run = 0;
-  if (d_me < nbins) {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t c = s_cnt[w][d_me];
-      s_cnt[w][d_me] = (uint16_t)run;
-      run += c;
-    }
-    // tell later tiles how many keys of this digit the tile holds, as early as possible
-    if (pass != 0) publish_u32(status + (size_t)tile * kMaxBins + d_me, kStatusAggregate | run);
-  }
+  // global start of every digit = exclusive scan of the digit totals (its barriers also cover s_hist)
+  uint32_t gsum;
+  const uint32_t dtot = d_me < nbins ? digit_tot[(size_t)pass * kMaxBins + d_me] : 0u;
+  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
+  const uint32_t run = d_me < nbins ? s_hist[d_me] : 0u;
+  if (pass != 0 && d_me < nbins) publish_u32(status + (size_t)tile * kMaxBins + d_me, kStatusAggregate | run);
   uint32_t tile_valid;
   const uint32_t dstart = block_excl_scan<NW, uint32_t>(run, s_scan, tile_valid);
-  PCC_KT(3);
-  // Keys of each digit in the tiles before this one: known up front for pass 0 (k_digit_totals).
-  // Otherwise a two-level decoupled look-back over one self-describing word per (tile, digit):
-  // (1) the earlier tiles of the own group of 16; the last tile of a group then publishes the group's
-  // count; (2) the groups before, 16 per poll, ending at the first group that already knows its
-  // inclusive prefix.  To keep the polling traffic off the memory system only ONE lane per awaited
-  // tile polls (the digit-0 word) until it is there; then every thread reads its own digit's words.
-  uint32_t acc = 0;
-  if (pass == 0) {
-    if (d_me < nbins) acc = tile_prefix0[(size_t)tile * kMaxBins + d_me];
-  } else {
-    const uint32_t g = tile / kLookBackGroup, q = tile % kLookBackGroup;
-    uint32_t spins = 0;
+  PCC_KT(2);
+
+  // Two-level decoupled look-back over one self-describing word per (tile, digit) / (group of 16 tiles, digit).
+  // To keep the polling traffic off the memory system only ONE lane per awaited tile polls (the digit-0 word)
+  // until it is there; then every thread reads its own digit's words.
+  uint32_t partial = 0;  // keys of this digit in the earlier tiles of the own group
+  auto wait_group_mates = [&](bool also_wait_for_previous_group) {
     if (threadIdx.x < q) {
       while ((poll_u32(status + (size_t)(g * kLookBackGroup + threadIdx.x) * kMaxBins) >> 30) == 0) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
       }
-    }
-    __syncthreads();
-    PCC_KT(4);
-    uint32_t partial = 0;
-    const bool closes_group = q == kLookBackGroup - 1;
-    if (d_me < nbins) {
-      for (;;) {
-        uint32_t sum = 0;
-        bool all = true;
-#pragma unroll
-        for (uint32_t k = 0; k < kLookBackGroup - 1; ++k) {
-          if (k < q) {
-            const uint32_t v = poll_u32(status + (size_t)(g * kLookBackGroup + k) * kMaxBins + d_me);
-            all &= (v >> 30) != 0;
-            sum += v & kStatusValue;
-          }
-        }
-        if (all) { partial = sum; break; }
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
-      }
-      if (closes_group) publish_u32(gstatus + (size_t)g * kMaxBins + d_me, (g == 0 ? kStatusInclusive : kStatusAggregate) | (partial + run));
-    }
-    PCC_KT(5);
-    if (g > 0 && threadIdx.x == 0) {
+    } else if (also_wait_for_previous_group && g > 0 && threadIdx.x == 64) {
       while ((poll_u32(gstatus + (size_t)(g - 1) * kMaxBins) >> 30) == 0) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
       }
     }
     __syncthreads();
+  };
+  auto read_group_mates = [&]() {  // every thread reads its digit's words of the earlier tiles of the group
+    for (;;) {
+      uint32_t sum = 0;
+      bool all = true;
+#pragma unroll
+      for (uint32_t k = 0; k < kLookBackGroup - 1; ++k) {
+        if (k < q) {
+          const uint32_t v = poll_u32(status + (size_t)(g * kLookBackGroup + k) * kMaxBins + d_me);
+          all &= (v >> 30) != 0;
+          sum += v & kStatusValue;
+        }
+      }
+      if (all) { partial = sum; break; }
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+    }
+  };
+  // The last tile of a group publishes the group's count BEFORE it ranks its own keys: the two hops of the
+  // look-back (tile counts -> group count -> the tiles that need it) then overlap with everybody's ranking.
+  if (pass != 0 && closes_group) {
+    wait_group_mates(false);
+    if (d_me < nbins) read_group_mates();
+    if (d_me < nbins) publish_u32(gstatus + (size_t)g * kMaxBins + d_me, (g == 0 ? kStatusInclusive : kStatusAggregate) | (partial + run));
+  }
+  PCC_KT(3);
+
+  // ---- ranking.  Peers = lanes of this wave whose key has the same digit.  Every lane ORs its lane bit
+  // into the (wave, digit) mask in LDS and reads the mask back: three LDS operations instead of one ballot
+  // and a handful of 64-bit VALU operations per digit bit.  The first peer clears the mask again and advances
+  // the wave's digit counter (LDS operations of one wave execute in program order, so no barrier is needed).
+  uint64_t* wmatch = s_match + (size_t)wave * kMaxBins;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const bool valid = key[r] != kInvalidKey;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    // the peers of the row's first key come from one ballot (see the histogram above), the others through LDS
+    const uint64_t vm = __ballot(valid);
+    const int first = vm ? __ffsll((long long)vm) - 1 : 0;
+    const uint32_t d0 = __shfl(d, first);
+    const uint64_t same = __ballot(valid && d == d0);
+    const bool via_lds = valid && d != d0;
+    if (via_lds) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
+    const uint64_t peers = via_lds ? wmatch[d] : (valid ? same : 0ull);
+    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+    const uint32_t prior = s_cnt[wave][d];
+    if (valid && rank == 0) {
+      if (via_lds) wmatch[d] = 0ull;
+      s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
+    }
+    lrank[r] = (uint16_t)(prior + rank);
+  }
+  __syncthreads();
+  PCC_KT(4);
+  if (d_me < nbins) {  // per-wave counts -> wave start ranks inside the tile
+    uint32_t sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = s_cnt[w][d_me];
+      s_cnt[w][d_me] = (uint16_t)sum;
+      sum += c;
+    }
+  }
+
+  // ---- keys of each digit in the tiles before this one ----
+  uint32_t acc = 0;
+  if (pass == 0) {  // known up front (k_digit_totals)
+    if (d_me < nbins) acc = tile_prefix0[(size_t)tile * kMaxBins + d_me];
+  } else {
+    // one barrier interval waits for the own group's earlier tiles AND the group before; then the tile words
+    // and the group words are read back to back
+    if (!closes_group) {
+      wait_group_mates(true);
+    } else {
+      if (g > 0 && threadIdx.x == 64) {
+        while ((poll_u32(gstatus + (size_t)(g - 1) * kMaxBins) >> 30) == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+        }
+      }
+      __syncthreads();
+    }
     PCC_KT(6);
     if (d_me < nbins) {
-      uint32_t before = 0;
+      // the first batch of group words is requested together with the tile words: one round trip for both
+      uint32_t v[kLookBackGroup];
       int j = (int)g - 1;
-      while (j >= 0) {
-        uint32_t v[kLookBackGroup];
 #pragma unroll
-        for (int k = 0; k < kLookBackGroup; ++k)
-          v[k] = (j - k >= 0) ? poll_u32(gstatus + (size_t)(j - k) * kMaxBins + d_me) : kStatusInclusive;
+      for (int k = 0; k < kLookBackGroup; ++k)
+        v[k] = (j - k >= 0) ? poll_u32(gstatus + (size_t)(j - k) * kMaxBins + d_me) : kStatusInclusive;
+      if (!closes_group) read_group_mates();
+      // the groups before: 16 per poll, ending at the first one that knows its inclusive prefix
+      uint32_t before = 0;
+      while (j >= 0) {
         int used = 0;
         bool done = false;
 #pragma unroll
@@ -768,6 +812,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
           __builtin_amdgcn_s_sleep(1);
           if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
         }
+#pragma unroll
+        for (int k = 0; k < kLookBackGroup; ++k)
+          v[k] = (j - k >= 0) ? poll_u32(gstatus + (size_t)(j - k) * kMaxBins + d_me) : kStatusInclusive;
       }
       if (closes_group && g != 0) publish_u32(gstatus + (size_t)g * kMaxBins + d_me, kStatusInclusive | ((before + partial + run) & kStatusValue));
       acc = before + partial;

@@ -362,3 +362,25 @@ def test_jpeg_huffman_rows_that_do_not_fit_fall_back_to_coefficients(pkg, oracle
     stream, perf = c.entropy_encode(hot.raw, pkg.binding.make_params(**kw))
     c.close()
     assert stream == want.bitstream
+
+
+def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
+    """pcc_pipeline_encode: frames of different sizes in flight on several contexts, host stage for up to four
+    frames at once -- the bitstreams must be those of the reference's serial frame loop (frame ids by index)."""
+    b = pkg.binding
+    sizes = [30_000, 5_000, 41_000, 12_345, 30_000, 777, 20_000, 9_999, 33_333, 1, 16_000]
+    frames = [pkg.synthetic.sphere_shell(n, 0x900 + i) for i, n in enumerate(sizes)]
+    kw = dict(octree_bits=8, color_coding_type=1, jpeg_quality=80)
+    want = [oracle.encode_intra(f, oracle.make_params(frame_id=3 + i, **kw), keep=False).bitstream for i, f in enumerate(frames)]
+    pipe = b.Pipeline(0, workers=3)
+    ctx = pipe.context(0)
+    devs = [ctx.upload(f) for f in frames]
+    for rep in range(2):   # the second call reuses every context
+        got = pipe.encode(devs, sizes, b.make_params(frame_id=3, **kw))
+        assert [g[0] for g in got] == want
+    pipe.gpu_stage_only(devs, sizes, b.make_params(frame_id=3, **kw))
+    st = pipe.stats()
+    assert st["frames"] == 0   # nothing went through the entropy stage in the last call
+    for d in devs:
+        ctx.free(d)
+    pipe.close()

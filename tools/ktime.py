@@ -19,7 +19,7 @@ for ps in range(4):
     x = t[ps, :245, :8]
     t0 = x[:, 0].min()
     rel = (x - t0) / 100.0
-    print("pass %d: stamps (median us): start %.2f tile %.2f ranked %.2f scanned %.2f | prewait1 %.2f partial %.2f prewait2 %.2f lookback-done %.2f" % ((ps,) + tuple(np.median(rel, axis=0))))
+    print("pass %d: stamps (median us): start %.2f tile %.2f published %.2f closers-done %.2f ranked %.2f mates-read %.2f prev-group-ready %.2f lookback-done %.2f" % ((ps,) + tuple(np.median(rel, axis=0))))
     print("        stamps (max us):", np.round(rel.max(axis=0), 2))
 x = t[5, :231, :7]
 rel = (x - x[:, 0].min()) / 100.0
