@@ -293,6 +293,16 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     std::unique_lock<std::mutex> lk(p->mu);
     p->cv_done.wait(lk, [&] { return p->busy == 0; });
   }
+  // frame_ID_ is only incremented for frames that are not dropped (impl.hpp:133 vs :206-212): renumber the
+  // headers in sequence order (u32 behind the two 28 + 20 byte identifiers)
+  if (mode == 0) {
+    uint32_t id = params->frame_id;
+    for (size_t f = 0; f < n_frames; ++f) {
+      if (p->status[f] != PCC_OK || p->streams[f].size() < 52) continue;
+      memcpy(p->streams[f].data() + 48, &id, sizeof(id));
+      ++id;
+    }
+  }
   for (size_t f = 0; f < n_frames; ++f)
     if (p->status[f] != PCC_OK && p->status[f] != PCC_ERR_EMPTY) return p->status[f];
   return PCC_OK;

@@ -181,8 +181,9 @@ int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 /* ---- a sequence of frames on one GPU (the app's frame loop, eval.hpp:818-835) ----
  * A pipeline owns a ring of pcc_ctx, a few GPU-stage threads that keep frames in flight on the GPU, and
  * `n_workers` entropy threads that run the serial host stage, two frames at a time (pcc_entropy_encode2).  Frames are independent I-frames (impl.hpp:89-90,126-130);
- * frame f gets frame_id = params->frame_id + f (frame_ID_ is the only state the reference carries from frame
- * to frame, impl.hpp:133), so the bitstreams equal those of the reference's serial loop.  The calls block
+ * the frames get consecutive frame ids starting at params->frame_id, dropped (empty / all non-finite) frames
+ * do not consume one (frame_ID_ is the only state the reference carries from frame to frame, impl.hpp:133,
+ * 206-212), so the bitstreams equal those of the reference's serial loop; a dropped frame yields len 0.  The calls block
  * until every frame is done; `out[f]` stays valid until the next call on the pipeline. */
 typedef struct pcc_pipeline pcc_pipeline;
 pcc_pipeline *pcc_pipeline_create(int device, int n_workers);

@@ -366,12 +366,19 @@ def test_jpeg_huffman_rows_that_do_not_fit_fall_back_to_coefficients(pkg, oracle
 
 def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
     """pcc_pipeline_encode: frames of different sizes in flight on several contexts, host stage for up to four
-    frames at once -- the bitstreams must be those of the reference's serial frame loop (frame ids by index)."""
+    frames at once -- the bitstreams must be those of the reference's serial frame loop; a dropped frame (all
+    NaN) in the middle yields nothing and does not consume a frame id."""
     b = pkg.binding
-    sizes = [30_000, 5_000, 41_000, 12_345, 30_000, 777, 20_000, 9_999, 33_333, 1, 16_000]
+    sizes = [30_000, 5_000, 41_000, 12_345, 30_000, 777, 20_000, 9_999, 33_333, 2, 16_000]
     frames = [pkg.synthetic.sphere_shell(n, 0x900 + i) for i, n in enumerate(sizes)]
+    frames[4]["x"] = np.nan   # this frame is dropped (impl.hpp:206-212)
     kw = dict(octree_bits=8, color_coding_type=1, jpeg_quality=80)
-    want = [oracle.encode_intra(f, oracle.make_params(frame_id=3 + i, **kw), keep=False).bitstream for i, f in enumerate(frames)]
+    want, fid = [], 3
+    for f in frames:
+        r = oracle.encode_intra(f, oracle.make_params(frame_id=fid, **kw), keep=False)
+        want.append(b"" if r is None else r.bitstream)
+        fid += 0 if r is None else 1
+    assert want[4] == b"" and all(len(w) for i, w in enumerate(want) if i != 4)
     pipe = b.Pipeline(0, workers=3)
     ctx = pipe.context(0)
     devs = [ctx.upload(f) for f in frames]
