@@ -36,6 +36,7 @@ EXPORTS = [
     "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
+    "pcc_quality_metrics",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
 ]
@@ -75,6 +76,13 @@ class Bitstream(C.Structure):
 class Cloud(C.Structure):
     _fields_ = [("points", C.c_void_p), ("n", C.c_size_t), ("params", Params), ("bbox", C.c_double * 6),
                 ("depth", C.c_uint32), ("consumed", C.c_size_t)]
+
+
+class Quality(C.Structure):
+    _fields_ = [("in_point_count", C.c_uint64), ("out_point_count", C.c_uint64), ("symm_rms", C.c_float),
+                ("symm_hausdorff", C.c_float), ("left_hausdorff", C.c_float), ("right_hausdorff", C.c_float),
+                ("left_rms", C.c_float), ("right_rms", C.c_float), ("psnr_db", C.c_double), ("psnr_yuv", C.c_double * 3),
+                ("gpu_ms", C.c_float)]
 
 
 class KernelTimes(C.Structure):
@@ -134,6 +142,7 @@ def load_library():
     lib.pcc_pipeline_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.pcc_pipeline_last_error.restype = C.c_char_p
     lib.pcc_pipeline_last_error.argtypes = [vp]
+    lib.pcc_quality_metrics.argtypes = [vp, vp, sz, vp, sz, C.c_double, C.POINTER(Quality)]
     lib.pcc_host_range_encode.restype = sz
     lib.pcc_host_range_encode.argtypes = [vp, sz, vp, sz]
     lib.pcc_host_range_decode.restype = sz
@@ -299,6 +308,15 @@ class Context:
         info = dict(bbox=np.array(list(c.bbox)), depth=int(c.depth), consumed=int(c.consumed),
                     params={k: getattr(c.params, k) for k, _ in Params._fields_})
         return pts, info
+
+    def quality_metrics(self, cloud_a: np.ndarray, cloud_b: np.ndarray, cell_hint=0.0):
+        """computeQualityMetric(original, decoded) (quality_metrics_impl.hpp:82-239) as a dict."""
+        a, b2 = np.ascontiguousarray(cloud_a), np.ascontiguousarray(cloud_b)
+        q = Quality()
+        self._check(self.lib.pcc_quality_metrics(self.h, a.ctypes.data, len(a), b2.ctypes.data, len(b2), float(cell_hint), C.byref(q)))
+        d = {k: getattr(q, k) for k, _ in Quality._fields_ if k != "psnr_yuv"}
+        d["psnr_yuv"] = list(q.psnr_yuv)
+        return d
 
     def set_option(self, name, value):
         self._check(self.lib.pcc_set_option(self.h, name.encode(), int(value)))

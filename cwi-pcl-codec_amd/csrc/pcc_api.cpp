@@ -14,6 +14,7 @@
 #include "pcc_device.h"
 #include "pcc_host_codec.h"
 #include "pcc_kernels.h"
+#include "pcc_quality.h"
 
 using namespace pcc;
 
@@ -85,6 +86,14 @@ struct pcc_ctx {
   DevBuf<uint32_t> d_jpeg_tiles;  // per-MCU-row Huffman records
   DevBuf<JpegHuffTables> d_huff;
   bool huff_uploaded = false;
+
+  // quality metric
+  DevBuf<uint8_t> d_qa, d_qb;
+  DevBuf<unsigned long long> d_qkeys;
+  DevBuf<uint32_t> d_qheads, d_qnext, d_qidx;
+  DevBuf<float> d_qd2;
+  DevBuf<double> d_qpart;
+  std::vector<double> h_qpart;
 
   // host landing buffers
   PinnedBuf<FrameState> h_state;
@@ -223,6 +232,8 @@ void pcc_destroy(pcc_ctx* c) {
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
   c->d_jpeg_tiles.release(); c->d_huff.release(); c->h_jpeg_tiles.release();
+  c->d_qa.release(); c->d_qb.release(); c->d_qkeys.release(); c->d_qheads.release(); c->d_qnext.release();
+  c->d_qidx.release(); c->d_qd2.release(); c->d_qpart.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
   c->h_simplified.release();
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -535,6 +546,95 @@ int pcc_get_output_cloud(pcc_ctx* ctx, const pcc_point_xyzrgb** points, size_t* 
   }
   *points = ctx->out_cloud.data();
   *n = L;
+  return PCC_OK;
+}
+
+int pcc_quality_metrics(pcc_ctx* ctx, const pcc_point_xyzrgb* cloud_a, size_t n_a, const pcc_point_xyzrgb* cloud_b, size_t n_b,
+                        double cell_hint, pcc_quality* out) {
+  if (!ctx || !out || (!cloud_a && n_a) || (!cloud_b && n_b)) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  memset(out, 0, sizeof(*out));
+  if (n_a == 0 || n_b == 0) return fail(ctx, PCC_ERR_EMPTY, "quality metric of an empty cloud");
+  if (n_a >= (1ull << 31) || n_b >= (1ull << 31)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^31 points");
+  PCC_HIP(hipSetDevice(ctx->device));
+  const size_t n_max = std::max(n_a, n_b);
+  const size_t slots = quality_table_slots(n_max);
+  const size_t blocks = (n_max + 255) / 256;
+  PCC_HIP(ctx->d_qa.ensure(32 * n_a));
+  PCC_HIP(ctx->d_qb.ensure(32 * n_b));
+  PCC_HIP(ctx->d_qkeys.ensure(slots));
+  PCC_HIP(ctx->d_qheads.ensure(slots));
+  PCC_HIP(ctx->d_qnext.ensure(n_max));
+  PCC_HIP(ctx->d_qidx.ensure(n_max));
+  PCC_HIP(ctx->d_qd2.ensure(n_max));
+  PCC_HIP(ctx->d_qpart.ensure(blocks * 8));
+  ctx->h_qpart.resize(blocks * 8);
+  PCC_HIP(hipMemcpyAsync(ctx->d_qa.p, cloud_a, 32 * n_a, hipMemcpyHostToDevice, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->d_qb.p, cloud_b, 32 * n_b, hipMemcpyHostToDevice, ctx->stream));
+
+  // grid: origin below both clouds, cell = hint or a size that puts about two points of a volume-filling cloud in a cell
+  float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  auto span = [&](const pcc_point_xyzrgb* c, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      const float q[3] = {c[i].x, c[i].y, c[i].z};
+      if (!std::isfinite(q[0]) || !std::isfinite(q[1]) || !std::isfinite(q[2])) continue;
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
+    }
+  };
+  span(cloud_a, n_a);
+  span(cloud_b, n_b);
+  if (!(lo[0] <= hi[0])) return fail(ctx, PCC_ERR_EMPTY, "quality metric: no finite point");
+  float ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  if (!(ext > 0.f)) ext = 1.f;
+  float cell = (float)cell_hint;
+  if (!(cell > 0.f)) cell = ext / std::cbrt((float)n_max / 2.0f);
+  cell = std::max(cell, ext / 1000000.0f);  // 21 bits of cell index per axis, with room to spare
+
+  QualityArgs qa{};
+  qa.keys = ctx->d_qkeys.p; qa.heads = ctx->d_qheads.p; qa.next = ctx->d_qnext.p;
+  qa.d2 = ctx->d_qd2.p; qa.idx = ctx->d_qidx.p; qa.partials = ctx->d_qpart.p;
+  qa.cell = cell;
+  for (int a = 0; a < 3; ++a) qa.origin[a] = lo[a] - cell;
+  double sum_d[2] = {0, 0}, sum_e[3] = {0, 0, 0};
+  float max_d[2] = {0, 0}, max_xyz[3] = {0, 0, 0};
+  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+  for (int dir = 0; dir < 2; ++dir) {  // 0: A -> B with colour, 1: B -> A geometry only
+    qa.query = dir == 0 ? ctx->d_qa.p : ctx->d_qb.p;
+    qa.target = dir == 0 ? ctx->d_qb.p : ctx->d_qa.p;
+    qa.n_query = (uint32_t)(dir == 0 ? n_a : n_b);
+    qa.n_target = (uint32_t)(dir == 0 ? n_b : n_a);
+    qa.table_slots = quality_table_slots(qa.n_target);
+    qa.with_colour = dir == 0;
+    launch_quality_direction(qa, ctx->stream);
+    PCC_HIP(hipGetLastError());
+    const size_t nb = ((size_t)qa.n_query + 255) / 256;
+    PCC_HIP(hipMemcpyAsync(ctx->h_qpart.data(), ctx->d_qpart.p, nb * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (dir == 1) PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    float md = -3.4e38f;
+    for (size_t b = 0; b < nb; ++b) {  // fixed order: the result does not depend on scheduling
+      const double* p = ctx->h_qpart.data() + 8 * b;
+      sum_d[dir] += p[0];
+      if (dir == 0) { sum_e[0] += p[1]; sum_e[1] += p[2]; sum_e[2] += p[3]; }
+      md = std::max(md, (float)p[4]);
+      if (dir == 0) for (int a = 0; a < 3; ++a) max_xyz[a] = b == 0 ? (float)p[5 + a] : std::max(max_xyz[a], (float)p[5 + a]);
+    }
+    max_d[dir] = md;
+  }
+  (void)hipEventElapsedTime(&out->gpu_ms, ctx->ev_begin, ctx->ev_end);
+  // quality_metrics_impl.hpp:163-198
+  const float max_dist_a = std::sqrt(max_d[0]), max_dist_b = std::sqrt(max_d[1]);
+  const double rms_a = std::sqrt(sum_d[0] / (double)n_a), rms_b = std::sqrt(sum_d[1] / (double)n_b);
+  const float dist_h = std::max(max_dist_a, max_dist_b);
+  const float dist_rms = (float)std::max(rms_a, rms_b);
+  const float energy = max_xyz[0] * max_xyz[0] + max_xyz[1] * max_xyz[1] + max_xyz[2] * max_xyz[2];
+  const float psnr = 10 * std::log10(energy / (dist_rms * dist_rms));
+  out->in_point_count = n_a;
+  out->out_point_count = n_b;
+  out->left_hausdorff = max_dist_a; out->right_hausdorff = max_dist_b; out->symm_hausdorff = dist_h;
+  out->left_rms = (float)rms_a; out->right_rms = (float)rms_b; out->symm_rms = dist_rms;
+  out->psnr_db = psnr;
+  for (int c = 0; c < 3; ++c) out->psnr_yuv[c] = 10 * std::log10(1.0 / (sum_e[c] / (double)n_a));
   return PCC_OK;
 }
 

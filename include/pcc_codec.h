@@ -205,6 +205,20 @@ int pcc_pipeline_stats(pcc_pipeline *p, double out_us[8]);
 int pcc_pipeline_kernel_times(pcc_pipeline *p, pcc_kernel_times *sums, int32_t *launches, int32_t *frames);
 const char *pcc_pipeline_last_error(pcc_pipeline *p);
 
+/* ---- computeQualityMetric (apps/evaluate_compression quality_metrics_impl.hpp:82-239; quality_metrics.h:53-80) ----
+ * cloud_a = original, cloud_b = decoded (host pointers).  Nearest neighbours on the GPU (uniform grid of cell size
+ * `cell_hint`, e.g. the octree resolution; <= 0: chosen from the clouds), exact like the reference's KdTree;
+ * among equally distant neighbours the lower index counts.  Non-finite points are left out of the searches. */
+typedef struct pcc_quality {
+  uint64_t in_point_count, out_point_count;
+  float symm_rms, symm_hausdorff, left_hausdorff, right_hausdorff, left_rms, right_rms;
+  double psnr_db;
+  double psnr_yuv[3];
+  float gpu_ms;
+} pcc_quality;
+int pcc_quality_metrics(pcc_ctx *ctx, const pcc_point_xyzrgb *cloud_a, size_t n_a, const pcc_point_xyzrgb *cloud_b,
+                        size_t n_b, double cell_hint, pcc_quality *out);
+
 /* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
 /* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).
  * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */

@@ -1,0 +1,62 @@
+"""CPU ORACLE (test infrastructure, not product code): the quality metric of the reference's evaluation app,
+computeQualityMetric (apps/evaluate_compression/include/pcl/apps/evaluate_compression/impl/quality_metrics_impl.hpp:82-239).
+
+The reference answers its nearest-neighbour queries with pcl::search::KdTree (FLANN, exact, L2_Simple on float), which
+is not in /root/reference (PCL is un-vendored): "parity unpinned" for the search itself; exact nearest neighbours are
+unique up to ties, and ties are resolved here towards the lower index.  Arithmetic follows the reference line by line:
+float squared distances accumulated in x, y, z order, double sums, float sqrt / max / log10 where the reference uses
+float variables."""
+import numpy as np
+
+
+def nearest(query_xyz, target_xyz):
+    """Exact nearest neighbour (lower index on ties) and FLANN-style float32 squared distance."""
+    from scipy.spatial import cKDTree
+    q = np.asarray(query_xyz, dtype=np.float32)
+    t = np.asarray(target_xyz, dtype=np.float32)
+    tree = cKDTree(t.astype(np.float64))
+    k = min(8, len(t))
+    _, cand = tree.query(q.astype(np.float64), k=k)
+    cand = cand.reshape(len(q), k)
+    diff = q[:, None, :] - t[cand]                                   # float32
+    d2 = (diff[..., 0] * diff[..., 0]).astype(np.float32)
+    d2 = (d2 + (diff[..., 1] * diff[..., 1]).astype(np.float32)).astype(np.float32)
+    d2 = (d2 + (diff[..., 2] * diff[..., 2]).astype(np.float32)).astype(np.float32)
+    best = d2.min(axis=1)
+    idx = np.where(d2 == best[:, None], cand, np.iinfo(np.int64).max).min(axis=1)   # lower index among equal distances
+    return idx, best
+
+
+def rgb_to_yuv(rgba):
+    r = ((rgba >> 16) & 0xFF).astype(np.float64)
+    g = ((rgba >> 8) & 0xFF).astype(np.float64)
+    b = (rgba & 0xFF).astype(np.float64)
+    y = ((0.299 * r + 0.587 * g + 0.114 * b) / 255.0).astype(np.float32)
+    u = ((-0.147 * r - 0.289 * g + 0.436 * b) / 255.0).astype(np.float32)
+    v = ((0.615 * r - 0.515 * g - 0.100 * b) / 255.0).astype(np.float32)
+    return np.stack([y, u, v], 1)
+
+
+def quality_metrics(cloud_a, cloud_b):
+    """cloud_a = original, cloud_b = decoded: numpy arrays of the 32-byte PointXYZRGB dtype (all points finite)."""
+    xa = np.stack([cloud_a["x"], cloud_a["y"], cloud_a["z"]], 1).astype(np.float32)
+    xb = np.stack([cloud_b["x"], cloud_b["y"], cloud_b["z"]], 1).astype(np.float32)
+    ia, da = nearest(xa, xb)
+    _, db = nearest(xb, xa)
+    max_a = np.float32(np.sqrt(np.float32(da.max())))
+    max_b = np.float32(np.sqrt(np.float32(db.max())))
+    rms_a = np.sqrt(da.astype(np.float64).sum() / len(xa))
+    rms_b = np.sqrt(db.astype(np.float64).sum() / len(xb))
+    dist_h = max(max_a, max_b)
+    dist_rms = np.float32(max(rms_a, rms_b))
+    mx = xa.max(axis=0)
+    energy = np.float32(np.float32(mx[0] * mx[0]) + np.float32(mx[1] * mx[1])) + np.float32(mx[2] * mx[2])
+    psnr = np.float32(10) * np.log10(np.float32(energy / np.float32(dist_rms * dist_rms)), dtype=np.float32)
+    ya, yb = rgb_to_yuv(cloud_a["rgba"]), rgb_to_yuv(cloud_b["rgba"][ia])
+    e = (ya - yb).astype(np.float32)
+    mse = (e * e).astype(np.float32).astype(np.float64).sum(axis=0) / len(xa)
+    with np.errstate(divide="ignore"):
+        psnr_yuv = 10 * np.log10(1.0 / mse)
+    return dict(in_point_count=len(xa), out_point_count=len(xb), left_hausdorff=float(max_a), right_hausdorff=float(max_b),
+                symm_hausdorff=float(dist_h), left_rms=float(np.float32(rms_a)), right_rms=float(np.float32(rms_b)),
+                symm_rms=float(dist_rms), psnr_db=float(psnr), psnr_yuv=[float(x) for x in psnr_yuv])
