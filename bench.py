@@ -32,8 +32,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="cfg2", help="cfg2 (headline), cfg2u, cfg1, cfg3, cfg4")
     ap.add_argument("--workers", type=int, default=0, help="host threads (= contexts) per GPU; 0 = auto")
     ap.add_argument("--distinct-frames", type=int, default=4)
@@ -84,16 +84,24 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # testing hook: several ranks on ONE GPU over gloo (a 1-GPU box cannot run RCCL between two ranks)
+    share_gpu = os.environ.get("PCC_BENCH_SHARE_GPU0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as G
     pkg = G.load_package()
     b, syn = pkg.binding, pkg.synthetic
+    trace = (lambda m: print("[rank %d] %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("PCC_BENCH_TRACE") else (lambda m: None)
 
     cfg = syn.CONFIGS[args.workload]
     kw = dict(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
@@ -110,6 +118,7 @@ def main():
     n_distinct = max(1, args.distinct_frames)
     host_frames = [syn.make_frame(args.workload, frame=rank * n_distinct + f) for f in range(n_distinct)]
     dev_frames = [ctx0.upload(f) for f in host_frames]
+    trace("frames uploaded, %d workers" % pipe.workers)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -122,6 +131,7 @@ def main():
     L, B, depth = hot0.n_leaves, hot0.n_branches, hot0.depth
     image_bytes = hot0.image_w * hot0.image_h * 3
 
+    trace("first frame done: L=%d B=%d D=%d" % (L, B, depth))
     warm = max(args.warmup, pipe.n_contexts)
     pipe.encode([dev_frames[s % n_distinct] for s in range(warm)], [n_points] * warm, params, copy=False)
 
@@ -130,18 +140,20 @@ def main():
     prof_ctx = pipe.context(pipe.n_contexts - 1)
     prof_ctx.set_profiling(True)
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
+    trace("warm-up done")
     sync_all()
     t0 = time.perf_counter()
     res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
     ktimes, profiled = pipe.kernel_times()
     prof_ctx.set_profiling(False)
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     nbytes = res[0][0]

@@ -40,7 +40,7 @@ constexpr int kMaxBins = 1 << kMaxDigitBits;  // 512 = one digit per thread in t
 constexpr int kMaxPasses = 7;              // 63 code bits / 9
 constexpr uint32_t kStatusAggregate = 1u << 30, kStatusInclusive = 2u << 30, kStatusValue = (1u << 30) - 1u;
 constexpr int kLookBackGroup = 16;         // tiles per look-back group (two-level look-back)
-constexpr uint32_t kSpinLimit = 1u << 22;  // bounded polling: a lost predecessor becomes an error, not a hang
+constexpr uint32_t kSpinLimit = 1u << 20;  // bounded polling: a lost predecessor becomes an error, not a hang
 
 struct ChunkBox {          // 32 bytes
   float mn[3];

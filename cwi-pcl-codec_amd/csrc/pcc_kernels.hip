@@ -614,11 +614,12 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   const uint32_t count = pass == 0 ? n : st->n_finite;  // pass 0 still holds the non-finite markers
   const uint32_t out_count = st->n_finite;
   const uint32_t n_tiles = (count + kSortTile - 1) / kSortTile;
-  // Tile id: a tile only ever waits for lower tile ids.  A grid that is co-resident as a whole (one
-  // 1024-thread workgroup per CU always fits) may use blockIdx; a larger one takes a ticket, so that
-  // every tile it waits for has started (dispatch order is not promised).
-  const bool ticketed = gridDim.x > 256u;
-  if (ticketed && threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
+  // Tile id = a ticket: a tile only ever waits for lower tile ids, and those belong to workgroups that have
+  // started.  (blockIdx would do only if the whole grid were co-resident; with several frames in flight on
+  // other streams it is not, and workgroups are dispatched per XCD: a resident workgroup could then wait for
+  // one that cannot start because of workgroups waiting the other way round.)
+  const bool ticketed = true;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += kSortThreads) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins; k += kSortThreads) s_match[k] = 0ull;
   for (int k = threadIdx.x; k < kMaxBins; k += kSortThreads) s_hist[k] = 0u;
@@ -881,12 +882,9 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
   __shared__ uint64_t s_prefix;
   __shared__ uint32_t s_tile;
   const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
-  const bool ticketed = gridDim.x > 256u;  // see k_sort_pass
-  if (ticketed) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-  }
-  const uint32_t tile = ticketed ? s_tile : blockIdx.x;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tile id = ticket: see k_sort_pass
+  __syncthreads();
+  const uint32_t tile = s_tile;
   if ((uint64_t)tile * kSortTile >= nfin) return;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, depth = st->depth;
@@ -1100,7 +1098,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
                                                            uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff) {
   PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
-  if (L == 0) return;
+  if (L == 0 || st->error != kErrNone) return;  // after an error upstream the leaf arrays are not to be trusted
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
   const uint32_t m = blockIdx.x;               // MCU row
   if (16u * m >= H) return;
