@@ -76,6 +76,44 @@ def uniform_volume(n, seed, do_normalize=True):
     return _finish(xyz.astype(np.float32), seed, n, do_normalize)
 
 
+def voxelised_body(n, seed, grid=1024, do_normalize=True):
+    """A capture-like frame in the style of the 8i voxelised full bodies (cfg3 stand-in): integer coordinates on a
+    `grid`^3 lattice, one point per occupied voxel of a closed surface (an ellipsoid "torso" with a bumpy radius),
+    stored in raster order of the lattice (z, y, x) -- spatially coherent, unlike the shuffled shells above --
+    with a smooth colour field."""
+    # sample more surface points than needed, snap to the lattice, keep the first n distinct voxels in raster order
+    m = int(n * 1.6) + 1000
+    u, v = _u01(seed, m, 0), _u01(seed, m, 1)
+    ct = 2.0 * u - 1.0
+    st = np.sqrt(np.maximum(0.0, 1.0 - ct * ct))
+    ph = 2.0 * np.pi * v
+    r = 1.0 + 0.08 * np.sin(5 * ph) * st + 0.05 * np.cos(7 * np.arccos(ct))
+    half = grid / 2.0
+    x = half + 0.23 * grid * r * st * np.cos(ph)
+    y = half + 0.23 * grid * r * st * np.sin(ph)
+    z = half + 0.46 * grid * r * ct
+    q = np.stack([np.floor(x), np.floor(y), np.floor(z)], 1).astype(np.int64)
+    q = np.clip(q, 0, grid - 1)
+    code = (q[:, 2] * grid + q[:, 1]) * grid + q[:, 0]
+    code = np.unique(code)            # distinct voxels, raster order
+    if len(code) > n:
+        keep = np.sort(np.argsort(splitmix64(seed, len(code), 3))[:n])   # thin out evenly, keep the order
+        code = code[keep]
+    xyz = np.stack([code % grid, (code // grid) % grid, code // (grid * grid)], 1).astype(np.float32)
+    pts = np.zeros(len(xyz), dtype=POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts["w"] = 1.0
+    if do_normalize:
+        normalize(pts)
+    # smooth colours with a little texture
+    t = xyz / grid
+    col = np.stack([128 + 100 * np.sin(6.0 * t[:, 0] + 2.0 * t[:, 2]), 128 + 100 * np.cos(5.0 * t[:, 1]), 60 + 180 * t[:, 2]], 1)
+    noise = (splitmix64(seed, 3 * len(xyz), 7) % np.uint64(9)).astype(np.int64).reshape(len(xyz), 3) - 4
+    col = np.clip(np.floor(col).astype(np.int64) + noise, 0, 255).astype(np.uint32)
+    pts["rgba"] = col[:, 2] | (col[:, 1] << 8) | (col[:, 0] << 16) | np.uint32(0xFF000000)
+    return pts
+
+
 CONFIGS = {
     # name: (generator, n, seed, codec settings)
     "cfg1": dict(gen="sphere", n=100_000, seed=0xC1, octree_bits=8, color_bits=8, color_coding_type=1,
@@ -86,6 +124,9 @@ CONFIGS = {
                   jpeg_quality=85, keep_centroid=0),
     "cfg3": dict(gen="sphere", n=800_000, seed=0xC3, octree_bits=10, color_bits=8, color_coding_type=1,
                  jpeg_quality=85, keep_centroid=0),
+    # cfg3 with capture-like data: voxelised surface on a 1024^3 lattice in raster order (8i longdress stand-in)
+    "cfg3v": dict(gen="body", n=800_000, seed=0xC3, octree_bits=10, color_bits=8, color_coding_type=1,
+                  jpeg_quality=85, keep_centroid=0),
     "cfg4": dict(gen="uniform", n=10_000_000, seed=0xC4, octree_bits=12, color_bits=0, color_coding_type=1,
                  jpeg_quality=85, keep_centroid=0),
 }
@@ -97,4 +138,6 @@ def make_frame(cfg, frame=0, n=None):
     seed = c["seed"] + frame
     if c["gen"] == "sphere":
         return sphere_shell(n, seed)
+    if c["gen"] == "body":
+        return voxelised_body(n, seed)
     return uniform_volume(n, seed)

@@ -243,6 +243,15 @@ def test_cfg3_gop_of_8_frames(pkg, oracle, ctx):
         assert enc.getPerformanceMetrics() == want.perf
 
 
+def test_cfg3_capture_like_voxelised_frames(pkg, oracle, ctx):
+    """cfg3 stand-in for the 8i sequences: integer lattice coordinates in raster order (spatially coherent input:
+    neighbouring points share their high digits), smooth colours; full size and two settings."""
+    pts = pkg.synthetic.make_frame("cfg3v")
+    assert_matches_oracle(pkg, oracle, ctx, pts, octree_bits=10, color_bits=8, color_coding_type=1, jpeg_quality=85)
+    small = pkg.synthetic.make_frame("cfg3v", frame=1, n=150_000)
+    assert_matches_oracle(pkg, oracle, ctx, small, octree_bits=9, color_bits=8, color_coding_type=1, jpeg_quality=60, keep_centroid=1)
+
+
 def test_cfg4_reduced_parity_and_full_size_properties(pkg, oracle, ctx):
     # parity at 1M points with cfg4's settings (depth 12, geometry only)
     pts = pkg.synthetic.make_frame("cfg4", n=1_000_000)
