@@ -18,12 +18,20 @@ struct PointView {
   uint32_t aligned16;  // base and stride are multiples of 16: x,y,z,w come in one 16-byte load
 };
 
+// defineBoundingBox() before the points are added (the delta path builds its trees in [0,1]^3, impl.hpp:340,426):
+// the box is given instead of grown around the first point; it still grows if a point lies outside.
+struct FixedBox {
+  int enabled;
+  double mn[3], mx[3];
+};
+
 struct LeafParams {
   uint32_t do_color;         // cloud_with_color_
   uint32_t color_reduction;  // colorBitReduction_ (only the PCL colour coder, type 0, ever has one)
   uint32_t do_centroid;      // do_voxel_centroid_enDecoding_
   uint32_t write_image;      // colour coding type 1: emit the snake-mapped 256 x H image
-  uint32_t ablate;           // profiling only (PCC_ABLATE): 1 no colour gather, 2 no colour stores, 4 no occupancy, 8 no simplified
+  uint32_t ablate;           // unused
+  uint32_t simplify_only;    // simplifyPCloud (impl.hpp:318-403): only the simplified cloud, centre = (key + 0.5) * res + min
 };
 
 // Quantiser of the JPEG front end: per component (0 luma, 1 chroma), natural order:
@@ -54,6 +62,8 @@ struct HotPathArgs {
   LeafParams lp;
   int max_passes;  // sort passes to enqueue (the device decides how many do work; more needed => kErrPasses)
   int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
+  FixedBox box;    // defineBoundingBox before addPointsFromInputCloud
+  int stop_after_leaf_scan;  // macroblock trees: only the sorted points and the leaf (= block) arrays are wanted
   ChunkBox* boxes;
   FrameState* state;
   uint64_t* keys_a;

@@ -231,7 +231,7 @@ __device__ __forceinline__ int block_min_int(int v, int* s_red) {
 
 __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n, uint32_t n_chunks,
                                                         const ChunkBox* __restrict__ boxes, double res,
-                                                        int force_pairs, int passes_launched, int do_color,
+                                                        int force_pairs, int passes_launched, int do_color, FixedBox box,
                                                         FrameState* __restrict__ st) {
   __shared__ float s_p[3][kTile];
   __shared__ int s_red;
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     for (int a = 0; a < 3; ++a) {
       mn[a] = __dsub_rn((double)p[a], __ddiv_rn(res, 2.0));
       mx[a] = __dadd_rn((double)p[a], __ddiv_rn(res, 2.0));
+      if (box.enabled) { mn[a] = box.mn[a]; mx[a] = box.mx[a]; }  // defineBoundingBox, then getKeyBitSize as below
     }
     unsigned max_voxels = 2;
     for (int a = 0; a < 3; ++a) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
   // growth event costs a single barrier (the one inside the block-wide minimum).
   double mn[3] = {s_mn[0], s_mn[1], s_mn[2]}, mx[3] = {s_mx[0], s_mx[1], s_mx[2]};
   int depth = s_depth, nev = 1, err = kErrNone;
-  int cur = i0 + 1, loaded = -1, parity = 0;
+  int cur = box.enabled ? i0 : i0 + 1, loaded = -1, parity = 0;  // a given box has to be checked against the first point too
   float px[kItems], py[kItems], pz[kItems];
 #pragma unroll
   for (int k = 0; k < kItems; ++k) px[k] = py[k] = pz[k] = __builtin_nanf("");
@@ -1246,7 +1247,9 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     float c[3];
     if (!lp.do_centroid) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) c[a] = (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
+      for (int a = 0; a < 3; ++a)
+        c[a] = lp.simplify_only ? (float)__dadd_rn(__dmul_rn(__dadd_rn((double)key[a], 0.5), res), st->mn[a])  // genLeafNodeCenterFromOctreeKey
+                                : (float)__dadd_rn(lc[a], __dmul_rn(0.5, res));
     } else {
       float sx = 0.f, sy = 0.f, sz = 0.f;  // pcl::compute3DCentroid: float sums in index order
       for (uint32_t i = ls[r]; i < le[r]; ++i) {
@@ -1257,11 +1260,13 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       const float cntf = (float)(le[r] - ls[r]);
       c[0] = __fdiv_rn(sx, cntf); c[1] = __fdiv_rn(sy, cntf); c[2] = __fdiv_rn(sz, cntf);
       const double prec = (double)0.001f;  // PointCoding default precision (ptv2.h:89-91)
+      if (!lp.simplify_only) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
-        d = max(-127, min(127, d));
-        centroid[3 * (size_t)j + a] = (uint8_t)d;
+        for (int a = 0; a < 3; ++a) {
+          int d = (int)__ddiv_rn(__dsub_rn((double)c[a], lc[a]), prec);
+          d = max(-127, min(127, d));
+          centroid[3 * (size_t)j + a] = (uint8_t)d;
+        }
       }
     }
     if (simplified) {
@@ -1274,6 +1279,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     // child bit on this leaf's path.  The topmost one is itself a new child of an older node: the node
     // opened by the nearest earlier leaf f with t(f) > t(j) (ballot masks inside the tile, binary
     // search over the leaf codes before it).
+    if (lp.simplify_only) continue;
     const int tt = t[r];
     for (int q = 0; q < tt; ++q) {
       const int level = D - tt + q;
@@ -1555,7 +1561,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("begin");
   hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes, reinterpret_cast<uint4*>(sync), sync_vec16);
   PCC_STAMP("k_chunk_boxes");
-  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, passes, (int)a.lp.do_color, a.state);
+  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, passes, (int)a.lp.do_color, a.box, a.state);
   PCC_STAMP("k_bbox_events");
   hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows);
   PCC_STAMP("k_make_keys");
@@ -1569,6 +1575,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
                      a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ);
   PCC_STAMP("k_leaf_scan");
+  if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,

@@ -290,3 +290,53 @@ void pcco_octree_serialize(const pcco_octree *t, const pcco_point *pts, const pc
   f->n_points_in = t->object_count;
   pcco_octree_bbox(t, f->bbox);
 }
+
+/* ---- trees of the delta (inter-frame) path: the box is defined before the points are added ----
+ * OctreePointCloud::defineBoundingBox(min, max) then addPointsFromInputCloud (impl.hpp:340-342, 426-428).
+ * Returns the leaves in depth-first order: key triples, point counts and the concatenated point index lists
+ * (each list in ascending point index).  The caller frees the three arrays. */
+typedef struct { uint32_t *keys, *counts; int *indices; size_t li, pi; unsigned depth; } leaf_dump;
+
+static void dump_rec(const obranch *b, unsigned level, unsigned depth, unsigned key[3], leaf_dump *d) {
+  for (unsigned c = 0; c < 8; c++) {
+    if (!b->child[c]) continue;
+    key[0] = (key[0] << 1) | (!!(c & 4));
+    key[1] = (key[1] << 1) | (!!(c & 2));
+    key[2] = (key[2] << 1) | (!!(c & 1));
+    if (level + 1 == depth) {
+      const oleaf *l = (const oleaf *)b->child[c];
+      d->keys[3 * d->li] = key[0]; d->keys[3 * d->li + 1] = key[1]; d->keys[3 * d->li + 2] = key[2];
+      d->counts[d->li] = (uint32_t)l->n;
+      memcpy(d->indices + d->pi, l->idx, sizeof(int) * (size_t)l->n);
+      d->pi += (size_t)l->n;
+      d->li++;
+    } else {
+      dump_rec((const obranch *)b->child[c], level + 1, depth, key, d);
+    }
+    key[0] >>= 1; key[1] >>= 1; key[2] >>= 1;
+  }
+}
+
+int pcco_tree_with_defined_box(const pcco_point *pts, size_t n, double res, const double box[6],
+                               uint32_t **keys, uint32_t **counts, int **indices, uint64_t *n_leaves,
+                               double bbox_out[6], unsigned *depth) {
+  pcco_octree *t = pcco_octree_new(res);
+  for (int a = 0; a < 3; a++) { t->min[a] = box[a]; t->max[a] = box[3 + a]; }
+  get_key_bit_size(t);   /* defineBoundingBox: leaf_count_ == 0 here */
+  t->bbox_defined = 1;
+  pcco_octree_add_points(t, pts, n);
+  leaf_dump d;
+  size_t L = (size_t)t->leaf_count;
+  d.keys = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (L ? L : 1));
+  d.counts = (uint32_t *)malloc(sizeof(uint32_t) * (L ? L : 1));
+  d.indices = (int *)malloc(sizeof(int) * ((size_t)t->object_count ? (size_t)t->object_count : 1));
+  d.li = d.pi = 0;
+  unsigned key[3] = {0, 0, 0};
+  if (t->depth) dump_rec(t->root, 0, t->depth, key, &d);
+  *keys = d.keys; *counts = d.counts; *indices = d.indices;
+  *n_leaves = L;
+  *depth = t->depth;
+  pcco_octree_bbox(t, bbox_out);
+  pcco_octree_free(t);
+  return 0;
+}

@@ -15,6 +15,10 @@ unsigned pcco_octree_depth(const pcco_octree *t);
 void pcco_octree_bbox(const pcco_octree *t, double bb[6]);
 void pcco_octree_serialize(const pcco_octree *t, const pcco_point *pts, const pcco_params *prm,
                            int cloud_with_color, pcco_frame *f);
+/* delta path: tree with defineBoundingBox() before the points (impl.hpp:340-342, 426-428); leaves in DFS order */
+int pcco_tree_with_defined_box(const pcco_point *pts, size_t n, double res, const double box[6],
+                               uint32_t **keys, uint32_t **counts, int **indices, uint64_t *n_leaves,
+                               double bbox_out[6], unsigned *depth);
 #ifdef __cplusplus
 }
 #endif
