@@ -37,6 +37,7 @@ EXPORTS = [
     "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
     "pcc_quality_metrics",
+    "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
 ]
@@ -83,6 +84,24 @@ class Quality(C.Structure):
                 ("symm_hausdorff", C.c_float), ("left_hausdorff", C.c_float), ("right_hausdorff", C.c_float),
                 ("left_rms", C.c_float), ("right_rms", C.c_float), ("psnr_db", C.c_double), ("psnr_yuv", C.c_double * 3),
                 ("gpu_ms", C.c_float)]
+
+
+class DeltaParams(C.Structure):
+    _fields_ = [("codec", Params), ("icp_on_original", C.c_int32), ("write_out_cloud", C.c_int32),
+                ("icp_max_iterations", C.c_int32), ("icp_var_threshold", C.c_float), ("transformation_epsilon", C.c_float)]
+
+
+class DeltaResult(C.Structure):
+    _fields_ = [("i_data", C.c_void_p), ("i_len", C.c_size_t), ("p_data", C.c_void_p), ("p_len", C.c_size_t),
+                ("out_cloud", C.c_void_p), ("out_n", C.c_size_t), ("macro_block_count", C.c_uint32),
+                ("shared_macroblock_count", C.c_uint32), ("convergence_count", C.c_uint32),
+                ("shared_macroblock_percentage", C.c_float), ("shared_macroblock_convergence_percentage", C.c_float),
+                ("n_intra_points", C.c_uint64), ("n_simplified", C.c_uint64), ("gpu_ms", C.c_float)]
+
+
+DELTA_BLOCK_DTYPE = np.dtype([("i_block", "<i4"), ("n_p", "<u4"), ("n_i", "<u4"), ("do_icp", "<i4"), ("converged", "<i4"),
+                              ("iterations", "<i4"), ("rgb_offsets", "i1", (4,)), ("key", "<u2", (4,)), ("fitness", "<f4"),
+                              ("rt", "<f4", (16,))])
 
 
 class KernelTimes(C.Structure):
@@ -143,6 +162,12 @@ def load_library():
     lib.pcc_pipeline_last_error.restype = C.c_char_p
     lib.pcc_pipeline_last_error.argtypes = [vp]
     lib.pcc_quality_metrics.argtypes = [vp, vp, sz, vp, sz, C.c_double, C.POINTER(Quality)]
+    lib.pcc_encode_delta.argtypes = [vp, vp, sz, vp, sz, C.POINTER(DeltaParams), C.POINTER(DeltaResult)]
+    lib.pcc_delta_blocks.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    lib.pcc_decode_delta.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(DeltaParams), C.POINTER(Cloud)]
+    lib.pcc_host_rigid_compress.restype = sz
+    lib.pcc_host_rigid_compress.argtypes = [vp, vp, sz]
+    lib.pcc_host_rigid_decompress.argtypes = [vp, sz, vp]
     lib.pcc_host_range_encode.restype = sz
     lib.pcc_host_range_encode.argtypes = [vp, sz, vp, sz]
     lib.pcc_host_range_decode.restype = sz
@@ -318,6 +343,39 @@ class Context:
         d["psnr_yuv"] = list(q.psnr_yuv)
         return d
 
+    def encode_delta(self, i_cloud: np.ndarray, p_cloud: np.ndarray, params, icp_on_original=False, write_out_cloud=True,
+                     icp_max_iterations=0, icp_var_threshold=0.0, transformation_epsilon=0.0):
+        """encodePointCloudDeltaFrame (codec.h:181-186): dict with i_stream, p_stream, out_cloud, statistics, blocks."""
+        ic, pc = np.ascontiguousarray(i_cloud), np.ascontiguousarray(p_cloud)
+        dp = DeltaParams()
+        dp.codec = params
+        dp.icp_on_original = 1 if icp_on_original else 0
+        dp.write_out_cloud = 1 if write_out_cloud else 0
+        dp.icp_max_iterations = icp_max_iterations
+        dp.icp_var_threshold = icp_var_threshold
+        dp.transformation_epsilon = transformation_epsilon
+        r = DeltaResult()
+        self._check(self.lib.pcc_encode_delta(self.h, ic.ctypes.data, len(ic), pc.ctypes.data, len(pc), C.byref(dp), C.byref(r)))
+        bp, bn = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.pcc_delta_blocks(self.h, C.byref(bp), C.byref(bn)))
+        out = {k: getattr(r, k) for k, _ in DeltaResult._fields_ if k not in ("i_data", "i_len", "p_data", "p_len", "out_cloud", "out_n")}
+        out["i_stream"] = _bytes_at(r.i_data, r.i_len)
+        out["p_stream"] = _bytes_at(r.p_data, r.p_len)
+        out["out_cloud"] = np.frombuffer(_bytes_at(r.out_cloud, 32 * r.out_n), dtype=POINT_DTYPE).copy()
+        out["blocks"] = np.frombuffer(_bytes_at(bp, DELTA_BLOCK_DTYPE.itemsize * bn.value), dtype=DELTA_BLOCK_DTYPE).copy()
+        return out
+
+    def decode_delta(self, i_cloud: np.ndarray, i_stream: bytes, p_stream: bytes, params):
+        """decodePointCloudDeltaFrame (codec.h:188-191)."""
+        ic = np.ascontiguousarray(i_cloud)
+        a, b2 = np.frombuffer(i_stream, dtype=np.uint8), np.frombuffer(p_stream, dtype=np.uint8)
+        dp = DeltaParams()
+        dp.codec = params
+        c = Cloud()
+        self._check(self.lib.pcc_decode_delta(self.h, ic.ctypes.data, len(ic), a.ctypes.data if len(a) else None, len(a),
+                                              b2.ctypes.data if len(b2) else None, len(b2), C.byref(dp), C.byref(c)))
+        return np.frombuffer(_bytes_at(c.points, 32 * c.n), dtype=POINT_DTYPE).copy()
+
     def set_option(self, name, value):
         self._check(self.lib.pcc_set_option(self.h, name.encode(), int(value)))
 
@@ -473,6 +531,22 @@ class OctreePointCloudCodecV2:
         pts, info = self._ctx.decode_intra(compressed_tree_data_in_arg)
         return pts, info["consumed"]
 
+    def encodePointCloudDeltaFrame(self, icloud_arg, pcloud_arg, icp_on_original=False, write_out_cloud=True):
+        """codec.h:181-186.  Returns (out_cloud_arg, i_coded_data, p_coded_data)."""
+        r = self._ctx.encode_delta(icloud_arg, pcloud_arg, self._p, icp_on_original, write_out_cloud)
+        self._delta = r
+        return r["out_cloud"], r["i_stream"], r["p_stream"]
+
+    def decodePointCloudDeltaFrame(self, icloud_arg, i_coded_data: bytes, p_coded_data: bytes):
+        """codec.h:188-191.  Returns cloud_out_arg."""
+        return self._ctx.decode_delta(icloud_arg, i_coded_data, p_coded_data, self._p)
+
+    def getMacroBlockPercentage(self):        # codec.h:199-202
+        return self._delta["shared_macroblock_percentage"]
+
+    def getMacroBlockConvergencePercentage(self):  # codec.h:204-207
+        return self._delta["shared_macroblock_convergence_percentage"]
+
     def getPerformanceMetrics(self):          # codec.h:193-197
         return list(self._perf)
 
@@ -517,6 +591,25 @@ def host_jpeg_decode(jpg: bytes, max_pixels=1 << 24) -> np.ndarray:
     if rc != PCC_OK:
         raise PccError(rc, "jpeg decode")
     return out[: 3 * w.value * h.value].reshape(h.value, w.value, 3).copy()
+
+
+def host_rigid_compress(tr: np.ndarray):
+    """RigidTransformCoding::compressRigidTransform: 4x4 float -> list of int16."""
+    lib = load_library()
+    m = np.ascontiguousarray(tr, dtype=np.float32).reshape(16)
+    out = np.zeros(16, dtype=np.int16)
+    n = lib.pcc_host_rigid_compress(m.ctypes.data, out.ctypes.data, len(out))
+    return out[:n].tolist()
+
+
+def host_rigid_decompress(comp):
+    lib = load_library()
+    c = np.ascontiguousarray(comp, dtype=np.int16)
+    out = np.zeros(16, dtype=np.float32)
+    rc = lib.pcc_host_rigid_decompress(c.ctypes.data, len(c), out.ctypes.data)
+    if rc != PCC_OK:
+        raise PccError(rc, "rigid transform decompress")
+    return out.reshape(4, 4)
 
 
 def host_snake_perm(w, h):

@@ -15,6 +15,7 @@
 #include "pcc_host_codec.h"
 #include "pcc_kernels.h"
 #include "pcc_quality.h"
+#include "pcc_delta.h"
 
 using namespace pcc;
 
@@ -94,6 +95,21 @@ struct pcc_ctx {
   DevBuf<float> d_qd2;
   DevBuf<double> d_qpart;
   std::vector<double> h_qpart;
+
+  // inter-frame path: sub-contexts for the simplified cloud and the two macroblock trees, block scratch
+  pcc_ctx* sub[3] = {nullptr, nullptr, nullptr};
+  DevBuf<uint8_t> d_delta_i, d_delta_p, d_delta_intra, d_delta_out;
+  DevBuf<uint64_t> d_ifull, d_pfull;
+  DevBuf<float4> d_ixyzc, d_pxyzc, d_cur;
+  DevBuf<uint32_t> d_nn, d_dst_intra, d_dst_out, d_fake_start;
+  DevBuf<BlockResult> d_blocks;
+  DevBuf<float> d_mdec;
+  std::vector<BlockResult> h_blocks;
+  std::vector<uint32_t> h_pstart, h_istart, h_dst_intra, h_dst_out;
+  std::vector<uint64_t> h_ifull;
+  std::vector<float> h_mdec;
+  Bytes p_stream, i_stream;
+  std::vector<pcc_point_xyzrgb> delta_cloud;
 
   // host landing buffers
   PinnedBuf<FrameState> h_state;
@@ -236,6 +252,10 @@ void pcc_destroy(pcc_ctx* c) {
   c->d_qidx.release(); c->d_qd2.release(); c->d_qpart.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
   c->h_simplified.release();
+  for (pcc_ctx*& sc : c->sub) { if (sc) pcc_destroy(sc); sc = nullptr; }
+  c->d_delta_i.release(); c->d_delta_p.release(); c->d_delta_intra.release(); c->d_delta_out.release(); c->d_ifull.release();
+  c->d_pfull.release(); c->d_ixyzc.release(); c->d_pxyzc.release(); c->d_cur.release(); c->d_nn.release(); c->d_dst_intra.release();
+  c->d_dst_out.release(); c->d_fake_start.release(); c->d_blocks.release(); c->d_mdec.release();
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -297,8 +317,9 @@ int pcc_device_upload(pcc_ctx* ctx, void* dev_dst, const void* host_src, size_t 
   return PCC_OK;
 }
 
-int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset,
-                       const pcc_params* prm) {
+// launch of one frame; `box`, `simplify_only`, `stop_after_leaf_scan` are the variations the inter-frame path needs
+static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset, const pcc_params* prm,
+                        const FixedBox* box, int simplify_only, int stop_after_leaf_scan) {
   if (!ctx || !prm) return PCC_ERR_ARG;
   PCC_NEED_GPU();
   if (n && !dev_points) return fail(ctx, PCC_ERR_ARG, "null point array");
@@ -361,10 +382,40 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   a.image = (a.lp.write_image && (ctx->copy_image || !a.coefs)) ? ctx->d_image.p : nullptr;
   a.jpeg_tiles = (a.coefs && ctx->jpeg_on_gpu >= 2) ? ctx->d_jpeg_tiles.p : nullptr;
   a.huff = ctx->d_huff.p;
+  if (box) a.box = *box;
+  a.lp.simplify_only = simplify_only ? 1u : 0u;
+  a.stop_after_leaf_scan = stop_after_leaf_scan;
   ctx->args = a;
   rc = enqueue(ctx);
   if (rc != PCC_OK) return rc;
   ctx->launched = true;
+  return PCC_OK;
+}
+
+int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset,
+                       const pcc_params* prm) {
+  return launch_frame(ctx, dev_points, n, stride, rgb_offset, prm, nullptr, 0, 0);
+}
+
+// wait for the frame's kernels and its FrameState; a frame that needs more sort passes than were enqueued runs again
+static int wait_frame_state(pcc_ctx* ctx) {
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  const FrameState& st = *ctx->h_state.p;
+  if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
+    // deeper tree than the frames before: run the frame again with every pass enqueued
+    ctx->args.max_passes = kMaxPasses;
+    const int rc = enqueue(ctx);
+    if (rc != PCC_OK) return rc;
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  }
+  if (st.n_epochs != 0 && st.error == kErrNone) ctx->pass_hint = st.npasses;
+  if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
+  if (st.error != kErrNone) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
+             st.error, st.depth, kMaxDepth, st.vbits);
+    return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
+  }
   return PCC_OK;
 }
 
@@ -376,27 +427,13 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   memset(out, 0, sizeof(*out));
   if (ctx->n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
   PCC_HIP(hipSetDevice(ctx->device));
-  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  const int src = wait_frame_state(ctx);
   const FrameState& st = *ctx->h_state.p;
-  if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
-    // deeper tree than the frames before: run the frame again with every pass enqueued
-    ctx->args.max_passes = kMaxPasses;
-    const int rc = enqueue(ctx);
-    if (rc != PCC_OK) return rc;
-    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
-  }
-  if (st.n_epochs != 0 && st.error == kErrNone) ctx->pass_hint = st.npasses;
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end);
   out->gpu_ms = ms;
   if (ctx->profiling) ctx->timer.collect(ctx->times);
-  if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
-  if (st.error != kErrNone) {
-    char buf[160];
-    snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
-             st.error, st.depth, kMaxDepth, st.vbits);
-    return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
-  }
+  if (src != PCC_OK) return src;
   const size_t L = st.n_leaves, B = st.n_branches;
   const pcc_params& prm = ctx->params;
   const bool color = prm.do_color_encoding != 0;
@@ -716,6 +753,362 @@ int pcc_restore_scaling(pcc_point_xyzrgb* cloud, size_t n, const float bb_min[3]
     cloud[i].x *= dyn[0]; cloud[i].y *= dyn[1]; cloud[i].z *= dyn[2];
     cloud[i].x += bb_min[0]; cloud[i].y += bb_min[1]; cloud[i].z += bb_min[2];
   }
+  return PCC_OK;
+}
+
+// =====================================================================================================
+// inter-frame ("delta") path: encodePointCloudDeltaFrame / decodePointCloudDeltaFrame (impl.hpp:787-1235)
+// =====================================================================================================
+static_assert(sizeof(pcc_delta_block) == sizeof(BlockResult), "pcc_delta_block mirrors BlockResult");
+
+static uint64_t host_split3(uint64_t x) {
+  x &= 0x1fffffULL;
+  x = (x | x << 32) & 0x1f00000000ffffULL;
+  x = (x | x << 16) & 0x1f0000ff0000ffULL;
+  x = (x | x << 8) & 0x100f00f00f00f00fULL;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+  x = (x | x << 2) & 0x1249249249249249ULL;
+  return x;
+}
+static uint64_t host_morton3(uint32_t kx, uint32_t ky, uint32_t kz) {
+  return (host_split3(kx) << 2) | (host_split3(ky) << 1) | host_split3(kz);
+}
+
+static int delta_subcontexts(pcc_ctx* ctx) {
+  for (pcc_ctx*& sc : ctx->sub)
+    if (!sc) {
+      sc = pcc_create(ctx->device);
+      if (!sc) return fail(ctx, PCC_ERR_HIP, "inter-frame path: cannot create a sub-context");
+    }
+  return PCC_OK;
+}
+
+// generate_macroblock_tree (impl.hpp:411-434): an octree over [0,1]^3 at resolution * macroblock size; the leaves are
+// the macroblocks.  Only the sorted points and the leaf arrays are needed.
+static int launch_block_tree(pcc_ctx* sc, const void* dev_points, size_t n, size_t stride, size_t rgb_off, double res_mb) {
+  pcc_params tp{};
+  tp.octree_resolution = res_mb;
+  tp.point_resolution = res_mb;
+  tp.do_color_encoding = 0;
+  tp.color_bit_resolution = 8;
+  tp.color_coding_type = 3;
+  FixedBox box{};
+  box.enabled = 1;
+  for (int a = 0; a < 3; ++a) { box.mn[a] = 0.0; box.mx[a] = 1.0; }
+  return launch_frame(sc, dev_points, n, stride, rgb_off, &tp, &box, 0, 1);
+}
+
+static int block_tree_of(pcc_ctx* owner, pcc_ctx* sc, const void* dev_points, size_t stride, size_t rgb_off, BlockTree& t) {
+  const int rc = wait_frame_state(sc);
+  if (rc != PCC_OK) return fail(owner, rc, std::string("macroblock tree: ") + sc->err);
+  const FrameState& st = *sc->h_state.p;
+  if (!st.packed) return fail(owner, PCC_ERR_UNSUPPORTED, "macroblock tree: key and point index do not fit 64 bits");
+  t.sorted_keys = (st.npasses & 1) ? sc->d_keys_b.p : sc->d_keys_a.p;
+  t.leaf_start = sc->d_leaf_start.p;
+  t.leaf_code = sc->d_leaf_code.p;
+  t.prefix_code = host_morton3(st.prefix[0], st.prefix[1], st.prefix[2]);
+  t.index_mask = st.ibits >= 64 ? ~0ull : ((1ull << st.ibits) - 1ull);
+  t.n_blocks = st.n_leaves;
+  t.n_points = st.n_finite;
+  t.points = static_cast<const uint8_t*>(dev_points);
+  t.stride = (uint32_t)stride;
+  t.rgb_off = (uint32_t)rgb_off;
+  return PCC_OK;
+}
+
+int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, const pcc_point_xyzrgb* p_cloud, size_t n_p,
+                     const pcc_delta_params* dp, pcc_delta_result* out) {
+  if (!ctx || !dp || !out || (!i_cloud && n_i) || (!p_cloud && n_p)) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  memset(out, 0, sizeof(*out));
+  const pcc_params& cp = dp->codec;
+  if (n_i == 0 || n_p == 0) return fail(ctx, PCC_ERR_EMPTY, "inter-frame coding of an empty cloud");
+  if (n_i >= (1ull << 30) || n_p >= (1ull << 30)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^30 points");
+  if (!(cp.octree_resolution > 0.0) || cp.macroblock_size < 1) return fail(ctx, PCC_ERR_ARG, "octree_resolution / macroblock_size");
+  PCC_HIP(hipSetDevice(ctx->device));
+  { const int rc = delta_subcontexts(ctx); if (rc != PCC_OK) return rc; }
+  pcc_ctx *s_simp = ctx->sub[0], *s_it = ctx->sub[1], *s_pt = ctx->sub[2];
+  const double res = cp.octree_resolution, res_mb = res * (double)cp.macroblock_size;
+
+  PCC_HIP(ctx->d_delta_i.ensure(32 * n_i));
+  PCC_HIP(ctx->d_delta_p.ensure(32 * n_p));
+  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->d_delta_i.p, i_cloud, 32 * n_i, hipMemcpyHostToDevice, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->d_delta_p.p, p_cloud, 32 * n_p, hipMemcpyHostToDevice, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+
+  // the I frame's macroblocks and the simplification of the P frame are independent: two streams
+  int rc = launch_block_tree(s_it, ctx->d_delta_i.p, n_i, 32, 16, res_mb);
+  if (rc != PCC_OK) return fail(ctx, rc, "I macroblock tree: " + s_it->err);
+  const uint8_t* p_points = ctx->d_delta_p.p;
+  size_t p_count = n_p, p_stride = 32, p_rgb = 16;
+  if (!dp->icp_on_original) {  // simplifyPCloud (impl.hpp:318-403): voxel centres (or float centroids) and mean colours
+    pcc_params sp{};
+    sp.octree_resolution = res;
+    sp.point_resolution = res;
+    sp.do_color_encoding = 1;
+    sp.color_bit_resolution = 8;
+    sp.color_coding_type = 3;
+    sp.do_voxel_centroid = cp.do_voxel_centroid;
+    FixedBox box{};
+    box.enabled = 1;
+    for (int a = 0; a < 3; ++a) { box.mn[a] = 0.0; box.mx[a] = 1.0; }
+    rc = launch_frame(s_simp, ctx->d_delta_p.p, n_p, 32, 16, &sp, &box, 1, 0);
+    if (rc != PCC_OK) return fail(ctx, rc, "simplification: " + s_simp->err);
+    rc = wait_frame_state(s_simp);
+    if (rc != PCC_OK) return fail(ctx, rc, "simplification: " + s_simp->err);
+    p_points = reinterpret_cast<const uint8_t*>(s_simp->d_simplified.p);
+    p_count = s_simp->h_state.p->n_leaves;
+    p_stride = 16;
+    p_rgb = 12;
+  }
+  rc = launch_block_tree(s_pt, p_points, p_count, p_stride, p_rgb, res_mb);
+  if (rc != PCC_OK) return fail(ctx, rc, "P macroblock tree: " + s_pt->err);
+
+  DeltaArgs da{};
+  rc = block_tree_of(ctx, s_it, ctx->d_delta_i.p, 32, 16, da.i_tree);
+  if (rc != PCC_OK) return rc;
+  rc = block_tree_of(ctx, s_pt, p_points, p_stride, p_rgb, da.p_tree);
+  if (rc != PCC_OK) return rc;
+  const uint32_t nbi = da.i_tree.n_blocks, nbp = da.p_tree.n_blocks;
+  PCC_HIP(ctx->d_ifull.ensure(nbi));
+  PCC_HIP(ctx->d_pfull.ensure(nbp));
+  PCC_HIP(ctx->d_ixyzc.ensure(da.i_tree.n_points));
+  PCC_HIP(ctx->d_pxyzc.ensure(da.p_tree.n_points));
+  PCC_HIP(ctx->d_cur.ensure(da.i_tree.n_points));
+  PCC_HIP(ctx->d_nn.ensure(da.i_tree.n_points));
+  PCC_HIP(ctx->d_blocks.ensure(nbp));
+  da.i_full = ctx->d_ifull.p; da.p_full = ctx->d_pfull.p;
+  da.i_xyzc = ctx->d_ixyzc.p; da.p_xyzc = ctx->d_pxyzc.p; da.cur = ctx->d_cur.p; da.nn = ctx->d_nn.p;
+  da.results = ctx->d_blocks.p;
+  da.point_resolution = cp.point_resolution;
+  da.max_iterations = dp->icp_max_iterations > 0 ? dp->icp_max_iterations : 50;
+  da.transformation_epsilon = dp->transformation_epsilon > 0.f ? dp->transformation_epsilon : 1e-8f;
+  da.var_threshold = dp->icp_var_threshold > 0.f ? dp->icp_var_threshold : 100.f;
+  da.do_icp_color_offset = cp.do_icp_color_offset ? 1 : 0;
+  launch_delta_blocks(da, ctx->stream);
+  PCC_HIP(hipGetLastError());
+  ctx->h_blocks.resize(nbp);
+  ctx->h_pstart.resize((size_t)nbp + 1);
+  PCC_HIP(hipMemcpyAsync(ctx->h_blocks.data(), ctx->d_blocks.p, (size_t)nbp * sizeof(BlockResult), hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->h_pstart.data(), da.p_tree.leaf_start, ((size_t)nbp + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+
+  // chunks of the predicted blocks, in the depth-first order of the P frame's macroblocks (impl.hpp:1003-1070)
+  const uint32_t kNone = 0xffffffffu;
+  ctx->p_stream.clear();
+  ctx->h_dst_intra.assign(nbp, kNone);
+  ctx->h_dst_out.assign(nbp, kNone);
+  ctx->h_mdec.assign((size_t)nbp * 16, 0.f);
+  uint32_t shared = 0, converged = 0;
+  size_t intra_n = 0, out_n = 0;
+  std::vector<int16_t> comp;
+  for (uint32_t b = 0; b < nbp; ++b) {
+    const BlockResult& r = ctx->h_blocks[b];
+    if (r.i_block >= 0) ++shared;
+    const bool predicted = r.i_block >= 0 && r.do_icp && r.converged;
+    if (predicted) {
+      ++converged;
+      rigid_compress(r.rt, comp);
+      const size_t chunk = 3 * 2 + comp.size() * 2 + (cp.do_icp_color_offset ? 3 : 0);
+      ctx->p_stream.push_back((uint8_t)chunk);
+      for (int a = 0; a < 3; ++a) { const int16_t k = (int16_t)r.key[a]; ctx->p_stream.push_back((uint8_t)(k & 0xff)); ctx->p_stream.push_back((uint8_t)((k >> 8) & 0xff)); }
+      for (int16_t v : comp) { ctx->p_stream.push_back((uint8_t)(v & 0xff)); ctx->p_stream.push_back((uint8_t)((v >> 8) & 0xff)); }
+      if (cp.do_icp_color_offset) for (int a = 0; a < 3; ++a) ctx->p_stream.push_back((uint8_t)r.rgb_offsets[a]);
+      rigid_decompress(comp.data(), comp.size(), &ctx->h_mdec[(size_t)b * 16]);  // the out cloud shows what the decoder will see
+      if (dp->write_out_cloud) { ctx->h_dst_out[b] = (uint32_t)out_n; out_n += r.n_i; }
+    } else {
+      ctx->h_dst_intra[b] = (uint32_t)intra_n; intra_n += r.n_p;
+      if (dp->write_out_cloud) { ctx->h_dst_out[b] = (uint32_t)out_n; out_n += r.n_p; }
+    }
+  }
+
+  PCC_HIP(ctx->d_dst_intra.ensure(nbp));
+  PCC_HIP(ctx->d_dst_out.ensure(nbp));
+  PCC_HIP(ctx->d_mdec.ensure((size_t)nbp * 16));
+  PCC_HIP(ctx->d_delta_intra.ensure(32 * intra_n + 32));
+  PCC_HIP(ctx->d_delta_out.ensure(32 * out_n + 32));
+  PCC_HIP(hipMemcpyAsync(ctx->d_dst_intra.p, ctx->h_dst_intra.data(), (size_t)nbp * 4, hipMemcpyHostToDevice, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->d_dst_out.p, ctx->h_dst_out.data(), (size_t)nbp * 4, hipMemcpyHostToDevice, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(ctx->d_mdec.p, ctx->h_mdec.data(), (size_t)nbp * 64, hipMemcpyHostToDevice, ctx->stream));
+  GatherArgs ga{};
+  ga.i_xyzc = da.i_xyzc; ga.p_xyzc = da.p_xyzc;
+  ga.i_leaf_start = da.i_tree.leaf_start; ga.p_leaf_start = da.p_tree.leaf_start;
+  ga.results = da.results; ga.mdec = ctx->d_mdec.p;
+  ga.dst_intra = ctx->d_dst_intra.p; ga.dst_out = ctx->d_dst_out.p;
+  ga.n_blocks = nbp;
+  ga.do_icp_color_offset = cp.do_icp_color_offset ? 1 : 0;
+  ga.colour_doubled = 0;
+  ga.out_intra = ctx->d_delta_intra.p; ga.out_cloud = ctx->d_delta_out.p;
+  launch_delta_gather(ga, ctx->stream);
+  PCC_HIP(hipGetLastError());
+  ctx->delta_cloud.resize(out_n);
+  if (out_n) PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.data(), ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end);
+
+  // the points that were not predicted go through the intra coder; it is built with the constructor's defaults for the
+  // arguments the reference does not pass (impl.hpp:1089-1101 vs codec.h:108-121), and a fresh coder's first frame has id 1
+  ctx->i_stream.clear();
+  if (intra_n) {
+    pcc_params ip = cp;
+    ip.do_color_encoding = 1;
+    ip.create_scalable = 1;
+    ip.do_connectivity = 0;
+    ip.jpeg_quality = 75;
+    ip.macroblock_size = 16;
+    ip.do_icp_color_offset = 0;
+    ip.frame_id = 1;
+    pcc_bitstream bs;
+    rc = pcc_encode_intra_device(ctx, ctx->d_delta_intra.p, intra_n, 32, 16, &ip, &bs);
+    if (rc != PCC_OK && rc != PCC_ERR_EMPTY) return rc;
+    if (rc == PCC_OK) {
+      ctx->i_stream.assign(bs.data, bs.data + bs.len);
+      ms += ctx->last_hot.gpu_ms;
+    }
+  }
+  out->i_data = ctx->i_stream.data(); out->i_len = ctx->i_stream.size();
+  out->p_data = ctx->p_stream.data(); out->p_len = ctx->p_stream.size();
+  out->out_cloud = ctx->delta_cloud.data(); out->out_n = out_n;
+  out->macro_block_count = nbp; out->shared_macroblock_count = shared; out->convergence_count = converged;
+  out->shared_macroblock_percentage = (float)shared / (float)nbp;                 // impl.hpp:1105-1106
+  out->shared_macroblock_convergence_percentage = (float)converged / (float)shared;
+  out->n_intra_points = intra_n;
+  out->n_simplified = dp->icp_on_original ? 0 : p_count;
+  out->gpu_ms = ms;
+  return PCC_OK;
+}
+
+int pcc_delta_blocks(pcc_ctx* ctx, const pcc_delta_block** blocks, size_t* n) {
+  if (!ctx || !blocks || !n) return PCC_ERR_ARG;
+  *blocks = reinterpret_cast<const pcc_delta_block*>(ctx->h_blocks.data());
+  *n = ctx->h_blocks.size();
+  return PCC_OK;
+}
+
+int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, const uint8_t* i_stream, size_t i_len,
+                     const uint8_t* p_stream, size_t p_len, const pcc_delta_params* dp, pcc_cloud* out) {
+  if (!ctx || !dp || !out || (!i_cloud && n_i) || (!i_stream && i_len) || (!p_stream && p_len)) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  memset(out, 0, sizeof(*out));
+  const pcc_params& cp = dp->codec;
+  if (!(cp.octree_resolution > 0.0) || cp.macroblock_size < 1) return fail(ctx, PCC_ERR_ARG, "octree_resolution / macroblock_size");
+  PCC_HIP(hipSetDevice(ctx->device));
+  ctx->delta_cloud.clear();
+  size_t out_n = 0;
+  if (n_i && p_len) {
+    { const int rc = delta_subcontexts(ctx); if (rc != PCC_OK) return rc; }
+    pcc_ctx* s_it = ctx->sub[1];
+    PCC_HIP(ctx->d_delta_i.ensure(32 * n_i));
+    PCC_HIP(hipMemcpyAsync(ctx->d_delta_i.p, i_cloud, 32 * n_i, hipMemcpyHostToDevice, ctx->stream));
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    int rc = launch_block_tree(s_it, ctx->d_delta_i.p, n_i, 32, 16, cp.octree_resolution * (double)cp.macroblock_size);
+    if (rc != PCC_OK) return fail(ctx, rc, "I macroblock tree: " + s_it->err);
+    DeltaArgs da{};
+    rc = block_tree_of(ctx, s_it, ctx->d_delta_i.p, 32, 16, da.i_tree);
+    if (rc == PCC_OK) {
+      const uint32_t nbi = da.i_tree.n_blocks;
+      PCC_HIP(ctx->d_ifull.ensure(nbi));
+      PCC_HIP(ctx->d_ixyzc.ensure(da.i_tree.n_points));
+      da.i_full = ctx->d_ifull.p; da.i_xyzc = ctx->d_ixyzc.p;
+      launch_delta_blocks(da, ctx->stream);  // no P tree: only the I frame's keys and block-ordered points
+      PCC_HIP(hipGetLastError());
+      ctx->h_ifull.resize(nbi);
+      ctx->h_istart.resize((size_t)nbi + 1);
+      PCC_HIP(hipMemcpyAsync(ctx->h_ifull.data(), ctx->d_ifull.p, (size_t)nbi * 8, hipMemcpyDeviceToHost, ctx->stream));
+      PCC_HIP(hipMemcpyAsync(ctx->h_istart.data(), da.i_tree.leaf_start, ((size_t)nbi + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+      // the chunks (impl.hpp:1135-1200)
+      ctx->h_blocks.clear();
+      ctx->h_mdec.clear();
+      ctx->h_dst_out.clear();
+      size_t pos = 0;
+      const size_t off_bytes = cp.do_icp_color_offset ? 3 : 0;
+      std::vector<int16_t> comp;
+      while (pos < p_len) {
+        const size_t chunk = p_stream[pos++];
+        if (chunk == 0 || pos + chunk > p_len || chunk < 6 + off_bytes) break;
+        int16_t key[3];
+        for (int a = 0; a < 3; ++a) key[a] = (int16_t)(p_stream[pos + 2 * a] | (p_stream[pos + 2 * a + 1] << 8));
+        const size_t n_comp = (chunk - 6 - off_bytes) / 2;
+        comp.resize(n_comp);
+        for (size_t k = 0; k < n_comp; ++k) comp[k] = (int16_t)(p_stream[pos + 6 + 2 * k] | (p_stream[pos + 6 + 2 * k + 1] << 8));
+        BlockResult r{};
+        if (cp.do_icp_color_offset) for (int a = 0; a < 3; ++a) r.rgb_offsets[a] = (int8_t)p_stream[pos + 6 + 2 * n_comp + a];
+        pos += chunk;
+        if (key[0] < 0 || key[1] < 0 || key[2] < 0 || (n_comp != 6 && n_comp < 10)) continue;
+        const uint64_t full = host_morton3((uint32_t)key[0], (uint32_t)key[1], (uint32_t)key[2]);
+        const auto it = std::lower_bound(ctx->h_ifull.begin(), ctx->h_ifull.end(), full);
+        if (it == ctx->h_ifull.end() || *it != full) continue;  // "no corresponding i block"
+        r.i_block = (int32_t)(it - ctx->h_ifull.begin());
+        r.n_i = ctx->h_istart[r.i_block + 1] - ctx->h_istart[r.i_block];
+        float m[16];
+        rigid_decompress(comp.data(), comp.size(), m);
+        ctx->h_blocks.push_back(r);
+        ctx->h_mdec.insert(ctx->h_mdec.end(), m, m + 16);
+        ctx->h_dst_out.push_back((uint32_t)out_n);
+        out_n += r.n_i;
+      }
+      const uint32_t nch = (uint32_t)ctx->h_blocks.size();
+      if (nch) {
+        ctx->h_dst_intra.assign(nch, 0xffffffffu);
+        ctx->h_pstart.assign((size_t)nch + 1, 0u);
+        PCC_HIP(ctx->d_blocks.ensure(nch));
+        PCC_HIP(ctx->d_dst_intra.ensure(nch));
+        PCC_HIP(ctx->d_dst_out.ensure(nch));
+        PCC_HIP(ctx->d_fake_start.ensure((size_t)nch + 1));
+        PCC_HIP(ctx->d_mdec.ensure((size_t)nch * 16));
+        PCC_HIP(ctx->d_delta_out.ensure(32 * out_n + 32));
+        PCC_HIP(hipMemcpyAsync(ctx->d_blocks.p, ctx->h_blocks.data(), (size_t)nch * sizeof(BlockResult), hipMemcpyHostToDevice, ctx->stream));
+        PCC_HIP(hipMemcpyAsync(ctx->d_dst_intra.p, ctx->h_dst_intra.data(), (size_t)nch * 4, hipMemcpyHostToDevice, ctx->stream));
+        PCC_HIP(hipMemcpyAsync(ctx->d_dst_out.p, ctx->h_dst_out.data(), (size_t)nch * 4, hipMemcpyHostToDevice, ctx->stream));
+        PCC_HIP(hipMemcpyAsync(ctx->d_fake_start.p, ctx->h_pstart.data(), ((size_t)nch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        PCC_HIP(hipMemcpyAsync(ctx->d_mdec.p, ctx->h_mdec.data(), (size_t)nch * 64, hipMemcpyHostToDevice, ctx->stream));
+        GatherArgs ga{};
+        ga.i_xyzc = da.i_xyzc; ga.p_xyzc = nullptr;
+        ga.i_leaf_start = da.i_tree.leaf_start; ga.p_leaf_start = ctx->d_fake_start.p;
+        ga.results = ctx->d_blocks.p; ga.mdec = ctx->d_mdec.p;
+        ga.dst_intra = ctx->d_dst_intra.p; ga.dst_out = ctx->d_dst_out.p;
+        ga.n_blocks = nch;
+        ga.do_icp_color_offset = cp.do_icp_color_offset ? 1 : 0;
+        ga.colour_doubled = 1;  // p.r += p.r + offset (impl.hpp:1187-1189)
+        ga.out_intra = nullptr; ga.out_cloud = ctx->d_delta_out.p;
+        launch_delta_gather(ga, ctx->stream);
+        PCC_HIP(hipGetLastError());
+        ctx->delta_cloud.resize(out_n);
+        PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.data(), ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
+        { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+      }
+    } else if (rc != PCC_ERR_EMPTY) {
+      return rc;
+    }
+  }
+  if (i_len) {  // the intra coded points follow the predicted ones (impl.hpp:1207-1229)
+    pcc_cloud ic;
+    const int rc = decode_frame(i_stream, i_len, ctx->dec_points, ic);
+    if (rc != PCC_OK) return fail(ctx, rc, "decode: intra part of the delta frame: header not found, or stream truncated/corrupt");
+    out->params = ic.params; out->depth = ic.depth; out->consumed = ic.consumed;
+    for (int a = 0; a < 6; ++a) out->bbox[a] = ic.bbox[a];
+    ctx->delta_cloud.insert(ctx->delta_cloud.end(), ctx->dec_points.begin(), ctx->dec_points.end());
+  }
+  out->points = ctx->delta_cloud.data();
+  out->n = ctx->delta_cloud.size();
+  return PCC_OK;
+}
+
+size_t pcc_host_rigid_compress(const float tr[16], int16_t* comp_out, size_t cap) {
+  if (!tr || !comp_out) return 0;
+  std::vector<int16_t> comp;
+  rigid_compress(tr, comp);
+  if (comp.size() > cap) return 0;
+  memcpy(comp_out, comp.data(), comp.size() * sizeof(int16_t));
+  return comp.size();
+}
+int pcc_host_rigid_decompress(const int16_t* comp, size_t count, float tr_out[16]) {
+  if (!comp || !tr_out || (count != 6 && count != 10)) return PCC_ERR_ARG;
+  rigid_decompress(comp, count, tr_out);
   return PCC_OK;
 }
 

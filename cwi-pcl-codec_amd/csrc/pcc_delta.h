@@ -71,6 +71,7 @@ struct GatherArgs {
   const uint32_t* dst_out;      // [p blocks] or 0xffffffff
   uint32_t n_blocks;
   int do_icp_color_offset;
+  int colour_doubled;           // decoder: p.r += p.r + offset (impl.hpp:1187-1189); encoder's out cloud: pt.r += offset (impl.hpp:901-905)
   uint8_t* out_intra;           // PointXYZRGB[]
   uint8_t* out_cloud;           // PointXYZRGB[]
 };

@@ -340,8 +340,9 @@ __global__ __launch_bounds__(kDBlock) void k_delta_gather(GatherArgs a) {
       se3(m, p.x, p.y, p.z, x, y, z);
       uint32_t w = __float_as_uint(p.w);
       if (a.do_icp_color_offset) {
-        const uint32_t rr = (((w >> 16) & 0xffu) + (uint32_t)(int)r.rgb_offsets[0]) & 0xffu, gg = (((w >> 8) & 0xffu) + (uint32_t)(int)r.rgb_offsets[1]) & 0xffu,
-                       bb = ((w & 0xffu) + (uint32_t)(int)r.rgb_offsets[2]) & 0xffu;
+        const uint32_t mul = a.colour_doubled ? 2u : 1u;
+        const uint32_t rr = (mul * ((w >> 16) & 0xffu) + (uint32_t)(int)r.rgb_offsets[0]) & 0xffu, gg = (mul * ((w >> 8) & 0xffu) + (uint32_t)(int)r.rgb_offsets[1]) & 0xffu,
+                       bb = (mul * (w & 0xffu) + (uint32_t)(int)r.rgb_offsets[2]) & 0xffu;
         w = (w & 0xff000000u) | (rr << 16) | (gg << 8) | bb;
       }
       store_point(a.out_cloud + (size_t)(dout + k) * 32, x, y, z, w);

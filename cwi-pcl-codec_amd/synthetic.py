@@ -114,6 +114,33 @@ def voxelised_body(n, seed, grid=1024, do_normalize=True):
     return pts
 
 
+def delta_pair(n, seed, grid=256, jitter=0.15):
+    """An (I frame, P frame) pair for the inter-frame path: the I frame is a voxelised body on a `grid`^3 lattice; the P
+    frame is the same surface a moment later -- the whole body turned and shifted by a fraction of a voxel, the top
+    third moved much further (its macroblocks cannot be predicted), every point jittered by `jitter` voxels, some points
+    dropped, colours re-noised and slightly brightened.  Both frames live in the same normalised [0,1]^3 box."""
+    i_cloud = voxelised_body(n, seed, grid=grid)
+    m = len(i_cloud)
+    xyz = np.stack([i_cloud["x"], i_cloud["y"], i_cloud["z"]], 1).astype(np.float64)
+    vox = 1.0 / grid
+    ang = 0.004
+    rot = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+    moved = (xyz - 0.5) @ rot.T + 0.5 + np.array([0.3, -0.2, 0.25]) * vox
+    top = xyz[:, 2] > 0.62
+    moved[top] += np.array([3.7, 2.9, 0.0]) * vox * ((xyz[top, 2:3] - 0.62) * 20.0)
+    moved += (np.stack([_u01(seed, m, 11), _u01(seed, m, 12), _u01(seed, m, 13)], 1) - 0.5) * (2.0 * jitter * vox)
+    keep = (splitmix64(seed, m, 14) % np.uint64(100)) >= np.uint64(7)   # 7 % of the points are not seen again
+    moved = np.clip(moved, 0.001, 0.999)[keep]
+    p_cloud = np.zeros(len(moved), dtype=POINT_DTYPE)
+    p_cloud["x"], p_cloud["y"], p_cloud["z"] = moved[:, 0].astype(np.float32), moved[:, 1].astype(np.float32), moved[:, 2].astype(np.float32)
+    p_cloud["w"] = 1.0
+    col = np.stack([(i_cloud["rgba"] >> 16) & 0xFF, (i_cloud["rgba"] >> 8) & 0xFF, i_cloud["rgba"] & 0xFF], 1).astype(np.int64)[keep]
+    noise = (splitmix64(seed, 3 * len(col), 15) % np.uint64(7)).astype(np.int64).reshape(len(col), 3) - 3
+    col = np.clip(col + noise + np.array([5, 3, -4]), 0, 255).astype(np.uint32)
+    p_cloud["rgba"] = col[:, 2] | (col[:, 1] << 8) | (col[:, 0] << 16) | np.uint32(0xFF000000)
+    return i_cloud, p_cloud
+
+
 CONFIGS = {
     # name: (generator, n, seed, codec settings)
     "cfg1": dict(gen="sphere", n=100_000, seed=0xC1, octree_bits=8, color_bits=8, color_coding_type=1,

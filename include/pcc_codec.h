@@ -219,6 +219,55 @@ typedef struct pcc_quality {
 int pcc_quality_metrics(pcc_ctx *ctx, const pcc_point_xyzrgb *cloud_a, size_t n_a, const pcc_point_xyzrgb *cloud_b,
                         size_t n_b, double cell_hint, pcc_quality *out);
 
+/* ---- encodePointCloudDeltaFrame / decodePointCloudDeltaFrame (codec.h:181-191, impl.hpp:787-1235): predictive frames ----
+ * The P frame is simplified to voxel centres (simplifyPCloud, impl.hpp:318-403), both frames are cut into macroblocks
+ * (octree leaves at octree_resolution * macroblock_size inside [0,1]^3, impl.hpp:411-434); a macroblock that exists in
+ * both frames, passes the size and colour-variance gates (impl.hpp:453-521) and whose ICP converges (impl.hpp:544-567) is
+ * coded as a rigid transform of the I frame's block (p_data); all other points are intra coded (i_data).  Clouds are
+ * host pointers; macroblock trees, gates, one ICP per block and the cloud assembly run on the GPU.
+ * PCL's IterativeClosestPoint is not part of the reference tree: transforms agree with PCL's to ICP convergence
+ * accuracy, not bit for bit ("parity unpinned"). */
+typedef struct pcc_delta_params {
+  pcc_params codec;              /* the coder's configuration: octree_resolution, point_resolution, color_bit_resolution,
+                                    color_coding_type, do_voxel_centroid, macroblock_size, do_icp_color_offset are used */
+  int32_t icp_on_original;       /* argument of encodePointCloudDeltaFrame: skip the simplification */
+  int32_t write_out_cloud;       /* argument: also build the predicted cloud (what the decoder will produce, before the
+                                    intra part's own quantisation) */
+  int32_t icp_max_iterations;    /* icp_max_iterations_ (codec.h: 50); <= 0: default */
+  float icp_var_threshold;       /* icp_var_threshold_ (100); <= 0: default */
+  float transformation_epsilon;  /* transformationepsilon_ (1e-8); <= 0: default */
+} pcc_delta_params;
+
+typedef struct pcc_delta_result {
+  const uint8_t *i_data; size_t i_len;   /* i_coded_data: the intra coded residual points */
+  const uint8_t *p_data; size_t p_len;   /* p_coded_data: chunks  u8 size | 3 x int16 key | 6 or 10 x int16 transform | [3 x int8 rgb] */
+  const pcc_point_xyzrgb *out_cloud; size_t out_n;
+  uint32_t macro_block_count, shared_macroblock_count, convergence_count;
+  float shared_macroblock_percentage;              /* getMacroBlockPercentage() */
+  float shared_macroblock_convergence_percentage;  /* getMacroBlockConvergencePercentage() */
+  uint64_t n_intra_points, n_simplified;
+  float gpu_ms;
+} pcc_delta_result;
+
+/* one macroblock of the P frame as the GPU judged it (inspection / tests) */
+typedef struct pcc_delta_block {
+  int32_t i_block;            /* index of the I frame's macroblock with the same key, -1: none */
+  uint32_t n_p, n_i;          /* points in the P / I block */
+  int32_t do_icp;             /* passed the gates */
+  int32_t converged;          /* ICP converged and fitness < 2 * point_resolution */
+  int32_t iterations;
+  int8_t rgb_offsets[4];
+  uint16_t key[4];            /* x, y, z */
+  float fitness;
+  float rt[16];               /* final transformation, row-major */
+} pcc_delta_block;
+
+int pcc_encode_delta(pcc_ctx *ctx, const pcc_point_xyzrgb *i_cloud, size_t n_i, const pcc_point_xyzrgb *p_cloud, size_t n_p,
+                     const pcc_delta_params *params, pcc_delta_result *out);
+int pcc_delta_blocks(pcc_ctx *ctx, const pcc_delta_block **blocks, size_t *n); /* of the last pcc_encode_delta */
+int pcc_decode_delta(pcc_ctx *ctx, const pcc_point_xyzrgb *i_cloud, size_t n_i, const uint8_t *i_stream, size_t i_len,
+                     const uint8_t *p_stream, size_t p_len, const pcc_delta_params *params, pcc_cloud *out);
+
 /* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
 /* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).
  * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */
@@ -229,6 +278,11 @@ size_t pcc_host_jpeg_encode(const uint8_t *rgb, int w, int h, int quality, uint8
 int pcc_host_jpeg_decode(const uint8_t *jpg, size_t len, uint8_t *rgb, size_t rgb_cap, int *w, int *h);
 /* SnakeGridMapping iterator position (snake_grid_mapping.h:46-71) in closed form */
 uint32_t pcc_host_snake_position(uint32_t i, uint32_t w, uint32_t h);
+
+/* RigidTransformCoding::compressRigidTransform / deCompressRigidTransform (rigid_transform_coding_impl.hpp:63-203):
+ * row-major 4x4 -> 6 int16 (quaternion + translation) or 10 (two rotation rows, sign word, translation) */
+size_t pcc_host_rigid_compress(const float tr[16], int16_t *comp_out, size_t cap);
+int pcc_host_rigid_decompress(const int16_t *comp, size_t count, float tr_out[16]);
 
 /* normalize_pointclouds / restore_scaling for one group (codec.h:216-227, impl.hpp:1871-1986), host side */
 int pcc_normalize_group(pcc_point_xyzrgb **clouds, const size_t *sizes, size_t n_clouds, double bb_expand_factor,
