@@ -12,8 +12,10 @@
 //   per group                             eval.hpp:798-893: deep copy, normalize_pointclouds, per frame encode /
 //                                         decode / computeQualityMetric / csv line / restore_scaling / .ply output
 //   csv header and line                   quality_metrics_impl.hpp:242-285 (same stream formatting: operator<<)
-// Not part of this build: the V1 algorithm, the outlier filter, delta (inter-frame) coding and the VTK windows;
-// asking for them prints a note and goes on without.
+//   delta (predictive) coding branch      eval.hpp:498-527, 854-890 (do_delta_coding, icp_on_original, predictive csv,
+//                                         delta_decoded_pc_<n>.ply)
+// Not part of this build: the V1 algorithm, the outlier filter and the VTK windows; asking for them prints a note
+// and goes on without.
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -413,7 +415,7 @@ struct App {
   std::unique_ptr<Codec> encoder, decoder;
   pcc_ctx* quality_ctx = nullptr;
   int output_index = -1;
-  bool delta_note_given = false;
+  std::ofstream predictive_csv;
 
   ~App() { if (quality_ctx) pcc_destroy(quality_ctx); }
 
@@ -434,6 +436,26 @@ struct App {
     decoder.reset(make());
     encoder->setMacroblockSize(opt.integer("macroblock_size"));
     encoder->setDoICPColorOffset(opt.flag("do_icp_color_offset"));
+  }
+
+  // do_quality_computation (eval.hpp:529-541): computeQualityMetric on the GPU
+  void do_quality_computation(const CloudPtr& reference, const CloudPtr& cloud, QualityMetric& q, double res) {
+    if (!quality_ctx) quality_ctx = pcc_create(0);
+    pcc_quality m;
+    const int rc = quality_ctx ? pcc_quality_metrics(quality_ctx, reinterpret_cast<const pcc_point_xyzrgb*>(reference->points.data()), reference->points.size(),
+                                                     reinterpret_cast<const pcc_point_xyzrgb*>(cloud->points.data()), cloud->points.size(), res, &m)
+                               : PCC_ERR_HIP;
+    if (rc == PCC_OK) {
+      q.in_point_count = m.in_point_count; q.out_point_count = m.out_point_count;
+      q.symm_rms = m.symm_rms; q.symm_hausdorff = m.symm_hausdorff; q.left_hausdorff = m.left_hausdorff;
+      q.right_hausdorff = m.right_hausdorff; q.left_rms = m.left_rms; q.right_rms = m.right_rms; q.psnr_db = m.psnr_db;
+      for (int c = 0; c < 3; ++c) q.psnr_yuv[c] = m.psnr_yuv[c];
+      std::cout << "Symmetric Geometric Hausdorff Distance: " << q.symm_hausdorff << "\nSymmetric Geometric Root Mean Square Distance: "
+                << q.symm_rms << "\nGeometric PSNR: " << q.psnr_db << " dB\nA->B color psnr Y: " << (float)q.psnr_yuv[0] << " dB U: "
+                << (float)q.psnr_yuv[1] << " dB V: " << (float)q.psnr_yuv[2] << " dB\n";
+    } else {
+      std::cerr << "quality computation failed: " << (quality_ctx ? pcc_last_error(quality_ctx) : "no GPU") << "\n";
+    }
   }
 
   bool evaluate_group(std::vector<CloudPtr>& group, const std::string& settings, std::ofstream& intra_csv) {
@@ -467,22 +489,7 @@ struct App {
         q.decoding_time_ms = ms_since(t0);
       }
       if (opt.flag("do_quality_computation")) {  // eval.hpp:836-843; computed on the normalised clouds
-        if (!quality_ctx) quality_ctx = pcc_create(0);
-        pcc_quality m;
-        const int rc = quality_ctx ? pcc_quality_metrics(quality_ctx, reinterpret_cast<const pcc_point_xyzrgb*>(pc->points.data()), pc->points.size(),
-                                                         reinterpret_cast<const pcc_point_xyzrgb*>(output->points.data()), output->points.size(), res, &m)
-                                   : PCC_ERR_HIP;
-        if (rc == PCC_OK) {
-          q.in_point_count = m.in_point_count; q.out_point_count = m.out_point_count;
-          q.symm_rms = m.symm_rms; q.symm_hausdorff = m.symm_hausdorff; q.left_hausdorff = m.left_hausdorff;
-          q.right_hausdorff = m.right_hausdorff; q.left_rms = m.left_rms; q.right_rms = m.right_rms; q.psnr_db = m.psnr_db;
-          for (int c = 0; c < 3; ++c) q.psnr_yuv[c] = m.psnr_yuv[c];
-          std::cout << "Symmetric Geometric Hausdorff Distance: " << q.symm_hausdorff << "\nSymmetric Geometric Root Mean Square Distance: "
-                    << q.symm_rms << "\nGeometric PSNR: " << q.psnr_db << " dB\nA->B color psnr Y: " << (float)q.psnr_yuv[0] << " dB U: "
-                    << (float)q.psnr_yuv[1] << " dB V: " << (float)q.psnr_yuv[2] << " dB\n";
-        } else {
-          std::cerr << "quality computation failed: " << (quality_ctx ? pcc_last_error(quality_ctx) : "no GPU") << "\n";
-        }
+        do_quality_computation(pc, output, q, res);
         if (!opt.str("intra_frame_quality_csv").empty()) q.print_csv_line(settings, intra_csv);
       }
       CloudPtr rescaled(new Cloud(*output));
@@ -492,9 +499,42 @@ struct App {
         name << opt.str("output_directory") << "/pointcloud_" << output_index++ << ".ply";
         write_ply(name.str(), *rescaled);
       }
-      if (opt.flag("do_delta_coding") && !delta_note_given) {
-        std::cerr << "note: delta (inter-frame) coding is not part of this build (SURVEY.md 8f); frames are intra coded only\n";
-        delta_note_given = true;
+      // test and evaluation of the iterative-closest-point predictive coding (eval.hpp:853-890)
+      if (opt.flag("do_delta_coding") && f >= 0.0 && i + 1 < working_group.size()) {
+        CloudPtr predicted(new Cloud());
+        std::cout << " delta coding frame nr " << i + 1 << std::endl;
+        std::stringstream p_frame_pdat, p_frame_idat;
+        QualityMetric pq;
+        const bool icp_on_original = opt.flag("icp_on_original");
+        {  // do_delta_encoding (eval.hpp:498-514)
+          const auto t0 = std::chrono::steady_clock::now();
+          encoder->encodePointCloudDeltaFrame(icp_on_original ? pc : encoder->getOutputCloud(), working_group[i + 1], predicted, p_frame_idat, p_frame_pdat,
+                                              icp_on_original, false);
+          pq.encoding_time_ms = ms_since(t0);
+          pq.byte_count_octree_layer = (size_t)p_frame_idat.tellp();
+          pq.byte_count_centroid_layer = (size_t)p_frame_pdat.tellp();
+          pq.compressed_size = pq.byte_count_octree_layer + pq.byte_count_centroid_layer;
+          pq.byte_count_color_layer = 0;
+        }
+        std::cout << " shared macroblocks " << encoder->getMacroBlockPercentage() << " of which icp converged "
+                  << encoder->getMacroBlockConvergencePercentage() << std::endl;
+        std::cout << " encoded a predictive frame: coded " << pq.byte_count_octree_layer << " bytes intra and " << pq.byte_count_centroid_layer
+                  << " inter frame encoded " << std::endl;
+        {  // do_delta_decoding (eval.hpp:516-527): from the decoded I frame
+          const auto t0 = std::chrono::steady_clock::now();
+          encoder->decodePointCloudDeltaFrame(output, predicted, p_frame_idat, p_frame_pdat);
+          pq.decoding_time_ms = ms_since(t0);
+        }
+        if (opt.flag("do_quality_computation")) {
+          do_quality_computation(working_group[i + 1], predicted, pq, res);
+          if (predictive_csv.is_open()) pq.print_csv_line(settings, predictive_csv);
+        }
+        if (f > 0.0) Codec::restore_scaling(predicted, bb);
+        if (!opt.str("output_directory").empty()) {
+          std::ostringstream name;
+          name << opt.str("output_directory") << "/delta_decoded_pc_" << output_index << ".ply";
+          write_ply(name.str(), *predicted);
+        }
       }
     }
     return true;
@@ -540,8 +580,8 @@ struct App {
       QualityMetric::print_csv_header(intra_csv);
     }
     if (!opt.str("predictive_quality_csv").empty()) {
-      std::ofstream predictive(opt.str("predictive_quality_csv").c_str());
-      QualityMetric::print_csv_header(predictive);
+      predictive_csv.open(opt.str("predictive_quality_csv").c_str());
+      QualityMetric::print_csv_header(predictive_csv);
     }
     const int group_size = opt.integer("group_size");
     std::vector<CloudPtr> group;

@@ -97,7 +97,7 @@ struct pcc_ctx {
   std::vector<double> h_qpart;
 
   // inter-frame path: sub-contexts for the simplified cloud and the two macroblock trees, block scratch
-  pcc_ctx* sub[3] = {nullptr, nullptr, nullptr};
+  pcc_ctx* sub[4] = {nullptr, nullptr, nullptr, nullptr};  // simplification, I blocks, P blocks, residual intra coder
   DevBuf<uint8_t> d_delta_i, d_delta_p, d_delta_intra, d_delta_out;
   DevBuf<uint64_t> d_ifull, d_pfull;
   DevBuf<float4> d_ixyzc, d_pxyzc, d_cur;
@@ -962,11 +962,12 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
     ip.do_icp_color_offset = 0;
     ip.frame_id = 1;
     pcc_bitstream bs;
-    rc = pcc_encode_intra_device(ctx, ctx->d_delta_intra.p, intra_n, 32, 16, &ip, &bs);
-    if (rc != PCC_OK && rc != PCC_ERR_EMPTY) return rc;
+    pcc_ctx* s_intra = ctx->sub[3];  // a coder of its own, as in the reference: this one's getOutputCloud() stays the I frame's
+    rc = pcc_encode_intra_device(s_intra, ctx->d_delta_intra.p, intra_n, 32, 16, &ip, &bs);
+    if (rc != PCC_OK && rc != PCC_ERR_EMPTY) return fail(ctx, rc, "residual intra coder: " + s_intra->err);
     if (rc == PCC_OK) {
       ctx->i_stream.assign(bs.data, bs.data + bs.len);
-      ms += ctx->last_hot.gpu_ms;
+      ms += s_intra->last_hot.gpu_ms;
     }
   }
   out->i_data = ctx->i_stream.data(); out->i_len = ctx->i_stream.size();

@@ -137,15 +137,52 @@ class OctreePointCloudCodecV2 {
     return c;
   }
 
-  virtual void encodePointCloudDeltaFrame(const PointCloudConstPtr&, const PointCloudConstPtr&, PointCloudPtr&, std::ostream&,
-                                          std::ostream&, bool = false, bool = false) {
-    throw std::logic_error("encodePointCloudDeltaFrame: inter-frame coding is not part of this build (SURVEY.md 8f)");
+  // codec.h:181-186 / impl.hpp:787-1118
+  virtual void encodePointCloudDeltaFrame(const PointCloudConstPtr& icloud_arg, const PointCloudConstPtr& pcloud_arg, PointCloudPtr& out_cloud_arg,
+                                          std::ostream& i_coded_data, std::ostream& p_coded_data, bool icp_on_original = false,
+                                          bool write_out_cloud = true) {
+    pcc_delta_params dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.codec = prm_;
+    dp.icp_on_original = icp_on_original;
+    dp.write_out_cloud = write_out_cloud;
+    pcc_delta_result r;
+    const int rc = pcc_encode_delta(ctx_, reinterpret_cast<const pcc_point_xyzrgb*>(icloud_arg->points.data()), icloud_arg->points.size(),
+                                    reinterpret_cast<const pcc_point_xyzrgb*>(pcloud_arg->points.data()), pcloud_arg->points.size(), &dp, &r);
+    if (rc != PCC_OK) throw std::runtime_error(std::string("encodePointCloudDeltaFrame: ") + pcc_last_error(ctx_));
+    i_coded_data.write(reinterpret_cast<const char*>(r.i_data), (std::streamsize)r.i_len);
+    p_coded_data.write(reinterpret_cast<const char*>(r.p_data), (std::streamsize)r.p_len);
+    if (write_out_cloud && out_cloud_arg) {  // push_back onto whatever the caller had in it (impl.hpp:899-935)
+      const size_t before = out_cloud_arg->points.size();
+      out_cloud_arg->points.resize(before + r.out_n);
+      if (r.out_n) memcpy(static_cast<void*>(out_cloud_arg->points.data() + before), r.out_cloud, r.out_n * sizeof(PointT));
+      out_cloud_arg->width = (uint32_t)out_cloud_arg->points.size();
+      out_cloud_arg->height = 1;
+    }
+    shared_macroblock_percentage_ = r.shared_macroblock_percentage;
+    shared_macroblock_convergence_percentage_ = r.shared_macroblock_convergence_percentage;
   }
-  virtual void decodePointCloudDeltaFrame(const PointCloudConstPtr&, PointCloudPtr&, std::istream&, std::istream&) {
-    throw std::logic_error("decodePointCloudDeltaFrame: inter-frame coding is not part of this build (SURVEY.md 8f)");
+  // codec.h:188-191 / impl.hpp:1120-1235
+  virtual void decodePointCloudDeltaFrame(const PointCloudConstPtr& icloud_arg, PointCloudPtr& cloud_out_arg, std::istream& i_coded_data,
+                                          std::istream& p_coded_data) {
+    std::vector<char> ib((std::istreambuf_iterator<char>(i_coded_data)), std::istreambuf_iterator<char>());
+    std::vector<char> pb((std::istreambuf_iterator<char>(p_coded_data)), std::istreambuf_iterator<char>());
+    pcc_delta_params dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.codec = prm_;
+    pcc_cloud out;
+    const int rc = pcc_decode_delta(ctx_, reinterpret_cast<const pcc_point_xyzrgb*>(icloud_arg->points.data()), icloud_arg->points.size(),
+                                    reinterpret_cast<const uint8_t*>(ib.data()), ib.size(), reinterpret_cast<const uint8_t*>(pb.data()),
+                                    pb.size(), &dp, &out);
+    if (rc != PCC_OK) throw std::runtime_error(std::string("decodePointCloudDeltaFrame: ") + pcc_last_error(ctx_));
+    const size_t before = cloud_out_arg->points.size();
+    cloud_out_arg->points.resize(before + out.n);
+    if (out.n) memcpy(static_cast<void*>(cloud_out_arg->points.data() + before), out.points, out.n * sizeof(PointT));
+    cloud_out_arg->width = (uint32_t)cloud_out_arg->points.size();
+    cloud_out_arg->height = 1;
   }
-  float getMacroBlockPercentage() { return 0.0f; }             // codec.h:200-204
-  float getMacroBlockConvergencePercentage() { return 0.0f; }  // codec.h:207-210
+  float getMacroBlockPercentage() { return shared_macroblock_percentage_; }                        // codec.h:200-204
+  float getMacroBlockConvergencePercentage() { return shared_macroblock_convergence_percentage_; }  // codec.h:207-210
 
   // codec.h:223-227 (vectors of dyn_range/offset are unused by the reference as well)
   static BoundingBox normalize_pointclouds(std::vector<PointCloudPtr>& point_clouds, std::vector<BoundingBox>& bounding_boxes,
@@ -174,6 +211,7 @@ class OctreePointCloudCodecV2 {
   bool show_statistics_;
   uint32_t frame_id_;
   uint64_t perf_[3];
+  float shared_macroblock_percentage_ = 0.f, shared_macroblock_convergence_percentage_ = 0.f;
 };
 
 }  // namespace io

@@ -127,3 +127,36 @@ def test_app_group_loop_matches_the_oracle(pkg, oracle, tmp_path):
         got = np.loadtxt(str(tmp_path / "out" / ("pointcloud_%d.ply" % i)), skiprows=11)
         assert got.shape == (r.n_leaves, 6)
         assert np.allclose(got[:, 0], back["x"], rtol=1e-5, atol=1e-6) and np.array_equal(got[:, 3].astype(np.uint32), (back["rgba"] >> 16) & 0xFF)
+
+
+@pytest.mark.gpu
+def test_app_delta_coding_branch(pkg, tmp_path):
+    """do_delta_coding: every frame but the last of a group also predicts its successor (eval.hpp:853-890): one line per
+    predicted frame in the predictive csv, one delta_decoded_pc_<n>.ply each, sizes as the codec class reports them."""
+    i_cloud, p_cloud = pkg.synthetic.delta_pair(20_000, 9, grid=256)
+    d = tmp_path / "in"
+    d.mkdir()
+    (tmp_path / "out").mkdir()
+    _write_ply(str(d / "f0.ply"), i_cloud, binary=True)
+    _write_ply(str(d / "f1.ply"), p_cloud, binary=True)
+    p = subprocess.run([APP, "-b", "8", "--color_bits=8", "--color_coding_type=1", "--jpeg_quality=85", "--group_size=2", "--bb_expand_factor=0.0",
+                        "--do_delta_coding=1", "--do_quality_computation=1", "--output_directory=out", "-i", str(d)],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert " delta coding frame nr 1" in p.stdout
+    lines = open(tmp_path / "predictive_quality.csv").read().splitlines()
+    assert lines[0] == CSV_HEADER and len(lines) == 2
+    col = lines[1].split(";")
+    # the same through the class interface: I frame = the decoded (simplified) first frame
+    B = pkg.binding
+    codec = B.OctreePointCloudCodecV2(B.MANUAL_CONFIGURATION, False, 1 / 256, 1 / 256, True, 0, True, 8, 1, False, False, False, 85)
+    codec.encodePointCloud(i_cloud)
+    i_simplified = codec.getOutputCloud()
+    _, i_data, p_data = codec.encodePointCloudDeltaFrame(i_simplified, p_cloud, False, False)
+    assert codec.getOutputCloud().tobytes() == i_simplified.tobytes()   # the residual coder is a separate object (impl.hpp:1089)
+    assert int(col[1]) == len(p_cloud)
+    assert int(col[3]) == len(i_data) + len(p_data)
+    dec = codec.decodePointCloudDeltaFrame(codec.getOutputCloud(), i_data, p_data)
+    assert int(col[2]) == len(dec)
+    got = np.loadtxt(str(tmp_path / "out" / "delta_decoded_pc_1.ply"), skiprows=11)
+    assert got.shape == (len(dec), 6)
