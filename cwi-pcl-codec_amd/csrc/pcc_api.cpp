@@ -882,6 +882,8 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   da.i_xyzc = ctx->d_ixyzc.p; da.p_xyzc = ctx->d_pxyzc.p; da.cur = ctx->d_cur.p; da.nn = ctx->d_nn.p;
   da.results = ctx->d_blocks.p;
   da.point_resolution = cp.point_resolution;
+  da.octree_resolution = res;
+  da.macroblock_size = cp.macroblock_size;
   da.max_iterations = dp->icp_max_iterations > 0 ? dp->icp_max_iterations : 50;
   da.transformation_epsilon = dp->transformation_epsilon > 0.f ? dp->transformation_epsilon : 1e-8f;
   da.var_threshold = dp->icp_var_threshold > 0.f ? dp->icp_var_threshold : 100.f;

@@ -49,6 +49,8 @@ struct DeltaArgs {
   uint32_t* nn;                // [n_i] scratch: nearest target of every source point
   BlockResult* results;        // [p blocks]
   double point_resolution;
+  double octree_resolution;    // voxel size of the coder; a macroblock is macroblock_size voxels a side
+  int macroblock_size;
   int max_iterations;
   float transformation_epsilon;
   float var_threshold;

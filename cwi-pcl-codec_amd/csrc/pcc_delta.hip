@@ -51,8 +51,12 @@ __global__ __launch_bounds__(kDBlock) void k_block_points(BlockTree t, float4* _
 
 // one thread per macroblock of the predictive frame: partner in the I frame, gates, colour offsets
 __global__ __launch_bounds__(kDBlock) void k_block_match(DeltaArgs a) {
-  const uint32_t b = blockIdx.x * kDBlock + threadIdx.x;
-  if (b >= a.p_tree.n_blocks) return;
+  // two lanes per macroblock: lane 0 takes the I frame's points, lane 1 the P frame's (the colour statistics are
+  // sequential sums in point order, impl.hpp:470-517: the only parallelism inside a block is between its two clouds)
+  const uint32_t t = blockIdx.x * kDBlock + threadIdx.x;
+  const uint32_t b = min(t >> 1, a.p_tree.n_blocks - 1);
+  const bool owner = (t >> 1) < a.p_tree.n_blocks && (t & 1u) == 0;
+  const int side = (int)(t & 1u);
   BlockResult r;
   const uint64_t key = a.p_full[b];
   r.key[0] = (uint16_t)compact3_21(key >> 2); r.key[1] = (uint16_t)compact3_21(key >> 1); r.key[2] = (uint16_t)compact3_21(key); r.key[3] = 0;
@@ -68,62 +72,50 @@ __global__ __launch_bounds__(kDBlock) void k_block_match(DeltaArgs a) {
   r.do_icp = 0; r.converged = 0; r.iterations = 0; r.fitness = 0.f;
   r.rgb_offsets[0] = r.rgb_offsets[1] = r.rgb_offsets[2] = r.rgb_offsets[3] = 0;
   for (int k = 0; k < 16; ++k) r.rt[k] = (k % 5 == 0) ? 1.f : 0.f;
+  uint32_t i0 = 0;
+  bool do_icp = false;
   if (r.i_block >= 0) {
-    const uint32_t i0 = a.i_tree.leaf_start[r.i_block], i1 = a.i_tree.leaf_start[r.i_block + 1];
-    r.n_i = i1 - i0;
+    i0 = a.i_tree.leaf_start[r.i_block];
+    r.n_i = a.i_tree.leaf_start[r.i_block + 1] - i0;
     // impl.hpp:453-456
-    bool do_icp = r.n_p > 6 ? ((double)r.n_p < (double)r.n_i * 2) && ((double)r.n_p >= (double)r.n_i * 0.5) : false;
-    if (do_icp) {  // colour means and variances, sequential double sums in point order (impl.hpp:470-517)
-      double av[2][3], var[2];
-      for (int s = 0; s < 2; ++s) {
-        const float4* pts = s == 0 ? a.i_xyzc + i0 : a.p_xyzc + p0;
-        const uint32_t n = s == 0 ? r.n_i : r.n_p;
-        double m[3] = {0, 0, 0};
-        for (uint32_t k = 0; k < n; ++k) {
-          const uint32_t w = __float_as_uint(pts[k].w);
-          m[0] += (double)((w >> 16) & 0xffu); m[1] += (double)((w >> 8) & 0xffu); m[2] += (double)(w & 0xffu);
-        }
-        for (int c = 0; c < 3; ++c) m[c] = __ddiv_rn(m[c], (double)n);
-        double v = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-          const uint32_t w = __float_as_uint(pts[k].w);
-          const double dr = __dsub_rn((double)((w >> 16) & 0xffu), m[0]), dg = __dsub_rn((double)((w >> 8) & 0xffu), m[1]),
-                       db = __dsub_rn((double)(w & 0xffu), m[2]);
-          const double val = __dadd_rn(__dadd_rn(__dmul_rn(dr, dr), __dmul_rn(dg, dg)), __dmul_rn(db, db));
-          v = __dadd_rn(v, val);
-        }
-        var[s] = __ddiv_rn(v, (double)(3 * n));
-        for (int c = 0; c < 3; ++c) av[s][c] = m[c];
-      }
-      if (var[0] > (double)a.var_threshold || var[1] > (double)a.var_threshold) do_icp = false;
-      if (a.do_icp_color_offset) {  // impl.hpp:528-535 (computed before the variance gate returns)
-        for (int c = 0; c < 3; ++c) {
-          const double d = __dsub_rn(av[1][c], av[0][c]);
-          if (fabs(d) < 32) r.rgb_offsets[c] = (int8_t)d;
-        }
-      }
-    }
-    r.do_icp = do_icp ? 1 : 0;
+    do_icp = r.n_p > 6 ? ((double)r.n_p < (double)r.n_i * 2) && ((double)r.n_p >= (double)r.n_i * 0.5) : false;
   }
+  double m[3] = {0, 0, 0}, var = 0;
+  if (do_icp) {  // colour mean and variance of this lane's cloud
+    const float4* pts = side == 0 ? a.i_xyzc + i0 : a.p_xyzc + p0;
+    const uint32_t n = side == 0 ? r.n_i : r.n_p;
+    uint32_t sr = 0, sg = 0, sb = 0;  // sums of 8-bit values: exact in any arithmetic (the reference adds them in double)
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t w = __float_as_uint(pts[k].w);
+      sr += (w >> 16) & 0xffu; sg += (w >> 8) & 0xffu; sb += w & 0xffu;
+    }
+    m[0] = __ddiv_rn((double)sr, (double)n); m[1] = __ddiv_rn((double)sg, (double)n); m[2] = __ddiv_rn((double)sb, (double)n);
+    double v = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t w = __float_as_uint(pts[k].w);
+      const double dr = __dsub_rn((double)((w >> 16) & 0xffu), m[0]), dg = __dsub_rn((double)((w >> 8) & 0xffu), m[1]),
+                   db = __dsub_rn((double)(w & 0xffu), m[2]);
+      const double val = __dadd_rn(__dadd_rn(__dmul_rn(dr, dr), __dmul_rn(dg, dg)), __dmul_rn(db, db));
+      v = __dadd_rn(v, val);
+    }
+    var = __ddiv_rn(v, (double)(3 * n));
+  }
+  // the partner lane's numbers (lanes 2k and 2k+1 hold the same block and took the same branches)
+  const double om0 = __shfl_xor(m[0], 1), om1 = __shfl_xor(m[1], 1), om2 = __shfl_xor(m[2], 1), ovar = __shfl_xor(var, 1);
+  if (!owner) return;
+  if (do_icp) {
+    if (var > (double)a.var_threshold || ovar > (double)a.var_threshold) do_icp = false;
+    if (a.do_icp_color_offset) {  // impl.hpp:528-535 (computed before the variance gate returns)
+      const double d[3] = {__dsub_rn(om0, m[0]), __dsub_rn(om1, m[1]), __dsub_rn(om2, m[2])};  // P mean - I mean
+      for (int c = 0; c < 3; ++c)
+        if (fabs(d[c]) < 32) r.rgb_offsets[c] = (int8_t)d[c];
+    }
+  }
+  r.do_icp = do_icp ? 1 : 0;
   a.results[b] = r;
 }
 
 // ---- ICP helpers ----
-__device__ __forceinline__ float block_sum_f(float v, float* s_red) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
-__device__ __forceinline__ double block_sum_d(double v, double* s_red) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
-
 __device__ __forceinline__ void nearest_in(const float4* __restrict__ tgt, uint32_t nt, float x, float y, float z, uint32_t& best_j, float& best) {
   best = FLT_MAX;
   best_j = 0;
@@ -144,82 +136,168 @@ __device__ __forceinline__ void se3(const float* m, float x, float y, float z, f
 }
 
 // Rotation of Eigen::umeyama (without scaling) from the 3x3 covariance sigma = (1/n) sum (dst - dm)(src - sm)^T:
-// R = U diag(1, 1, +-1) V^T.  SVD by Jacobi rotations on sigma^T sigma, in double.
-__device__ void umeyama_rotation(const float sg[9], float Rm[9]) {
-  double A[3][3], B[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) A[r][c] = (double)sg[3 * r + c];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) B[r][c] = A[0][r] * A[0][c] + A[1][r] * A[1][c] + A[2][r] * A[2][c];
-  for (int sweep = 0; sweep < 12; ++sweep) {
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (fabs(B[p][q]) < 1e-300) continue;
-        const double theta = (B[q][q] - B[p][p]) / (2.0 * B[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) { const double bkp = B[k][p], bkq = B[k][q]; B[k][p] = c * bkp - s * bkq; B[k][q] = s * bkp + c * bkq; }
-        for (int k = 0; k < 3; ++k) { const double bpk = B[p][k], bqk = B[q][k]; B[p][k] = c * bpk - s * bqk; B[q][k] = s * bpk + c * bqk; }
-        for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
-      }
-  }
-  int ord[3] = {0, 1, 2};  // singular values descending
-  for (int i = 0; i < 2; ++i)
-    for (int j = i + 1; j < 3; ++j)
-      if (B[ord[j]][ord[j]] > B[ord[i]][ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
-  double Vs[3][3], U[3][3], sv[3];
-  for (int i = 0; i < 3; ++i) {
-    sv[i] = sqrt(fmax(B[ord[i]][ord[i]], 0.0));
-    for (int k = 0; k < 3; ++k) Vs[k][i] = V[k][ord[i]];
-  }
-  const double tiny = 1e-12 * fmax(sv[0], 1e-300);
-  for (int i = 0; i < 3; ++i) {
-    if (sv[i] > tiny) {
-      for (int k = 0; k < 3; ++k) U[k][i] = (A[k][0] * Vs[0][i] + A[k][1] * Vs[1][i] + A[k][2] * Vs[2][i]) / sv[i];
-    } else if (i == 2) {  // complete the basis
-      U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
-      U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
-      U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
-    } else if (i == 1) {  // rank 1: any unit vector orthogonal to u0
-      const double ax = fabs(U[0][0]), ay = fabs(U[1][0]), az = fabs(U[2][0]);
-      double e[3] = {0, 0, 0};
-      e[(ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2)] = 1.0;
-      const double dot = e[0] * U[0][0] + e[1] * U[1][0] + e[2] * U[2][0];
-      double w[3] = {e[0] - dot * U[0][0], e[1] - dot * U[1][0], e[2] - dot * U[2][0]};
-      const double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-      for (int k = 0; k < 3; ++k) U[k][1] = w[k] / nw;
-    } else {  // zero matrix
-      U[0][0] = 1; U[1][0] = 0; U[2][0] = 0;
-    }
-  }
-  auto det3 = [](double M[3][3]) {
-    return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-  };
-  const double s2 = det3(U) * det3(Vs) < 0 ? -1.0 : 1.0;
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) Rm[3 * r + c] = (float)(U[r][0] * Vs[c][0] + U[r][1] * Vs[c][1] + s2 * U[r][2] * Vs[c][2]);
+// R = U diag(1, 1, det(U) det(V)) V^T for sigma = U S V^T.  With u2' = u0 x u1 and v2' = v0 x v1 (both right-handed) this
+// is R = u0 v0^T + u1 v1^T + u2' v2'^T for either sign of the determinants, so only the two leading singular pairs are
+// needed -- and those are well conditioned even for the flat (surface patch) blocks that are the rule here.
+// V from Jacobi rotations on sigma^T sigma; float, like Eigen's JacobiSVD<Matrix3f> inside PCL.
+__device__ __forceinline__ void jacobi_rotate(float& bpp, float& bqq, float& bpq, float& bpr, float& bqr, float& v0p, float& v0q, float& v1p,
+                                              float& v1q, float& v2p, float& v2q) {
+  if (fabsf(bpq) < 1e-37f) return;
+  const float theta = (bqq - bpp) / (2.0f * bpq);
+  const float t = copysignf(1.0f, theta) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+  const float c = 1.0f / sqrtf(t * t + 1.0f), sn = t * c;
+  bpp -= t * bpq;
+  bqq += t * bpq;
+  bpq = 0.0f;
+  const float r0 = bpr, r1 = bqr;
+  bpr = c * r0 - sn * r1;
+  bqr = sn * r0 + c * r1;
+  float a0 = v0p, a1 = v0q;
+  v0p = c * a0 - sn * a1; v0q = sn * a0 + c * a1;
+  a0 = v1p; a1 = v1q;
+  v1p = c * a0 - sn * a1; v1q = sn * a0 + c * a1;
+  a0 = v2p; a1 = v2q;
+  v2p = c * a0 - sn * a1; v2q = sn * a0 + c * a1;
 }
 
-// one workgroup per macroblock of the predictive frame
+__device__ void umeyama_rotation(const float A[9], float Rm[9]) {
+  // B = A^T A (symmetric): b00 b11 b22 b01 b02 b12
+  float b00 = A[0] * A[0] + A[3] * A[3] + A[6] * A[6], b11 = A[1] * A[1] + A[4] * A[4] + A[7] * A[7], b22 = A[2] * A[2] + A[5] * A[5] + A[8] * A[8];
+  float b01 = A[0] * A[1] + A[3] * A[4] + A[6] * A[7], b02 = A[0] * A[2] + A[3] * A[5] + A[6] * A[8], b12 = A[1] * A[2] + A[4] * A[5] + A[7] * A[8];
+  float v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;  // v[row][col]: columns = eigenvectors
+  for (int sweep = 0; sweep < 8; ++sweep) {
+    const float off = b01 * b01 + b02 * b02 + b12 * b12;
+    if (off <= 1e-15f * (b00 * b00 + b11 * b11 + b22 * b22)) break;
+    jacobi_rotate(b00, b11, b01, b02, b12, v00, v01, v10, v11, v20, v21);  // (p, q, r) = (0, 1, 2)
+    jacobi_rotate(b00, b22, b02, b01, b12, v00, v02, v10, v12, v20, v22);  // (0, 2, 1)
+    jacobi_rotate(b11, b22, b12, b01, b02, v01, v02, v11, v12, v21, v22);  // (1, 2, 0)
+  }
+  // the two largest eigenvalues' vectors
+  float e[3] = {b00, b11, b22};
+  float vc[3][3] = {{v00, v10, v20}, {v01, v11, v21}, {v02, v12, v22}};  // vc[k] = eigenvector k
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (e[i1] > e[i0]) { const int t = i0; i0 = i1; i1 = t; }
+  if (e[i2] > e[i0]) { const int t = i0; i0 = i2; i2 = t; }
+  if (e[i2] > e[i1]) { const int t = i1; i1 = i2; i2 = t; }
+  float va[3], vb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // selects instead of dynamic indexing (registers, no scratch)
+    va[k] = i0 == 0 ? vc[0][k] : (i0 == 1 ? vc[1][k] : vc[2][k]);
+    vb[k] = i1 == 0 ? vc[0][k] : (i1 == 1 ? vc[1][k] : vc[2][k]);
+  }
+  auto normalise = [](float w[3]) {
+    const float n2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (!(n2 > 1e-37f)) return false;
+    const float inv = 1.0f / sqrtf(n2);
+    w[0] *= inv; w[1] *= inv; w[2] *= inv;
+    return true;
+  };
+  auto any_orthogonal = [](const float u[3], float w[3]) {
+    const float ax = fabsf(u[0]), ay = fabsf(u[1]), az = fabsf(u[2]);
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    if (ax <= ay && ax <= az) ex = 1.f; else if (ay <= az) ey = 1.f; else ez = 1.f;
+    const float dot = ex * u[0] + ey * u[1] + ez * u[2];
+    w[0] = ex - dot * u[0]; w[1] = ey - dot * u[1]; w[2] = ez - dot * u[2];
+  };
+  normalise(va);
+  {  // vb orthogonal to va
+    const float dot = va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2];
+    vb[0] -= dot * va[0]; vb[1] -= dot * va[1]; vb[2] -= dot * va[2];
+    if (!normalise(vb)) { any_orthogonal(va, vb); normalise(vb); }
+  }
+  float ua[3], ub[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    ua[r] = A[3 * r] * va[0] + A[3 * r + 1] * va[1] + A[3 * r + 2] * va[2];
+    ub[r] = A[3 * r] * vb[0] + A[3 * r + 1] * vb[1] + A[3 * r + 2] * vb[2];
+  }
+  const float s0sq = ua[0] * ua[0] + ua[1] * ua[1] + ua[2] * ua[2];
+  if (!normalise(ua)) { ua[0] = va[0]; ua[1] = va[1]; ua[2] = va[2]; }  // zero covariance: identity
+  {
+    const float dot = ua[0] * ub[0] + ua[1] * ub[1] + ua[2] * ub[2];
+    ub[0] -= dot * ua[0]; ub[1] -= dot * ua[1]; ub[2] -= dot * ua[2];
+    const float n2 = ub[0] * ub[0] + ub[1] * ub[1] + ub[2] * ub[2];
+    if (n2 > 1e-12f * s0sq && normalise(ub)) {
+    } else if (s0sq > 1e-37f) {  // rank 1: the rotation about u0 is free; take the one that keeps vb's image closest
+      float w[3] = {vb[0] - (vb[0] * ua[0] + vb[1] * ua[1] + vb[2] * ua[2]) * ua[0], vb[1] - (vb[0] * ua[0] + vb[1] * ua[1] + vb[2] * ua[2]) * ua[1],
+                    vb[2] - (vb[0] * ua[0] + vb[1] * ua[1] + vb[2] * ua[2]) * ua[2]};
+      if (!normalise(w)) { any_orthogonal(ua, w); normalise(w); }
+      ub[0] = w[0]; ub[1] = w[1]; ub[2] = w[2];
+    } else {
+      ub[0] = vb[0]; ub[1] = vb[1]; ub[2] = vb[2];
+    }
+  }
+  const float uc[3] = {ua[1] * ub[2] - ua[2] * ub[1], ua[2] * ub[0] - ua[0] * ub[2], ua[0] * ub[1] - ua[1] * ub[0]};
+  const float vcx[3] = {va[1] * vb[2] - va[2] * vb[1], va[2] * vb[0] - va[0] * vb[2], va[0] * vb[1] - va[1] * vb[0]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Rm[3 * r + c] = ua[r] * va[c] + ub[r] * vb[c] + uc[r] * vcx[c];
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float dist2(float x, float y, float z, const float4& q) {
+  const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+  float d = __fmul_rn(dx, dx);
+  d = __fadd_rn(d, __fmul_rn(dy, dy));
+  return __fadd_rn(d, __fmul_rn(dz, dz));
+}
+
+// nearest target with the targets staged in LDS (every lane reads the same address: a broadcast); slot = target index
+__device__ __forceinline__ void nearest_lds(const float4* s_tgt, uint32_t nt, float x, float y, float z, uint32_t& best_slot, float& best) {
+  best = FLT_MAX;
+  best_slot = 0;
+  for (uint32_t j = 0; j < nt; ++j) {
+    const float d = dist2(x, y, z, s_tgt[j]);
+    if (d < best) { best = d; best_slot = j; }
+  }
+}
+
+__device__ __forceinline__ void wave_sync() {  // LDS written by some lanes of this wave, read by others
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One WAVE per macroblock of the predictive frame (a block holds some tens to a few hundred points): no barriers inside
+// the iteration, sums by cross-lane shuffles, the 3x3 SVD computed redundantly by every lane.
+constexpr int kIcpWaves = kDBlock / 64;
+constexpr uint32_t kIcpTargetCap = 1024;  // targets staged in LDS per wave (16 KB); larger blocks read them from HBM/L2
+
 __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
-  __shared__ float s_redf[kDBlock / 64];
-  __shared__ double s_redd[kDBlock / 64];
-  __shared__ float s_tr[16], s_final[16];
-  __shared__ int s_flag;  // 0 go on, 1 converged, 2 failed
-  const uint32_t b = blockIdx.x;
+  __shared__ float4 s_tgt_all[kIcpWaves][kIcpTargetCap];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t b = blockIdx.x * kIcpWaves + (uint32_t)wave;
+  const bool live = b < a.p_tree.n_blocks && a.results[min(b, a.p_tree.n_blocks - 1)].do_icp != 0;
+  if (!live) return;  // no workgroup barrier below: waves are independent
   const BlockResult r0 = a.results[b];
-  if (!r0.do_icp) return;
   const uint32_t s0 = a.i_tree.leaf_start[r0.i_block], ns = r0.n_i;
   const uint32_t t0 = a.p_tree.leaf_start[b], nt = r0.n_p;
   const float4* src = a.i_xyzc + s0;  // source = the I frame's block, target = the predictive frame's block (impl.hpp:547-548)
   const float4* tgt = a.p_xyzc + t0;
-  float4* cur = a.cur + s0;
+  float4* s_tgt = s_tgt_all[wave];
+  const bool staged = nt <= kIcpTargetCap;
+  if (staged) {
+    for (uint32_t j = lane; j < nt; j += 64) s_tgt[j] = tgt[j];
+    wave_sync();
+  }
+  auto nearest = [&](float x, float y, float z, uint32_t& slot, float& d) {
+    if (staged) nearest_lds(s_tgt, nt, x, y, z, slot, d);
+    else nearest_in(tgt, nt, x, y, z, slot, d);
+  };
+  float4* cur = a.cur + s0;  // lane-private elements (i = lane, lane + 64, ...): no synchronisation needed
   uint32_t* nn = a.nn + s0;
-  for (uint32_t i = threadIdx.x; i < ns; i += kDBlock) cur[i] = src[i];
-  if (threadIdx.x < 16) s_final[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.f : 0.f;
-  if (threadIdx.x == 0) s_flag = 0;
-  __syncthreads();
+  for (uint32_t i = lane; i < ns; i += 64) cur[i] = src[i];
+  float fin[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) fin[k] = (k % 5 == 0) ? 1.f : 0.f;
   const float fn = (float)ns;
   double prev_mse = DBL_MAX;
   int it = 0;
@@ -229,82 +307,87 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
     // correspondences: nearest target of every (moved) source point; sums for the means
     float sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
     double sd = 0;
-    for (uint32_t i = threadIdx.x; i < ns; i += kDBlock) {
+    for (uint32_t i = lane; i < ns; i += 64) {
       const float4 p = cur[i];
       uint32_t j; float d;
-      nearest_in(tgt, nt, p.x, p.y, p.z, j, d);
+      nearest(p.x, p.y, p.z, j, d);
       nn[i] = j;
+      const float4 q = staged ? s_tgt[j] : tgt[j];
       sx += p.x; sy += p.y; sz += p.z;
-      tx += tgt[j].x; ty += tgt[j].y; tz += tgt[j].z;
+      tx += q.x; ty += q.y; tz += q.z;
       sd += (double)d;
     }
-    const float smx = block_sum_f(sx, s_redf) / fn, smy = block_sum_f(sy, s_redf) / fn, smz = block_sum_f(sz, s_redf) / fn;
-    const float tmx = block_sum_f(tx, s_redf) / fn, tmy = block_sum_f(ty, s_redf) / fn, tmz = block_sum_f(tz, s_redf) / fn;
-    const double mse = block_sum_d(sd, s_redd) / (double)ns;
+    const float smx = wave_sum_f(sx) / fn, smy = wave_sum_f(sy) / fn, smz = wave_sum_f(sz) / fn;
+    const float tmx = wave_sum_f(tx) / fn, tmy = wave_sum_f(ty) / fn, tmz = wave_sum_f(tz) / fn;
+    const double mse = wave_sum_d(sd) / (double)ns;
     float sg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < ns; i += kDBlock) {
+    for (uint32_t i = lane; i < ns; i += 64) {
       const float4 p = cur[i];
-      const float4 q = tgt[nn[i]];
+      const float4 q = staged ? s_tgt[nn[i]] : tgt[nn[i]];
       const float ds[3] = {p.x - smx, p.y - smy, p.z - smz}, dt[3] = {q.x - tmx, q.y - tmy, q.z - tmz};
+#pragma unroll
       for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) sg[3 * r + c] += dt[r] * ds[c];
     }
-    for (int k = 0; k < 9; ++k) sg[k] = block_sum_f(sg[k], s_redf) / fn;
-    if (threadIdx.x == 0) {
-      float Rm[9];
-      umeyama_rotation(sg, Rm);
-      float tr[16];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sg[k] = wave_sum_f(sg[k]) / fn;
+    // every lane: the same transformation from the same sums
+    float Rm[9], tr[16];
+    umeyama_rotation(sg, Rm);
+    {
+      const float sm[3] = {smx, smy, smz}, tm[3] = {tmx, tmy, tmz};
+#pragma unroll
       for (int r = 0; r < 3; ++r) {
+#pragma unroll
         for (int c = 0; c < 3; ++c) tr[4 * r + c] = Rm[3 * r + c];
-        const float sm[3] = {smx, smy, smz}, tm[3] = {tmx, tmy, tmz};
         tr[4 * r + 3] = tm[r] - (Rm[3 * r] * sm[0] + Rm[3 * r + 1] * sm[1] + Rm[3 * r + 2] * sm[2]);
       }
       tr[12] = tr[13] = tr[14] = 0.f; tr[15] = 1.f;
-      float nf[16];  // final = tr * final
-      for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c)
-          nf[4 * r + c] = ((tr[4 * r] * s_final[c] + tr[4 * r + 1] * s_final[4 + c]) + tr[4 * r + 2] * s_final[8 + c]) + tr[4 * r + 3] * s_final[12 + c];
-      for (int k = 0; k < 16; ++k) { s_tr[k] = tr[k]; s_final[k] = nf[k]; }
-      // DefaultConvergenceCriteria::hasConverged (PCL 1.10) with the settings of impl.hpp:549-553
-      int flag = 0;
-      if (it + 1 >= a.max_iterations) flag = 1;
-      else {
-        const double cos_angle = 0.5 * ((double)tr[0] + (double)tr[5] + (double)tr[10] - 1.0);
-        const double tsq = (double)tr[3] * tr[3] + (double)tr[7] * tr[7] + (double)tr[11] * tr[11];
-        if (cos_angle >= rot_thr && tsq <= trans_thr) flag = 1;
-        else if (fabs(mse - prev_mse) < mse_abs || fabs(mse - prev_mse) / prev_mse < mse_rel) flag = 1;
-      }
-      s_flag = flag;
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ns; i += kDBlock) {  // move the source points
+    float nf[16];  // final = tr * final
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        nf[4 * r + c] = ((tr[4 * r] * fin[c] + tr[4 * r + 1] * fin[4 + c]) + tr[4 * r + 2] * fin[8 + c]) + tr[4 * r + 3] * fin[12 + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fin[k] = nf[k];
+    for (uint32_t i = lane; i < ns; i += 64) {  // move the source points
       const float4 p = cur[i];
       float4 o = p;
-      se3(s_tr, p.x, p.y, p.z, o.x, o.y, o.z);
+      se3(tr, p.x, p.y, p.z, o.x, o.y, o.z);
       cur[i] = o;
     }
-    prev_mse = mse;
     ++it;
-    const int flag = s_flag;
-    __syncthreads();
-    if (flag) break;
+    // DefaultConvergenceCriteria::hasConverged (PCL 1.10) with the settings of impl.hpp:549-553
+    bool stop = false;
+    if (it >= a.max_iterations) stop = true;
+    else {
+      const double cos_angle = 0.5 * ((double)tr[0] + (double)tr[5] + (double)tr[10] - 1.0);
+      const double tsq = (double)tr[3] * tr[3] + (double)tr[7] * tr[7] + (double)tr[11] * tr[11];
+      if (cos_angle >= rot_thr && tsq <= trans_thr) stop = true;
+      else if (fabs(mse - prev_mse) < mse_abs || fabs(mse - prev_mse) / prev_mse < mse_rel) stop = true;
+    }
+    prev_mse = mse;
+    if (stop) break;  // uniform across the wave: every lane holds the same values
   }
   // getFitnessScore: mean squared distance of the source moved by the final transformation to its nearest target
   double fs = 0;
-  for (uint32_t i = threadIdx.x; i < ns; i += kDBlock) {
+  for (uint32_t i = lane; i < ns; i += 64) {
     float x, y, z;
-    se3(s_final, src[i].x, src[i].y, src[i].z, x, y, z);
+    se3(fin, src[i].x, src[i].y, src[i].z, x, y, z);
     uint32_t j; float d;
-    nearest_in(tgt, nt, x, y, z, j, d);
+    nearest(x, y, z, j, d);
     fs += (double)d;
   }
-  const double fitness = block_sum_d(fs, s_redd) / (double)ns;
-  if (threadIdx.x == 0) {
+  const double fitness = wave_sum_d(fs) / (double)ns;
+  if (lane == 0) {
     BlockResult* out = a.results + b;
     out->iterations = it;
     out->fitness = (float)fitness;
     out->converged = fitness < a.point_resolution * 2.0 ? 1 : 0;  // hasConverged() is true also at the iteration limit
-    for (int k = 0; k < 16; ++k) out->rt[k] = s_final[k];
+    for (int k = 0; k < 16; ++k) out->rt[k] = fin[k];
   }
 }
 
@@ -359,8 +442,8 @@ void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream) {
   if (a.i_tree.n_points) hipLaunchKernelGGL(k_block_points, dim3((a.i_tree.n_points + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a.i_tree, a.i_xyzc);
   if (a.p_tree.n_points) hipLaunchKernelGGL(k_block_points, dim3((a.p_tree.n_points + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a.p_tree, a.p_xyzc);
   if (!nbp) return;
-  hipLaunchKernelGGL(k_block_match, dim3((nbp + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a);
-  hipLaunchKernelGGL(k_block_icp, dim3(nbp), dim3(kDBlock), 0, stream, a);
+  hipLaunchKernelGGL(k_block_match, dim3((2 * nbp + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a);
+  hipLaunchKernelGGL(k_block_icp, dim3((nbp + kIcpWaves - 1) / kIcpWaves), dim3(kDBlock), 0, stream, a);
 }
 
 void launch_delta_gather(const GatherArgs& a, hipStream_t stream) {
