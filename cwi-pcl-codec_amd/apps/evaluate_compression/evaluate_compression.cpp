@@ -14,8 +14,8 @@
 //   csv header and line                   quality_metrics_impl.hpp:242-285 (same stream formatting: operator<<)
 //   delta (predictive) coding branch      eval.hpp:498-527, 854-890 (do_delta_coding, icp_on_original, predictive csv,
 //                                         delta_decoded_pc_<n>.ply)
-// Not part of this build: the V1 algorithm, the outlier filter and the VTK windows; asking for them prints a note
-// and goes on without.
+//   radius outlier filter                 eval.hpp:430-435 (K_outlier_filter, radius)
+// Not part of this build: the V1 algorithm and the VTK windows; asking for them prints a note and goes on without.
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -461,7 +461,8 @@ struct App {
   bool evaluate_group(std::vector<CloudPtr>& group, const std::string& settings, std::ofstream& intra_csv) {
     std::vector<CloudPtr> working_group;
     for (CloudPtr& c : group) working_group.push_back(CloudPtr(new Cloud(*c)));  // deep copy (eval.hpp:804-808)
-    if (opt.integer("K_outlier_filter") > 0) std::cerr << "note: the radius outlier filter is not part of this build; going on without\n";
+    if (opt.integer("K_outlier_filter") > 0)  // do_outlier_removal (eval.hpp:430-435)
+      Codec::remove_outliers(working_group, opt.integer("K_outlier_filter"), opt.real("radius"), (unsigned)opt.integer("debug_level"));
     pcl::io::BoundingBox bb;
     memset(&bb, 0, sizeof(bb));
     std::vector<pcl::io::BoundingBox> boxes;

@@ -36,7 +36,7 @@ EXPORTS = [
     "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
-    "pcc_quality_metrics",
+    "pcc_quality_metrics", "pcc_remove_outliers",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
@@ -162,6 +162,7 @@ def load_library():
     lib.pcc_pipeline_last_error.restype = C.c_char_p
     lib.pcc_pipeline_last_error.argtypes = [vp]
     lib.pcc_quality_metrics.argtypes = [vp, vp, sz, vp, sz, C.c_double, C.POINTER(Quality)]
+    lib.pcc_remove_outliers.argtypes = [vp, vp, sz, i32, C.c_double, vp, C.POINTER(sz)]
     lib.pcc_encode_delta.argtypes = [vp, vp, sz, vp, sz, C.POINTER(DeltaParams), C.POINTER(DeltaResult)]
     lib.pcc_delta_blocks.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     lib.pcc_decode_delta.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(DeltaParams), C.POINTER(Cloud)]
@@ -342,6 +343,16 @@ class Context:
         d = {k: getattr(q, k) for k, _ in Quality._fields_ if k != "psnr_yuv"}
         d["psnr_yuv"] = list(q.psnr_yuv)
         return d
+
+    def remove_outliers(self, cloud: np.ndarray, min_points: int, radius: float):
+        """remove_outliers for one cloud (codec.h:216-217): the kept points, in order."""
+        c = np.ascontiguousarray(cloud)
+        keep = np.zeros(max(len(c), 1), dtype=np.uint8)
+        n_kept = C.c_size_t()
+        self._check(self.lib.pcc_remove_outliers(self.h, c.ctypes.data, len(c), int(min_points), float(radius), keep.ctypes.data, C.byref(n_kept)))
+        out = c[keep[:len(c)] != 0]
+        assert len(out) == n_kept.value
+        return out
 
     def encode_delta(self, i_cloud: np.ndarray, p_cloud: np.ndarray, params, icp_on_original=False, write_out_cloud=True,
                      icp_max_iterations=0, icp_var_threshold=0.0, transformation_epsilon=0.0):

@@ -675,6 +675,53 @@ int pcc_quality_metrics(pcc_ctx* ctx, const pcc_point_xyzrgb* cloud_a, size_t n_
   return PCC_OK;
 }
 
+int pcc_remove_outliers(pcc_ctx* ctx, const pcc_point_xyzrgb* cloud, size_t n, int min_points, double radius, uint8_t* keep, size_t* n_kept) {
+  if (!ctx || (!cloud && n) || !keep || !n_kept) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  *n_kept = 0;
+  if (n == 0) return PCC_OK;
+  if (min_points <= 0) {  // the reference does nothing then (impl.hpp:1844)
+    memset(keep, 1, n);
+    *n_kept = n;
+    return PCC_OK;
+  }
+  if (!(radius > 0.0)) return fail(ctx, PCC_ERR_ARG, "remove_outliers: radius must be positive");
+  if (n >= (1ull << 31)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^31 points");
+  PCC_HIP(hipSetDevice(ctx->device));
+  float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (size_t i = 0; i < n; ++i) {
+    const float q[3] = {cloud[i].x, cloud[i].y, cloud[i].z};
+    if (!std::isfinite(q[0]) || !std::isfinite(q[1]) || !std::isfinite(q[2])) continue;
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
+  }
+  if (!(lo[0] <= hi[0])) { memset(keep, 0, n); return PCC_OK; }
+  const float ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  const float cell = std::max((float)radius, ext / 1000000.0f);  // 21 bits of cell index per axis
+  const size_t slots = quality_table_slots(n);
+  PCC_HIP(ctx->d_qa.ensure(32 * n));
+  PCC_HIP(ctx->d_qkeys.ensure(slots));
+  PCC_HIP(ctx->d_qheads.ensure(slots));
+  PCC_HIP(ctx->d_qnext.ensure(n));
+  PCC_HIP(ctx->d_qb.ensure(n));
+  PCC_HIP(hipMemcpyAsync(ctx->d_qa.p, cloud, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  RadiusArgs ra{};
+  ra.cloud = ctx->d_qa.p; ra.n = (uint32_t)n;
+  for (int a = 0; a < 3; ++a) ra.origin[a] = lo[a] - cell;
+  ra.radius = (float)radius;
+  if (cell > ra.radius) return fail(ctx, PCC_ERR_UNSUPPORTED, "remove_outliers: radius too small for the cloud's extent");
+  ra.min_points = (uint32_t)min_points;
+  ra.table_slots = slots;
+  ra.keys = ctx->d_qkeys.p; ra.heads = ctx->d_qheads.p; ra.next = ctx->d_qnext.p; ra.keep = ctx->d_qb.p;
+  launch_radius_filter(ra, ctx->stream);
+  PCC_HIP(hipGetLastError());
+  PCC_HIP(hipMemcpyAsync(keep, ctx->d_qb.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  size_t k = 0;
+  for (size_t i = 0; i < n; ++i) k += keep[i] ? 1 : 0;
+  *n_kept = k;
+  return PCC_OK;
+}
+
 int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud* out) {
   if (!ctx || !out || (!stream && len)) return PCC_ERR_ARG;
   const int rc = decode_frame(stream, len, ctx->dec_points, *out);

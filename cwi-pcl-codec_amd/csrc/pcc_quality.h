@@ -23,6 +23,21 @@ struct QualityArgs {
   double* partials;          // [ceil(n_query / 256)][8] per-workgroup partial sums / maxima
 };
 
+// pcl::RadiusOutlierRemoval (remove_outliers, impl.hpp:1840-1866): keep[i] = 1 if at least min_points other points lie within radius
+struct RadiusArgs {
+  const void* cloud;  // pcl::PointXYZRGB on the device
+  uint32_t n;
+  float origin[3];    // grid origin (below every point)
+  float radius;       // = grid cell size
+  uint32_t min_points;
+  size_t table_slots;
+  unsigned long long* keys;
+  uint32_t* heads;
+  uint32_t* next;
+  uint8_t* keep;      // [n]
+};
+void launch_radius_filter(const RadiusArgs& a, hipStream_t stream);
+
 size_t quality_table_slots(size_t n_target);
 void launch_quality_direction(const QualityArgs& a, hipStream_t stream);
 

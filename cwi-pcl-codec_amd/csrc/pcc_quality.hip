@@ -201,6 +201,45 @@ __global__ __launch_bounds__(kQBlock) void k_quality_partials(const QPoint* __re
   }
 }
 
+
+// pcl::RadiusOutlierRemoval as the reference uses it (remove_outliers, impl.hpp:1840-1866): a point stays if at least
+// `min_points` OTHER points lie within `radius` (squared float distance <= radius^2).  Grid cell = radius: every such
+// neighbour is in the 3x3x3 cells around the point's own.  The walk stops as soon as enough neighbours were seen.
+__global__ __launch_bounds__(kQBlock) void k_radius_keep(const QPoint* __restrict__ t, uint32_t n, GridParams g, const unsigned long long* __restrict__ keys,
+                                                         const uint32_t* __restrict__ heads, const uint32_t* __restrict__ next, float r2,
+                                                         uint32_t min_points, uint8_t* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * kQBlock + threadIdx.x;
+  if (i >= n) return;
+  const float qx = t[i].x, qy = t[i].y, qz = t[i].z;
+  if (!finite3(qx, qy, qz)) { keep[i] = 0; return; }
+  int c[3];
+  cell_of(g, qx, qy, qz, c);
+  uint32_t found = 0;
+  for (int dz = -1; dz <= 1 && found < min_points; ++dz)
+    for (int dy = -1; dy <= 1 && found < min_points; ++dy)
+      for (int dx = -1; dx <= 1 && found < min_points; ++dx) {
+        const unsigned long long code = cell_code(c[0] + dx, c[1] + dy, c[2] + dz);
+        uint32_t slot = hash_code(code) & g.table_mask;
+        bool present = true;
+        for (;;) {
+          const unsigned long long k = keys[slot];
+          if (k == code) break;
+          if (k == 0ull) { present = false; break; }
+          slot = (slot + 1u) & g.table_mask;
+        }
+        if (!present) continue;
+        for (uint32_t j = heads[slot]; j != kNoPoint && found < min_points; j = next[j]) {
+          if (j == i) continue;
+          const float ex = qx - t[j].x, ey = qy - t[j].y, ez = qz - t[j].z;
+          float d = __fmul_rn(ex, ex);
+          d = __fadd_rn(d, __fmul_rn(ey, ey));
+          d = __fadd_rn(d, __fmul_rn(ez, ez));
+          if (d <= r2) ++found;
+        }
+      }
+  keep[i] = found >= min_points ? 1 : 0;
+}
+
 }  // namespace
 
 size_t quality_table_slots(size_t n_target) {
@@ -222,6 +261,19 @@ void launch_quality_direction(const QualityArgs& a, hipStream_t stream) {
   const uint32_t qb = (a.n_query + kQBlock - 1) / kQBlock;
   hipLaunchKernelGGL(k_nn_query, dim3(qb), dim3(kQBlock), 0, stream, q, a.n_query, t, a.n_target, g, a.keys, a.heads, a.next, a.d2, a.idx);
   hipLaunchKernelGGL(k_quality_partials, dim3(qb), dim3(kQBlock), 0, stream, q, a.n_query, t, a.d2, a.idx, a.with_colour, a.partials);
+}
+
+void launch_radius_filter(const RadiusArgs& a, hipStream_t stream) {
+  GridParams g;
+  for (int k = 0; k < 3; ++k) g.origin[k] = a.origin[k];
+  g.cell = a.radius;
+  g.inv_cell = 1.0f / a.radius;
+  g.table_mask = (uint32_t)(a.table_slots - 1);
+  const QPoint* t = reinterpret_cast<const QPoint*>(a.cloud);
+  const uint32_t nb = (a.n + kQBlock - 1) / kQBlock;
+  hipLaunchKernelGGL(k_nn_clear, dim3(1024), dim3(kQBlock), 0, stream, a.keys, a.heads, (uint32_t)a.table_slots);
+  hipLaunchKernelGGL(k_nn_build, dim3(nb), dim3(kQBlock), 0, stream, t, a.n, g, a.keys, a.heads, a.next);
+  hipLaunchKernelGGL(k_radius_keep, dim3(nb), dim3(kQBlock), 0, stream, t, a.n, g, a.keys, a.heads, a.next, a.radius * a.radius, a.min_points, a.keep);
 }
 
 }  // namespace pcc

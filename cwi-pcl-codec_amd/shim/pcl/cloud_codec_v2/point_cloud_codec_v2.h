@@ -184,6 +184,34 @@ class OctreePointCloudCodecV2 {
   float getMacroBlockPercentage() { return shared_macroblock_percentage_; }                        // codec.h:200-204
   float getMacroBlockConvergencePercentage() { return shared_macroblock_convergence_percentage_; }  // codec.h:207-210
 
+  // codec.h:216-217 / impl.hpp:1840-1866: radius outlier filter on every cloud of the group (GPU; a context of its own,
+  // the function is static in the reference as well)
+  static void remove_outliers(std::vector<PointCloudPtr>& point_clouds, int min_points, double radius, unsigned int debug_level = 0) {
+    if (min_points <= 0) return;
+    pcc_ctx* c = pcc_create(0);
+    if (!c) throw std::runtime_error("remove_outliers: no usable MI355X/HIP device (there is no CPU fallback)");
+    for (auto& pc : point_clouds) {
+      std::vector<uint8_t> keep(pc->points.size() + 1);
+      size_t kept = 0;
+      const int rc = pcc_remove_outliers(c, reinterpret_cast<const pcc_point_xyzrgb*>(pc->points.data()), pc->points.size(), min_points, radius,
+                                         keep.data(), &kept);
+      if (rc != PCC_OK) {
+        const std::string msg = std::string("remove_outliers: ") + pcc_last_error(c);
+        pcc_destroy(c);
+        throw std::runtime_error(msg);
+      }
+      PointCloudPtr out(new PointCloud());
+      out->points.reserve(kept);
+      for (size_t i = 0; i < pc->points.size(); ++i)
+        if (keep[i]) out->points.push_back(pc->points[i]);
+      out->width = (uint32_t)out->points.size();
+      out->height = 1;
+      if (debug_level > 2) std::cout << "filtered out a total of: " << pc->points.size() - kept << " outliers" << std::endl;
+      pc = out;  // "swap the pointer"
+    }
+    pcc_destroy(c);
+  }
+
   // codec.h:223-227 (vectors of dyn_range/offset are unused by the reference as well)
   static BoundingBox normalize_pointclouds(std::vector<PointCloudPtr>& point_clouds, std::vector<BoundingBox>& bounding_boxes,
                                            double bb_expand_factor, std::vector<float> = std::vector<float>(),

@@ -219,6 +219,13 @@ typedef struct pcc_quality {
 int pcc_quality_metrics(pcc_ctx *ctx, const pcc_point_xyzrgb *cloud_a, size_t n_a, const pcc_point_xyzrgb *cloud_b,
                         size_t n_b, double cell_hint, pcc_quality *out);
 
+/* ---- remove_outliers (codec.h:216-217, impl.hpp:1840-1866): pcl::RadiusOutlierRemoval on the GPU ----
+ * keep[i] = 1 if at least `min_points` other points of the cloud lie within `radius` of point i (squared float distance
+ * <= radius^2; non-finite points are dropped); min_points <= 0 keeps everything, as the reference does.  The caller
+ * compacts (the reference returns the kept points in their original order). */
+int pcc_remove_outliers(pcc_ctx *ctx, const pcc_point_xyzrgb *cloud, size_t n, int min_points, double radius, uint8_t *keep,
+                        size_t *n_kept);
+
 /* ---- encodePointCloudDeltaFrame / decodePointCloudDeltaFrame (codec.h:181-191, impl.hpp:787-1235): predictive frames ----
  * The P frame is simplified to voxel centres (simplifyPCloud, impl.hpp:318-403), both frames are cut into macroblocks
  * (octree leaves at octree_resolution * macroblock_size inside [0,1]^3, impl.hpp:411-434); a macroblock that exists in
