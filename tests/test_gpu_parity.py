@@ -400,3 +400,65 @@ def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
     for d in devs:
         ctx.free(d)
     pipe.close()
+
+
+# ---------------- randomised sweep ----------------
+
+def _random_case(pkg, seed):
+    """A random frame and codec configuration: size, shape, point order, non-finite points, duplicates, resolution
+    (power of two or not), colour mode, colour bits, centroids."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000, 30000, 70000]))
+    shape = rng.integers(0, 6)
+    if shape == 0:      # volume
+        xyz = rng.uniform(0.0, 1.0, (n, 3))
+    elif shape == 1:    # clusters
+        c = rng.uniform(0.1, 0.9, (8, 3))
+        xyz = c[rng.integers(0, 8, n)] + rng.normal(size=(n, 3)) * 0.02
+    elif shape == 2:    # lattice with many coincident points
+        xyz = rng.integers(0, 40, (n, 3)) / 64.0
+    elif shape == 3:    # a line: one long axis, deep tree for few points
+        t = rng.uniform(0, 1, n)
+        xyz = np.stack([t, 0.3 + 0.001 * t, 0.7 - 0.002 * t], 1)
+    elif shape == 4:    # surface, large offset and scale (not normalised)
+        u, v = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+        xyz = np.stack([50 + 30 * u, -20 + 25 * v, 5 + 3 * np.sin(6 * u) * np.cos(5 * v)], 1)
+    else:               # far outlier first: the box starts somewhere else and has to grow a lot
+        xyz = rng.uniform(0.4, 0.6, (n, 3))
+        xyz[0] = (7.5, -3.0, 0.01)
+    xyz = xyz.astype(np.float32)
+    order = rng.integers(0, 3)
+    if order == 1:
+        xyz = xyz[np.lexsort((xyz[:, 0], xyz[:, 1], xyz[:, 2]))]
+    elif order == 2:
+        xyz = xyz[::-1].copy()
+    if n > 16 and rng.integers(0, 3) == 0:
+        bad = rng.integers(0, n, max(1, n // 50))
+        xyz[bad, rng.integers(0, 3, len(bad))] = rng.choice([np.nan, np.inf, -np.inf], len(bad))
+    fin = xyz[np.isfinite(xyz).all(axis=1)]
+    ext = float((fin.max(axis=0) - fin.min(axis=0)).max()) if len(fin) > 1 else 1.0
+    ext = max(ext, 1e-3)
+    if rng.integers(0, 2):
+        res = ext / float(2 ** rng.integers(3, 11))
+        res = 2.0 ** round(np.log2(res))
+    else:
+        res = ext / float(rng.uniform(8, 900))
+    mode = int(rng.integers(0, 4))
+    kw = dict(octree_resolution=float(res), point_resolution=float(res), color_coding_type=mode,
+              color_bits=int(rng.choice([8, 8, 6, 4, 0])) if mode == 0 else int(rng.choice([8, 8, 0])),
+              keep_centroid=int(rng.integers(0, 2)), jpeg_quality=int(rng.choice([30, 75, 85, 95])), frame_id=int(rng.integers(1, 1000)))
+    return cloud(pkg, xyz, seed=seed), kw
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_sweep(pkg, oracle, ctx, seed):
+    pts, kw = _random_case(pkg, seed)
+    po = oracle.make_params(**kw)
+    want = oracle.encode_intra(pts, po)
+    if want is None:   # nothing finite: dropped on both sides
+        with pytest.raises(pkg.binding.PccError):
+            ctx.encode_intra_host(pts, pkg.binding.make_params(**kw))
+        return
+    if want.depth > 21:
+        pytest.skip("deeper than the 63-bit Morton limit (documented)")
+    assert_matches_oracle(pkg, oracle, ctx, pts, **kw)
