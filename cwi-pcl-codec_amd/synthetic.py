@@ -154,9 +154,35 @@ CONFIGS = {
     # cfg3 with capture-like data: voxelised surface on a 1024^3 lattice in raster order (8i longdress stand-in)
     "cfg3v": dict(gen="body", n=800_000, seed=0xC3, octree_bits=10, color_bits=8, color_coding_type=1,
                   jpeg_quality=85, keep_centroid=0),
+    # inter-frame family: a sphere shell whose centre moves +0.002 in x per frame, 30 frames, coded
+    # as I(0), P(1|0), I(1), P(2|1), ... like the reference app with do_delta_coding=1; frames come from moving_sphere_group
+    "cfg5": dict(gen="moving_sphere", n=200_000, seed=0xC5, frames=30, octree_bits=8, color_bits=8, color_coding_type=1,
+                 jpeg_quality=85, keep_centroid=0, macroblock_size=16),
     "cfg4": dict(gen="uniform", n=10_000_000, seed=0xC4, octree_bits=12, color_bits=0, color_coding_type=1,
                  jpeg_quality=85, keep_centroid=0),
 }
+
+
+def moving_sphere_group(n, seed, frames, step=0.002, bb_expand_factor=0.2):
+    """cfg5: `frames` sphere shells (same surface sample, fresh radial noise and colour noise per frame), centre moving
+    +step in x per frame, normalised as ONE group like normalize_pointclouds does for a group whose first frame sets the
+    box and later frames stay inside it (impl.hpp:1899-1926): every frame is mapped with the box of the union."""
+    raw = [sphere_shell(n, seed, centre=(0.5 + step * f, 0.5, 0.5), noise=0.0005, do_normalize=False) for f in range(frames)]
+    for f, r in enumerate(raw):   # per-frame radial jitter, deterministic
+        j = ((_u01(seed + 97 * (f + 1), n, 5) - 0.5) * 0.001).astype(np.float32)
+        d = np.stack([r["x"] - np.float32(0.5 + step * f), r["y"] - np.float32(0.5), r["z"] - np.float32(0.5)], 1)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        r["x"] += d[:, 0] * j; r["y"] += d[:, 1] * j; r["z"] += d[:, 2] * j
+    mn = np.array([min(r[a].min() for r in raw) for a in "xyz"], dtype=np.float32)
+    mx = np.array([max(r[a].max() for r in raw) for a in "xyz"], dtype=np.float32)
+    ext = np.abs(mx - mn)
+    bb_min = (mn.astype(np.float64) - bb_expand_factor * ext.astype(np.float64)).astype(np.float32)
+    bb_max = (mx.astype(np.float64) + bb_expand_factor * ext.astype(np.float64)).astype(np.float32)
+    dyn = bb_max - bb_min
+    for r in raw:
+        for i, a in enumerate("xyz"):
+            r[a] = (r[a] - bb_min[i]) / dyn[i]
+    return raw
 
 
 def make_frame(cfg, frame=0, n=None):

@@ -165,3 +165,28 @@ def test_delta_rejects_empty(pkg, ctx, pair):
     i_cloud, p_cloud = pair
     with pytest.raises(pkg.binding.PccError):
         ctx.encode_delta(i_cloud[:0], p_cloud, _params(pkg))
+
+
+def test_cfg5_moving_sphere_sequence(pkg, oracle, ctx):
+    """SURVEY.md 8(d) cfg5, reduced: I(0), P(1|0), I(1), P(2|1) like the reference app with do_delta_coding=1 -- the I
+    frame of each prediction is the encoder's simplified cloud (eval.hpp:862).  Bit-exact given the transforms;
+    the macroblock statistics against the oracle's own ICP (statistical parity)."""
+    cfg = dict(pkg.synthetic.CONFIGS["cfg5"])
+    frames = pkg.synthetic.moving_sphere_group(20_000, cfg["seed"], 3)
+    res = 2.0 ** -cfg["octree_bits"]
+    prm = pkg.binding.make_params(octree_bits=cfg["octree_bits"], color_bits=8, color_coding_type=1, jpeg_quality=85)
+    for f in range(2):
+        prm.frame_id = f + 1
+        _, _ = ctx.encode_intra_host(frames[f], prm)
+        i_cloud = ctx.output_cloud()
+        want_i = oracle.encode_intra(frames[f], oracle.make_params(octree_bits=cfg["octree_bits"], frame_id=f + 1)).simplified
+        assert i_cloud.tobytes() == want_i.tobytes()
+        got = ctx.encode_delta(i_cloud, frames[f + 1], prm)
+        want = D.encode_delta(i_cloud, frames[f + 1], res, res, icp_fn=_replay(got))
+        assert got["p_stream"] == want["p_stream"] and got["i_stream"] == want["i_stream"]
+        assert got["out_cloud"].tobytes() == want["out_cloud"].tobytes()
+        own = D.encode_delta(i_cloud, frames[f + 1], res, res, write_out_cloud=False)   # the oracle's ICP
+        assert abs(float(own["shared_percentage"]) - got["shared_macroblock_percentage"]) < 1e-6
+        assert abs(float(own["convergence_percentage"]) - got["shared_macroblock_convergence_percentage"]) < 0.02
+        assert abs(len(own["p_stream"]) - len(got["p_stream"])) <= 0.02 * len(got["p_stream"]) + 40
+        assert got["shared_macroblock_percentage"] > 0.9 and got["convergence_count"] > 300

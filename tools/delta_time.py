@@ -1,5 +1,5 @@
 """Timing of the inter-frame path on a capture-like pair (voxelised body, 1024^3 lattice): wall time and HIP-event time of
-pcc_encode_delta / pcc_decode_delta, sizes, block statistics.  Run on the GPU box:  python tools/delta_time.py [n] [reps]"""
+pcc_encode_delta / pcc_decode_delta, sizes, block statistics.  Run on the GPU box:  python tools/delta_time.py [n] [reps] [cfg5]"""
 import os
 import sys
 import time
@@ -13,9 +13,16 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     pkg = G.load_package()
     B = pkg.binding
-    i_cloud, p_cloud = pkg.synthetic.delta_pair(n, 0xD1, grid=1024)
-    prm = B.make_params(octree_bits=10, color_bits=8, color_coding_type=1, jpeg_quality=85)
     ctx = B.Context(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "cfg5":   # moving sphere shell, 8-bit octree
+        cfg = pkg.synthetic.CONFIGS["cfg5"]
+        frames = pkg.synthetic.moving_sphere_group(n, cfg["seed"], 2)
+        prm = B.make_params(octree_bits=cfg["octree_bits"], color_bits=8, color_coding_type=1, jpeg_quality=85)
+        ctx.encode_intra_host(frames[0], prm)
+        i_cloud, p_cloud = ctx.output_cloud(), frames[1]
+    else:
+        i_cloud, p_cloud = pkg.synthetic.delta_pair(n, 0xD1, grid=1024)
+        prm = B.make_params(octree_bits=10, color_bits=8, color_coding_type=1, jpeg_quality=85)
     best = None
     for r in range(reps):
         t0 = time.perf_counter()
