@@ -14,6 +14,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pcc_delta.h"
 
@@ -266,35 +267,58 @@ __device__ __forceinline__ void wave_sync() {  // LDS written by some lanes of t
   __builtin_amdgcn_wave_barrier();
 }
 
-// One WAVE per macroblock of the predictive frame (a block holds some tens to a few hundred points): no barriers inside
-// the iteration, sums by cross-lane shuffles, the 3x3 SVD computed redundantly by every lane.
+// ICP of one macroblock by WAVES waves.  WAVES = 1: one wave per macroblock, four macroblocks per workgroup, no
+// barrier inside the iteration (sums by cross-lane shuffles) -- the shape for frames with thousands of blocks, where the
+// chip is full anyway.  WAVES = 4: the whole workgroup works on one macroblock (two barriers per iteration to add the
+// waves' partial sums) -- for frames with few blocks, where the latency of the longest block is what counts.
+// The 3x3 SVD is computed redundantly by every lane; all lanes take the same decisions from the same sums.
 constexpr int kIcpWaves = kDBlock / 64;
 constexpr uint32_t kIcpTargetCap = 1024;  // targets staged in LDS per wave (16 KB); larger blocks read them from HBM/L2
 
+template <int WAVES>
 __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
-  __shared__ float4 s_tgt_all[kIcpWaves][kIcpTargetCap];
+  __shared__ float4 s_tgt_all[kIcpWaves * kIcpTargetCap];
+  __shared__ float s_redf[2][kIcpWaves][9];
+  __shared__ double s_redd[2][kIcpWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t b = blockIdx.x * kIcpWaves + (uint32_t)wave;
+  const uint32_t b = WAVES == 1 ? blockIdx.x * kIcpWaves + (uint32_t)wave : blockIdx.x;
   const bool live = b < a.p_tree.n_blocks && a.results[min(b, a.p_tree.n_blocks - 1)].do_icp != 0;
-  if (!live) return;  // no workgroup barrier below: waves are independent
+  if (!live) return;  // WAVES == 1: waves are independent; WAVES == 4: the whole workgroup leaves
   const BlockResult r0 = a.results[b];
   const uint32_t s0 = a.i_tree.leaf_start[r0.i_block], ns = r0.n_i;
   const uint32_t t0 = a.p_tree.leaf_start[b], nt = r0.n_p;
   const float4* src = a.i_xyzc + s0;  // source = the I frame's block, target = the predictive frame's block (impl.hpp:547-548)
   const float4* tgt = a.p_xyzc + t0;
-  float4* s_tgt = s_tgt_all[wave];
-  const bool staged = nt <= kIcpTargetCap;
+  float4* s_tgt = WAVES == 1 ? s_tgt_all + (size_t)wave * kIcpTargetCap : s_tgt_all;
+  const uint32_t first = WAVES == 1 ? (uint32_t)lane : threadIdx.x, step = 64u * WAVES;
+  const bool staged = nt <= kIcpTargetCap * (WAVES == 1 ? 1u : (uint32_t)kIcpWaves);
   if (staged) {
-    for (uint32_t j = lane; j < nt; j += 64) s_tgt[j] = tgt[j];
-    wave_sync();
+    for (uint32_t j = first; j < nt; j += step) s_tgt[j] = tgt[j];
+    if (WAVES == 1) wave_sync(); else __syncthreads();
   }
   auto nearest = [&](float x, float y, float z, uint32_t& slot, float& d) {
     if (staged) nearest_lds(s_tgt, nt, x, y, z, slot, d);
     else nearest_in(tgt, nt, x, y, z, slot, d);
   };
-  float4* cur = a.cur + s0;  // lane-private elements (i = lane, lane + 64, ...): no synchronisation needed
+  int parity = 0;
+  // sums over the block's points: v[0..count) floats and one double
+  auto block_sums = [&](float* v, int count, double& dv) {
+    for (int k = 0; k < count; ++k) v[k] = wave_sum_f(v[k]);
+    dv = wave_sum_d(dv);
+    if (WAVES > 1) {
+      if (lane == 0) {
+        for (int k = 0; k < count; ++k) s_redf[parity][wave][k] = v[k];
+        s_redd[parity][wave] = dv;
+      }
+      __syncthreads();
+      for (int k = 0; k < count; ++k) v[k] = (s_redf[parity][0][k] + s_redf[parity][1][k]) + (s_redf[parity][2][k] + s_redf[parity][3][k]);
+      dv = (s_redd[parity][0] + s_redd[parity][1]) + (s_redd[parity][2] + s_redd[parity][3]);
+      parity ^= 1;  // the other buffer next time: no second barrier needed
+    }
+  };
+  float4* cur = a.cur + s0;  // thread-private elements (i = first, first + step, ...): no synchronisation needed
   uint32_t* nn = a.nn + s0;
-  for (uint32_t i = lane; i < ns; i += 64) cur[i] = src[i];
+  for (uint32_t i = first; i < ns; i += step) cur[i] = src[i];
   float fin[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) fin[k] = (k % 5 == 0) ? 1.f : 0.f;
@@ -305,23 +329,23 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
   const double mse_rel = 3.0 * (double)a.transformation_epsilon, mse_abs = 1e-12;
   while (true) {
     // correspondences: nearest target of every (moved) source point; sums for the means
-    float sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
+    float m6[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double sd = 0;
-    for (uint32_t i = lane; i < ns; i += 64) {
+    for (uint32_t i = first; i < ns; i += step) {
       const float4 p = cur[i];
       uint32_t j; float d;
       nearest(p.x, p.y, p.z, j, d);
       nn[i] = j;
       const float4 q = staged ? s_tgt[j] : tgt[j];
-      sx += p.x; sy += p.y; sz += p.z;
-      tx += q.x; ty += q.y; tz += q.z;
+      m6[0] += p.x; m6[1] += p.y; m6[2] += p.z;
+      m6[3] += q.x; m6[4] += q.y; m6[5] += q.z;
       sd += (double)d;
     }
-    const float smx = wave_sum_f(sx) / fn, smy = wave_sum_f(sy) / fn, smz = wave_sum_f(sz) / fn;
-    const float tmx = wave_sum_f(tx) / fn, tmy = wave_sum_f(ty) / fn, tmz = wave_sum_f(tz) / fn;
-    const double mse = wave_sum_d(sd) / (double)ns;
+    block_sums(m6, 6, sd);
+    const float smx = m6[0] / fn, smy = m6[1] / fn, smz = m6[2] / fn, tmx = m6[3] / fn, tmy = m6[4] / fn, tmz = m6[5] / fn;
+    const double mse = sd / (double)ns;
     float sg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = lane; i < ns; i += 64) {
+    for (uint32_t i = first; i < ns; i += step) {
       const float4 p = cur[i];
       const float4 q = staged ? s_tgt[nn[i]] : tgt[nn[i]];
       const float ds[3] = {p.x - smx, p.y - smy, p.z - smz}, dt[3] = {q.x - tmx, q.y - tmy, q.z - tmz};
@@ -330,8 +354,10 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) sg[3 * r + c] += dt[r] * ds[c];
     }
+    double unused = 0;
+    block_sums(sg, 9, unused);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sg[k] = wave_sum_f(sg[k]) / fn;
+    for (int k = 0; k < 9; ++k) sg[k] /= fn;
     // every lane: the same transformation from the same sums
     float Rm[9], tr[16];
     umeyama_rotation(sg, Rm);
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
         nf[4 * r + c] = ((tr[4 * r] * fin[c] + tr[4 * r + 1] * fin[4 + c]) + tr[4 * r + 2] * fin[8 + c]) + tr[4 * r + 3] * fin[12 + c];
 #pragma unroll
     for (int k = 0; k < 16; ++k) fin[k] = nf[k];
-    for (uint32_t i = lane; i < ns; i += 64) {  // move the source points
+    for (uint32_t i = first; i < ns; i += step) {  // move the source points
       const float4 p = cur[i];
       float4 o = p;
       se3(tr, p.x, p.y, p.z, o.x, o.y, o.z);
@@ -370,19 +396,21 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
       else if (fabs(mse - prev_mse) < mse_abs || fabs(mse - prev_mse) / prev_mse < mse_rel) stop = true;
     }
     prev_mse = mse;
-    if (stop) break;  // uniform across the wave: every lane holds the same values
+    if (stop) break;  // uniform: every lane holds the same values
   }
   // getFitnessScore: mean squared distance of the source moved by the final transformation to its nearest target
   double fs = 0;
-  for (uint32_t i = lane; i < ns; i += 64) {
+  for (uint32_t i = first; i < ns; i += step) {
     float x, y, z;
     se3(fin, src[i].x, src[i].y, src[i].z, x, y, z);
     uint32_t j; float d;
     nearest(x, y, z, j, d);
     fs += (double)d;
   }
-  const double fitness = wave_sum_d(fs) / (double)ns;
-  if (lane == 0) {
+  float none[1] = {0.f};
+  block_sums(none, 0, fs);
+  const double fitness = fs / (double)ns;
+  if (first == 0) {
     BlockResult* out = a.results + b;
     out->iterations = it;
     out->fitness = (float)fitness;
@@ -443,7 +471,10 @@ void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream) {
   if (a.p_tree.n_points) hipLaunchKernelGGL(k_block_points, dim3((a.p_tree.n_points + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a.p_tree, a.p_xyzc);
   if (!nbp) return;
   hipLaunchKernelGGL(k_block_match, dim3((2 * nbp + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a);
-  hipLaunchKernelGGL(k_block_icp, dim3((nbp + kIcpWaves - 1) / kIcpWaves), dim3(kDBlock), 0, stream, a);
+  const char* force = getenv("PCC_ICP_WAVES");  // test hook: "1" or "4" picks the kernel shape regardless of the block count
+  const bool per_wave = force ? force[0] == '1' : nbp > 2048;
+  if (per_wave) hipLaunchKernelGGL(k_block_icp<1>, dim3((nbp + kIcpWaves - 1) / kIcpWaves), dim3(kDBlock), 0, stream, a);
+  else hipLaunchKernelGGL(k_block_icp<kIcpWaves>, dim3(nbp), dim3(kDBlock), 0, stream, a);  // few blocks: latency counts
 }
 
 void launch_delta_gather(const GatherArgs& a, hipStream_t stream) {

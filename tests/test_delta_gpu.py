@@ -76,8 +76,11 @@ def test_delta_encode_matches_oracle_given_the_transforms(pkg, ctx, pair, colour
         assert np.abs(blocks["rgb_offsets"]).max() > 0
 
 
-def test_delta_icp_close_to_oracle_icp(pkg, ctx, pair):
-    """The GPU's per-block ICP against the oracle's restatement of PCL's defaults on the same blocks."""
+@pytest.mark.parametrize("waves", ["1", "4"])
+def test_delta_icp_close_to_oracle_icp(pkg, ctx, pair, waves, monkeypatch):
+    """The GPU's per-block ICP (both kernel shapes: one wave per block, one workgroup per block) against the oracle's
+    restatement of PCL's defaults on the same blocks."""
+    monkeypatch.setenv("PCC_ICP_WAVES", waves)
     i_cloud, p_cloud = pair
     got = ctx.encode_delta(i_cloud, p_cloud, _params(pkg))
     simp = D.simplify(p_cloud, RES)
