@@ -244,6 +244,9 @@ def main():
                                   "occupancy_range_coder": round(stats["occupancy_coder_us"] / 1e3, 3),
                                   "jpeg_huffman": round(stats["jpeg_us"] / 1e3, 3),
                                   "colour_range_coder": round(stats["colour_coder_us"] / 1e3, 3)},
+            "host_cpu_ms_per_frame": {"launch_call": round(stats["launch_cpu_us"] / 1e3, 3),
+                                      "finish_call": round(stats["finish_cpu_us"] / 1e3, 3),
+                                      "entropy_call": round(stats["entropy_cpu_us"] / 1e3, 3)},
             "roofline": roofline,
             "kernels_ms_per_frame": {k: round(v, 5) for k, v in sorted(frame_ms.items(), key=lambda kv: -kv[1])},
             "cpu_baseline": cpu_baseline,

@@ -34,7 +34,7 @@ EXPORTS = [
     "pcc_set_option",
     "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_contexts",
     "pcc_pipeline_context",
-    "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_kernel_times",
+    "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
     "pcc_quality_metrics", "pcc_remove_outliers",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
@@ -158,6 +158,7 @@ def load_library():
     lib.pcc_pipeline_encode.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_pipeline_gpu_stage_only.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params)]
     lib.pcc_pipeline_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.pcc_pipeline_cpu_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_pipeline_kernel_times.argtypes = [vp, C.POINTER(KernelTimes), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.pcc_pipeline_last_error.restype = C.c_char_p
     lib.pcc_pipeline_last_error.argtypes = [vp]
@@ -476,7 +477,11 @@ class Pipeline:
         self.lib.pcc_pipeline_stats(self.h, buf)
         keys = ("launch_us", "finish_us", "entropy_us", "occupancy_coder_us", "jpeg_us", "colour_coder_us",
                 "host_stage_us", "frames")
-        return dict(zip(keys, buf))
+        out = dict(zip(keys, buf))
+        cpu = (C.c_double * 4)()
+        self.lib.pcc_pipeline_cpu_times(self.h, cpu)
+        out.update(launch_cpu_us=cpu[0], finish_cpu_us=cpu[1], entropy_cpu_us=cpu[2])
+        return out
 
 
 MANUAL_CONFIGURATION = "MANUAL_CONFIGURATION"

@@ -14,8 +14,12 @@
 // the ones the serial loop would have produced.
 //
 // Built on the public C ABI only (pcc_hotpath_launch / pcc_hotpath_finish / pcc_entropy_encode[2]).
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <chrono>
@@ -30,6 +34,11 @@
 
 namespace {
 typedef std::chrono::steady_clock Clock;
+inline double thread_cpu_us() {  // CPU time this thread has consumed
+  timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
 inline double us_since(Clock::time_point t0) { return std::chrono::duration<double, std::micro>(Clock::now() - t0).count(); }
 
 struct Job {  // one pcc_pipeline_encode call
@@ -51,6 +60,7 @@ struct Ready {  // a context whose GPU stage is done
 struct pcc_pipeline {
   int device = 0;
   int n_entropy = 0, n_gpu = 0;
+  int batch = PCC_MAX_FRAMES_AT_ONCE;  // frames an entropy thread codes in one loop
   std::vector<pcc_ctx*> ctxs;
   std::vector<std::thread> threads;
   std::mutex mu;  // guards everything below up to `stat_mu`
@@ -71,6 +81,7 @@ struct pcc_pipeline {
   // timing of the last job, summed over frames (microseconds)
   std::mutex stat_mu;
   double t_launch = 0, t_finish = 0, t_entropy = 0, host_us[4] = {0, 0, 0, 0};
+  double cpu_launch = 0, cpu_finish = 0, cpu_entropy = 0;  // CPU time (not wall time) of the same calls
   size_t frames_done = 0;
   // HIP-event kernel times of the frames that ran on a context with profiling enabled (sums per kernel name)
   std::vector<const char*> k_name;
@@ -100,7 +111,7 @@ struct pcc_pipeline {
   void gpu_thread() {
     uint64_t seen = 0;
     while (next_job(seen)) {
-      double tl = 0, tf = 0;
+      double tl = 0, tf = 0, cl = 0, cf = 0;
       for (;;) {
         Ready r;
         {
@@ -115,12 +126,16 @@ struct pcc_pipeline {
         r.prm = job.params;
         r.prm.frame_id = job.params.frame_id + (uint32_t)r.frame;  // frame_ID_ by sequence index
         Clock::time_point t0 = Clock::now();
+        double c0 = thread_cpu_us();
         int rc = pcc_hotpath_launch(r.ctx, job.frames[r.frame], job.counts[r.frame], job.stride, job.rgb_offset, &r.prm);
         tl += us_since(t0);
+        cl += thread_cpu_us() - c0;
         if (rc == PCC_OK) {
           t0 = Clock::now();
+          c0 = thread_cpu_us();
           rc = pcc_hotpath_finish(r.ctx, &r.hot);
           tf += us_since(t0);
+          cf += thread_cpu_us() - c0;
         }
         pcc_kernel_times kt;
         if (rc == PCC_OK && pcc_get_kernel_times(r.ctx, &kt) == PCC_OK && kt.count > 0) {
@@ -135,6 +150,7 @@ struct pcc_pipeline {
           ++k_frames;
         }
         note_error(r.ctx, rc);
+        bool wake_one = false, wake_all = false;
         {
           std::lock_guard<std::mutex> lk(mu);
           status[r.frame] = rc;
@@ -145,12 +161,16 @@ struct pcc_pipeline {
             free_ctx.push_back(r.ctx);
             cv_free.notify_one();
           }
+          wake_one = ready.size() >= (size_t)batch;  // a full batch is waiting: one entropy thread is enough
+          wake_all = gpu_done >= job.n_frames;
         }
-        cv_ready.notify_all();
+        if (wake_all) cv_ready.notify_all();
+        else if (wake_one) cv_ready.notify_one();
       }
       {
         std::lock_guard<std::mutex> lk(stat_mu);
         t_launch += tl; t_finish += tf;
+        cpu_launch += cl; cpu_finish += cf;
       }
       cv_ready.notify_all();
       job_done();
@@ -160,7 +180,7 @@ struct pcc_pipeline {
   void entropy_thread() {
     uint64_t seen = 0;
     while (next_job(seen)) {
-      double te = 0, hu[4] = {0, 0, 0, 0};
+      double te = 0, ce = 0, hu[4] = {0, 0, 0, 0};
       size_t done = 0;
       for (;;) {
         constexpr int kAtOnce = PCC_MAX_FRAMES_AT_ONCE;
@@ -168,10 +188,10 @@ struct pcc_pipeline {
         int nr = 0;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv_ready.wait(lk, [&] { return !ready.empty() || gpu_done >= job.n_frames; });
-          // take what is there, but leave the other entropy threads their share
-          const size_t share = (ready.size() + (size_t)n_entropy - 1) / (size_t)n_entropy;
-          while (nr < kAtOnce && !ready.empty() && (nr < 2 || (size_t)nr < share)) { r[nr++] = ready.front(); ready.pop_front(); }
+          // Four frames in one coder loop cost 1.5 ms of CPU per frame, one frame alone 3.3 ms (tools/rc_speed.py), and
+          // the CPU is what limits the pipeline: wait for a full batch unless the GPU stage has nothing more to give.
+          cv_ready.wait(lk, [&] { return ready.size() >= (size_t)batch || gpu_done >= job.n_frames; });
+          while (nr < kAtOnce && nr < batch && !ready.empty()) { r[nr++] = ready.front(); ready.pop_front(); }
           if (nr == 0) break;  // every frame went through the GPU stage and the queue is empty
         }
         pcc_bitstream bs[kAtOnce];
@@ -183,9 +203,11 @@ struct pcc_pipeline {
         pcc_bitstream* o[kAtOnce];
         for (int i = 0; i < nr; ++i) { c[i] = r[i].ctx; h[i] = &r[i].hot; pp[i] = &r[i].prm; o[i] = &bs[i]; }
         Clock::time_point t0 = Clock::now();
+        const double c0 = thread_cpu_us();
         const int rc_all = pcc_entropy_encode_many(nr, c, h, pp, o);
         for (int i = 0; i < nr; ++i) rc[i] = rc_all;
         te += us_since(t0);
+        ce += thread_cpu_us() - c0;
         for (int i = 0; i < nr; ++i) {
           if (rc[i] == PCC_OK) {
             double hh[4];
@@ -210,6 +232,7 @@ struct pcc_pipeline {
       {
         std::lock_guard<std::mutex> lk(stat_mu);
         t_entropy += te;
+        cpu_entropy += ce;
         for (int i = 0; i < 4; ++i) host_us[i] += hu[i];
         frames_done += done;
       }
@@ -217,6 +240,27 @@ struct pcc_pipeline {
     }
   }
 };
+
+// one logical CPU per physical core, out of the CPUs this process may run on
+static std::vector<int> one_cpu_per_core() {
+  std::vector<int> out;
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, &allowed)) continue;
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+    FILE* f = fopen(path, "r");
+    int first = c;
+    if (f) {
+      if (fscanf(f, "%d", &first) != 1) first = c;
+      fclose(f);
+    }
+    if (first == c || !CPU_ISSET(first, &allowed)) out.push_back(c);  // the lowest sibling stands for the core
+  }
+  return out;
+}
 
 extern "C" {
 
@@ -230,8 +274,12 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) p->n_gpu = v;
   }
-  // an entropy thread holds up to four contexts (usually two), a GPU-stage thread one, plus some in the queue
-  const int n_ctx = 3 * p->n_entropy + 2 * p->n_gpu;
+  if (const char* e = getenv("PCC_PIPELINE_BATCH")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= PCC_MAX_FRAMES_AT_ONCE) p->batch = v;
+  }
+  // an entropy thread holds `batch` contexts, a GPU-stage thread one, plus a batch or two waiting in the queue
+  const int n_ctx = p->batch * p->n_entropy + 2 * p->n_gpu + 2 * p->batch;
   for (int w = 0; w < n_ctx; ++w) {
     pcc_ctx* c = pcc_create(device);
     if (!c) {  // no usable GPU: there is no CPU fallback
@@ -243,6 +291,23 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   }
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p] { p->gpu_thread(); });
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p] { p->entropy_thread(); });
+  // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
+  // threads of one core run at about half speed each.  PCC_PIPELINE_PIN=cores gives every entropy thread a physical
+  // core of its own (first hardware thread of the k-th allowed core, starting at core PCC_PIPELINE_PIN_OFFSET).
+  if (const char* e = getenv("PCC_PIPELINE_PIN")) {
+    if (!strcmp(e, "cores")) {
+      const std::vector<int> cores = one_cpu_per_core();
+      int off = 0;
+      if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) off = atoi(o);
+      if (!cores.empty())
+        for (int w = 0; w < p->n_entropy; ++w) {
+          cpu_set_t set;
+          CPU_ZERO(&set);
+          CPU_SET(cores[(size_t)(off + w) % cores.size()], &set);
+          (void)pthread_setaffinity_np(p->threads[(size_t)p->n_gpu + w].native_handle(), sizeof(set), &set);
+        }
+    }
+  }
   return p;
 }
 
@@ -278,6 +343,7 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->status.assign(n_frames, PCC_OK);
     p->err.clear();
     p->t_launch = p->t_finish = p->t_entropy = 0;
+    p->cpu_launch = p->cpu_finish = p->cpu_entropy = 0;
     p->host_us[0] = p->host_us[1] = p->host_us[2] = p->host_us[3] = 0;
     p->frames_done = 0;
     p->k_name.clear(); p->k_ms.clear(); p->k_launches.clear(); p->k_frames = 0;
@@ -327,6 +393,14 @@ int pcc_pipeline_stats(pcc_pipeline* p, double out_us[8]) {
   out_us[0] = p->t_launch * k; out_us[1] = p->t_finish * k; out_us[2] = p->t_entropy * k;
   for (int i = 0; i < 4; ++i) out_us[3 + i] = p->host_us[i] * k;
   out_us[7] = (double)p->frames_done;
+  return PCC_OK;
+}
+
+int pcc_pipeline_cpu_times(pcc_pipeline* p, double out_us[4]) {
+  if (!p || !out_us) return PCC_ERR_ARG;
+  const double k = p->frames_done ? 1.0 / (double)p->frames_done : 0.0;
+  out_us[0] = p->cpu_launch * k; out_us[1] = p->cpu_finish * k; out_us[2] = p->cpu_entropy * k;
+  out_us[3] = (double)p->frames_done;
   return PCC_OK;
 }
 

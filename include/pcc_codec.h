@@ -199,6 +199,9 @@ int pcc_pipeline_gpu_stage_only(pcc_pipeline *p, const void *const *dev_frames, 
 /* per-frame means of the last call, microseconds: launch, finish, entropy call wall time; then the four values of
  * pcc_get_host_times; out_us[7] = frames processed */
 int pcc_pipeline_stats(pcc_pipeline *p, double out_us[8]);
+/* CPU time (not wall time) the pipeline's threads spent in the same three calls, per-frame means, microseconds;
+ * out_us[3] = frames processed.  Wall minus CPU = time asleep waiting for the GPU. */
+int pcc_pipeline_cpu_times(pcc_pipeline *p, double out_us[4]);
 /* HIP-event kernel times of the last call, summed over the frames that ran on a context with profiling
  * enabled: sums->ms[i] = total milliseconds of kernel sums->name[i], launches[i] = number of launches
  * (arrays of PCC_MAX_KERNEL_TIMES), *frames = profiled frames */
