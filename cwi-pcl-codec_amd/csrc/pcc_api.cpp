@@ -134,6 +134,7 @@ struct pcc_ctx {
   pcc_params params{};
   bool simplified_valid = false;
   size_t last_L = 0;
+  double usual_wait_ns[3] = {0, 0, 0};  // how long the waits took lately: kernels of a frame, copies, anything else
   pcc_hot_result last_hot{};
 };
 
@@ -196,7 +197,7 @@ int reserve(pcc_ctx* ctx, size_t n) {
 // frames needs it.  hipEventSynchronize spins in user space even on a hipEventBlockingSync event (measured: 0.71 ms of
 // CPU time for 0.77 ms of waiting per frame), so the default is to poll the event between short sleeps; the few
 // microseconds of extra latency are hidden by the other frames in flight.  PCC_WAIT=event restores the runtime's wait.
-int wait_stream(pcc_ctx* ctx) {
+int wait_stream(pcc_ctx* ctx, int site = 2) {
   static const int mode = [] {
     const char* e = getenv("PCC_WAIT");
     return (e && !strcmp(e, "event")) ? 1 : 0;
@@ -211,15 +212,26 @@ int wait_stream(pcc_ctx* ctx) {
     (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
     slack_set = true;
   }
-  long ns = 5000;  // first look soon (short waits: copies), then back off to a steady 40 us
+  // A sleep costs a few microseconds of CPU (two kernel crossings and a context switch), so few long sleeps beat many
+  // short ones: sleep through most of what this wait took the last times on this context (kernels of a frame: some
+  // hundred microseconds; copies: some ten), then look every 30 us.
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  double& usual = ctx->usual_wait_ns[site];
+  long ns = usual > 60000.0 ? (long)(0.7 * usual) : 5000;
   for (;;) {
     const hipError_t q = hipEventQuery(ctx->ev_wait);
-    if (q == hipSuccess) return PCC_OK;
+    if (q == hipSuccess) break;
     if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipEventQuery");
     timespec ts{0, ns};
     nanosleep(&ts, nullptr);
-    if (ns < 40000) ns *= 2;
+    ns = ns < 30000 ? std::min(2 * ns, 30000L) : 30000;
   }
+  timespec t1;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  const double took = (double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec);
+  usual = usual == 0.0 ? took : 0.75 * usual + 0.25 * took;
+  return PCC_OK;
 }
 
 // the kernel sequence of one frame + the FrameState read-back, all asynchronous on the context's stream
@@ -424,7 +436,7 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
 
 // wait for the frame's kernels and its FrameState; a frame that needs more sort passes than were enqueued runs again
 static int wait_frame_state(pcc_ctx* ctx) {
-  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  { const int wrc = wait_stream(ctx, 0); if (wrc != PCC_OK) return wrc; }
   const FrameState& st = *ctx->h_state.p;
   if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
     // deeper tree than the frames before: run the frame again with every pass enqueued
@@ -493,7 +505,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     PCC_HIP(ctx->h_centroid.ensure(3 * L + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_centroid.p, ctx->d_centroid.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
   }
-  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  { const int wrc = wait_stream(ctx, 1); if (wrc != PCC_OK) return wrc; }
 
   for (int a = 0; a < 3; ++a) { out->bbox[a] = st.mn[a]; out->bbox[3 + a] = st.mx[a]; }
   out->depth = (uint32_t)st.depth;
