@@ -193,3 +193,32 @@ def test_cfg5_moving_sphere_sequence(pkg, oracle, ctx):
         assert abs(float(own["convergence_percentage"]) - got["shared_macroblock_convergence_percentage"]) < 0.02
         assert abs(len(own["p_stream"]) - len(got["p_stream"])) <= 0.02 * len(got["p_stream"]) + 40
         assert got["shared_macroblock_percentage"] > 0.9 and got["convergence_count"] > 300
+
+
+@pytest.mark.parametrize("mb,on_original,waves", [(8, False, "4"), (32, False, "1"), (64, True, "1"), (128, True, "4")])
+def test_delta_other_macroblock_sizes_and_big_blocks(pkg, ctx, pair, mb, on_original, waves, monkeypatch):
+    """Macroblock sizes other than 16; with 64-voxel blocks on the unsimplified cloud a block holds thousands of points
+    (more targets than the ICP kernel stages in LDS: the HBM/L2 path)."""
+    monkeypatch.setenv("PCC_ICP_WAVES", waves)
+    i_cloud, p_cloud = pair
+    prm = _params(pkg, macroblock_size=mb)
+    got = ctx.encode_delta(i_cloud, p_cloud, prm, icp_on_original=on_original)
+    want = D.encode_delta(i_cloud, p_cloud, RES, RES, macroblock_size=mb, icp_on_original=on_original, icp_fn=_replay(got))
+    assert [tuple(b["key"][:3]) for b in got["blocks"]] == [b["key"] for b in want["blocks"]]
+    assert [bool(b["do_icp"]) for b in got["blocks"]] == [b["icp"] for b in want["blocks"]]
+    assert got["p_stream"] == want["p_stream"] and got["i_stream"] == want["i_stream"]
+    assert got["out_cloud"].tobytes() == want["out_cloud"].tobytes()
+    if mb >= 64:
+        assert int(got["blocks"]["n_p"].max()) > (1024 if waves == "1" else 4096)
+    # a few blocks against the oracle's own ICP
+    simp = p_cloud if on_original else D.simplify(p_cloud, RES)
+    _, i_lists, _, _ = D.tree(i_cloud, RES * mb)
+    _, p_lists, _, _ = D.tree(simp, RES * mb)
+    todo = [(b, pl) for b, pl in zip(got["blocks"], p_lists) if b["do_icp"]]
+    todo.sort(key=lambda t: -int(t[0]["n_p"]))
+    for b, pl in todo[:3]:
+        src, tgt = D._xyz(i_cloud[i_lists[b["i_block"]]]), D._xyz(simp[pl])
+        conv, final, fitness = D.icp(src, tgt)
+        assert (conv and fitness < 2 * RES) == bool(b["converged"])
+        diff = np.abs(D.transform_points(src, final) - D.transform_points(src, b["rt"].reshape(4, 4))).max()
+        assert diff < 0.5 * RES
