@@ -15,7 +15,9 @@ def main():
                       "from kernels order by start").fetchall()
     per = {}
     for name, dur, vg, sg, lds, gx, wx, start in rows:
-        short = re.sub(r"\(.*", "", name).replace("pcc::", "")
+        short = name.replace("(anonymous namespace)::", "").replace("pcc::", "")
+        short = re.sub(r"^void ", "", short)
+        short = re.sub(r"\(.*", "", short)
         per.setdefault(short, []).append((dur, vg, sg, lds, gx, wx))
     total = 0.0
     out = []
