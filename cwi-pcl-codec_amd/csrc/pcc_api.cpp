@@ -103,7 +103,7 @@ struct pcc_ctx {
   DevBuf<uint8_t> d_delta_i, d_delta_p, d_delta_intra, d_delta_out;
   DevBuf<uint64_t> d_ifull, d_pfull;
   DevBuf<float4> d_ixyzc, d_pxyzc, d_cur;
-  DevBuf<uint32_t> d_nn, d_dst_intra, d_dst_out, d_fake_start;
+  DevBuf<uint32_t> d_nn, d_dst_intra, d_dst_out, d_fake_start, d_work, d_order, d_counts;
   DevBuf<BlockResult> d_blocks;
   DevBuf<float> d_mdec;
   std::vector<BlockResult> h_blocks;
@@ -292,7 +292,7 @@ void pcc_destroy(pcc_ctx* c) {
   for (pcc_ctx*& sc : c->sub) { if (sc) pcc_destroy(sc); sc = nullptr; }
   c->d_delta_i.release(); c->d_delta_p.release(); c->d_delta_intra.release(); c->d_delta_out.release(); c->d_ifull.release();
   c->d_pfull.release(); c->d_ixyzc.release(); c->d_pxyzc.release(); c->d_cur.release(); c->d_nn.release(); c->d_dst_intra.release();
-  c->d_dst_out.release(); c->d_fake_start.release(); c->d_blocks.release(); c->d_mdec.release();
+  c->d_dst_out.release(); c->d_fake_start.release(); c->d_work.release(); c->d_order.release(); c->d_counts.release(); c->d_blocks.release(); c->d_mdec.release();
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -962,6 +962,10 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   PCC_HIP(ctx->d_cur.ensure(da.i_tree.n_points));
   PCC_HIP(ctx->d_nn.ensure(da.i_tree.n_points));
   PCC_HIP(ctx->d_blocks.ensure(nbp));
+  PCC_HIP(ctx->d_work.ensure(nbp));
+  PCC_HIP(ctx->d_order.ensure(nbp));
+  PCC_HIP(ctx->d_counts.ensure(4));
+  da.work = ctx->d_work.p; da.order = ctx->d_order.p; da.counts = ctx->d_counts.p;
   da.i_full = ctx->d_ifull.p; da.p_full = ctx->d_pfull.p;
   da.i_xyzc = ctx->d_ixyzc.p; da.p_xyzc = ctx->d_pxyzc.p; da.cur = ctx->d_cur.p; da.nn = ctx->d_nn.p;
   da.results = ctx->d_blocks.p;
@@ -972,7 +976,8 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   da.transformation_epsilon = dp->transformation_epsilon > 0.f ? dp->transformation_epsilon : 1e-8f;
   da.var_threshold = dp->icp_var_threshold > 0.f ? dp->icp_var_threshold : 100.f;
   da.do_icp_color_offset = cp.do_icp_color_offset ? 1 : 0;
-  launch_delta_blocks(da, ctx->stream);
+  // second stream: the residual intra coder's (idle until the blocks are decided); its two timing events do as fork / join
+  launch_delta_blocks(da, ctx->stream, ctx->sub[3]->stream, ctx->sub[3]->ev_begin, ctx->sub[3]->ev_end);
   PCC_HIP(hipGetLastError());
   ctx->h_blocks.resize(nbp);
   ctx->h_pstart.resize((size_t)nbp + 1);

@@ -48,6 +48,10 @@ struct DeltaArgs {
   float4* cur;                 // [n_i] scratch: the source points of a block while ICP moves them
   uint32_t* nn;                // [n_i] scratch: nearest target of every source point
   BlockResult* results;        // [p blocks]
+  uint32_t* work;              // [p blocks] n_i * n_p of the blocks that go through ICP, else 0
+  uint32_t* order;             // [p blocks] those blocks by falling work
+  uint32_t* counts;            // [2] how many there are, how many of them are heavy
+  int shape;                   // 0: heavy blocks get a workgroup each, the others a wave; 1: a workgroup each; 2: a wave each
   double point_resolution;
   double octree_resolution;    // voxel size of the coder; a macroblock is macroblock_size voxels a side
   int macroblock_size;
@@ -57,7 +61,9 @@ struct DeltaArgs {
   int do_icp_color_offset;
 };
 
-void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream);
+// aux, ev_fork, ev_join: an idle second stream and two events (or null): the two ICP kernel shapes then run side by side
+void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream, hipStream_t aux = nullptr, hipEvent_t ev_fork = nullptr,
+                         hipEvent_t ev_join = nullptr);
 
 // second phase, after the host has decided which blocks are predicted:
 //   out_intra[dst_intra[b] ..] = points of block b (exclusive / failed blocks), 32-byte PointXYZRGB

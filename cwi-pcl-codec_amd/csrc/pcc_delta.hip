@@ -114,6 +114,37 @@ __global__ __launch_bounds__(kDBlock) void k_block_match(DeltaArgs a) {
   }
   r.do_icp = do_icp ? 1 : 0;
   a.results[b] = r;
+  a.work[b] = do_icp ? (uint32_t)min((uint64_t)r.n_i * r.n_p, (uint64_t)0xffffffffu) : 0u;  // distance evaluations per ICP iteration
+}
+
+// Order of the ICP work: macroblocks by falling n_source x n_target (power-of-two classes; the order inside a class is
+// whatever the atomics give -- it only decides which wave takes which block, not any result).  Long blocks first keeps
+// the tail of the ICP kernel short; blocks above kIcpHeavy go to the workgroup-per-block shape.
+constexpr uint32_t kIcpHeavy = 128u * 128u;
+__global__ __launch_bounds__(1024) void k_block_order(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ order, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_count[33], s_start[33], s_heavy;
+  if (threadIdx.x < 33) s_count[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) s_heavy = 0u;
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n; b += 1024u) {
+    const uint32_t w = work[b];
+    if (!w) continue;
+    atomicAdd(&s_count[32 - __clz(w)], 1u);  // class 1..32
+    if (w >= kIcpHeavy) atomicAdd(&s_heavy, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t at = 0;
+    for (int c = 32; c >= 1; --c) { s_start[c] = at; at += s_count[c]; }
+    counts[0] = at;       // blocks that go through ICP
+    counts[1] = s_heavy;  // the first so many of them are heavy
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n; b += 1024u) {
+    const uint32_t w = work[b];
+    if (!w) continue;
+    order[atomicAdd(&s_start[32 - __clz(w)], 1u)] = b;
+  }
 }
 
 // ---- ICP helpers ----
@@ -256,7 +287,20 @@ __device__ __forceinline__ float dist2(float x, float y, float z, const float4& 
 __device__ __forceinline__ void nearest_lds(const float4* s_tgt, uint32_t nt, float x, float y, float z, uint32_t& best_slot, float& best) {
   best = FLT_MAX;
   best_slot = 0;
-  for (uint32_t j = 0; j < nt; ++j) {
+  uint32_t j = 0;
+  for (; j + 4 <= nt; j += 4) {  // four targets in flight: the LDS reads and the arithmetic of one overlap the compares of another
+    const float4 q0 = s_tgt[j], q1 = s_tgt[j + 1], q2 = s_tgt[j + 2], q3 = s_tgt[j + 3];
+    const float d0 = dist2(x, y, z, q0), d1 = dist2(x, y, z, q1), d2 = dist2(x, y, z, q2), d3 = dist2(x, y, z, q3);
+    // the lowest of the four, the earlier one on ties; then against the best so far (strictly smaller wins: lowest index)
+    const bool a = d1 < d0, b = d3 < d2;
+    const float m01 = a ? d1 : d0, m23 = b ? d3 : d2;
+    const uint32_t i01 = a ? j + 1 : j, i23 = b ? j + 3 : j + 2;
+    const bool c = m23 < m01;
+    const float m = c ? m23 : m01;
+    const uint32_t im = c ? i23 : i01;
+    if (m < best) { best = m; best_slot = im; }
+  }
+  for (; j < nt; ++j) {
     const float d = dist2(x, y, z, s_tgt[j]);
     if (d < best) { best = d; best_slot = j; }
   }
@@ -273,17 +317,21 @@ __device__ __forceinline__ void wave_sync() {  // LDS written by some lanes of t
 // waves' partial sums) -- for frames with few blocks, where the latency of the longest block is what counts.
 // The 3x3 SVD is computed redundantly by every lane; all lanes take the same decisions from the same sums.
 constexpr int kIcpWaves = kDBlock / 64;
-constexpr uint32_t kIcpTargetCap = 1024;  // targets staged in LDS per wave (16 KB); larger blocks read them from HBM/L2
+constexpr uint32_t kIcpTargetCap = 512;  // per wave: targets staged in LDS (8 KB) and as many moving source points (8 KB);
+                                         // larger blocks keep them in HBM/L2
 
 template <int WAVES>
 __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
   __shared__ float4 s_tgt_all[kIcpWaves * kIcpTargetCap];
+  __shared__ float4 s_cur_all[kIcpWaves * kIcpTargetCap];
   __shared__ float s_redf[2][kIcpWaves][9];
   __shared__ double s_redd[2][kIcpWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t b = WAVES == 1 ? blockIdx.x * kIcpWaves + (uint32_t)wave : blockIdx.x;
-  const bool live = b < a.p_tree.n_blocks && a.results[min(b, a.p_tree.n_blocks - 1)].do_icp != 0;
-  if (!live) return;  // WAVES == 1: waves are independent; WAVES == 4: the whole workgroup leaves
+  // rank in the work order: the workgroup shape takes ranks [0, first_light), the wave shape [first_light, n_live)
+  const uint32_t n_live = a.counts[0], first_light = a.shape == 1 ? n_live : (a.shape == 2 ? 0u : a.counts[1]);
+  const uint32_t rank = WAVES == 1 ? first_light + blockIdx.x * kIcpWaves + (uint32_t)wave : blockIdx.x;
+  if (rank >= (WAVES == 1 ? n_live : first_light)) return;  // WAVES == 1: waves are independent; WAVES == 4: the whole workgroup leaves
+  const uint32_t b = a.order[rank];
   const BlockResult r0 = a.results[b];
   const uint32_t s0 = a.i_tree.leaf_start[r0.i_block], ns = r0.n_i;
   const uint32_t t0 = a.p_tree.leaf_start[b], nt = r0.n_p;
@@ -316,8 +364,11 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
       parity ^= 1;  // the other buffer next time: no second barrier needed
     }
   };
-  float4* cur = a.cur + s0;  // thread-private elements (i = first, first + step, ...): no synchronisation needed
-  uint32_t* nn = a.nn + s0;
+  // the moving copy of the source points, w = slot of the nearest target: in LDS when the block fits (an iteration
+  // then has no HBM round trip at all), else in HBM.  Thread-private elements (i = first, first + step, ...): no
+  // synchronisation needed.
+  const uint32_t cap = kIcpTargetCap * (WAVES == 1 ? 1u : (uint32_t)kIcpWaves);
+  float4* cur = ns <= cap ? (WAVES == 1 ? s_cur_all + (size_t)wave * kIcpTargetCap : s_cur_all) : a.cur + s0;
   for (uint32_t i = first; i < ns; i += step) cur[i] = src[i];
   float fin[16];
 #pragma unroll
@@ -335,7 +386,7 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
       const float4 p = cur[i];
       uint32_t j; float d;
       nearest(p.x, p.y, p.z, j, d);
-      nn[i] = j;
+      cur[i].w = __uint_as_float(j);
       const float4 q = staged ? s_tgt[j] : tgt[j];
       m6[0] += p.x; m6[1] += p.y; m6[2] += p.z;
       m6[3] += q.x; m6[4] += q.y; m6[5] += q.z;
@@ -347,7 +398,8 @@ __global__ __launch_bounds__(kDBlock) void k_block_icp(DeltaArgs a) {
     float sg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = first; i < ns; i += step) {
       const float4 p = cur[i];
-      const float4 q = staged ? s_tgt[nn[i]] : tgt[nn[i]];
+      const uint32_t j = __float_as_uint(p.w);
+      const float4 q = staged ? s_tgt[j] : tgt[j];
       const float ds[3] = {p.x - smx, p.y - smy, p.z - smz}, dt[3] = {q.x - tmx, q.y - tmy, q.z - tmz};
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -463,7 +515,7 @@ __global__ __launch_bounds__(kDBlock) void k_delta_gather(GatherArgs a) {
 
 }  // namespace
 
-void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream) {
+void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const uint32_t nbi = a.i_tree.n_blocks, nbp = a.p_tree.n_blocks;
   if (nbi) hipLaunchKernelGGL(k_block_keys, dim3((nbi + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a.i_tree.leaf_code, a.i_tree.prefix_code, nbi, a.i_full);
   if (nbp) hipLaunchKernelGGL(k_block_keys, dim3((nbp + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a.p_tree.leaf_code, a.p_tree.prefix_code, nbp, a.p_full);
@@ -471,10 +523,25 @@ void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream) {
   if (a.p_tree.n_points) hipLaunchKernelGGL(k_block_points, dim3((a.p_tree.n_points + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a.p_tree, a.p_xyzc);
   if (!nbp) return;
   hipLaunchKernelGGL(k_block_match, dim3((2 * nbp + kDBlock - 1) / kDBlock), dim3(kDBlock), 0, stream, a);
-  const char* force = getenv("PCC_ICP_WAVES");  // test hook: "1" or "4" picks the kernel shape regardless of the block count
-  const bool per_wave = force ? force[0] == '1' : nbp > 2048;
-  if (per_wave) hipLaunchKernelGGL(k_block_icp<1>, dim3((nbp + kIcpWaves - 1) / kIcpWaves), dim3(kDBlock), 0, stream, a);
-  else hipLaunchKernelGGL(k_block_icp<kIcpWaves>, dim3(nbp), dim3(kDBlock), 0, stream, a);  // few blocks: latency counts
+  hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, stream, a.work, nbp, a.order, a.counts);
+  // Few blocks: every one gets a workgroup (the longest block's latency is what counts).  Many blocks: the heavy ones
+  // (first in the order) get a workgroup each, the rest a wave each; both launches cover the worst case and the
+  // surplus workgroups leave at once.  PCC_ICP_WAVES = 1 / 4 forces one shape for all blocks (tests).
+  const char* force = getenv("PCC_ICP_WAVES");
+  DeltaArgs b = a;
+  b.shape = force ? (force[0] == '4' ? 1 : 2) : (nbp <= 2048 ? 1 : 0);
+  // the two shapes work on disjoint blocks: side by side on two streams when the caller has a second one
+  const bool fork = b.shape == 0 && aux && ev_fork && ev_join;
+  if (fork) {
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(aux, ev_fork, 0);
+  }
+  if (b.shape != 2) hipLaunchKernelGGL(k_block_icp<kIcpWaves>, dim3(nbp), dim3(kDBlock), 0, stream, b);
+  if (b.shape != 1) hipLaunchKernelGGL(k_block_icp<1>, dim3((nbp + kIcpWaves - 1) / kIcpWaves), dim3(kDBlock), 0, fork ? aux : stream, b);
+  if (fork) {
+    (void)hipEventRecord(ev_join, aux);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
+  }
 }
 
 void launch_delta_gather(const GatherArgs& a, hipStream_t stream) {
