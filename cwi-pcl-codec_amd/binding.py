@@ -67,6 +67,7 @@ class HotResult(C.Structure):
         ("occupancy", C.c_void_p), ("bgr", C.c_void_p), ("centroid", C.c_void_p), ("image", C.c_void_p),
         ("image_w", C.c_uint32), ("image_h", C.c_uint32), ("gpu_ms", C.c_float), ("jpeg_coefs", C.c_void_p),
         ("jpeg_tiles", C.c_void_p), ("jpeg_tile_words", C.c_uint32), ("jpeg_n_tiles", C.c_uint32),
+        ("occupancy_histogram", C.c_void_p),
     ]
 
 
@@ -228,6 +229,7 @@ class HotProducts:
             self.bgr = np.frombuffer(_bytes_at(hr.bgr, 3 * L), dtype=np.uint8)
             self.centroid_bytes = np.frombuffer(_bytes_at(hr.centroid, 3 * L), dtype=np.uint8)
             self.snake_image = np.frombuffer(_bytes_at(hr.image, 3 * self.image_w * self.image_h), dtype=np.uint8)
+            self.occupancy_histogram = np.frombuffer(_bytes_at(hr.occupancy_histogram, 1024 if hr.occupancy_histogram else 0), dtype=np.uint32)
 
 
 class Context:

@@ -531,6 +531,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->jpeg_tiles = tiles_ok ? ctx->h_jpeg_tiles.p : nullptr;
   out->jpeg_tile_words = kJpegTileWords;
   out->jpeg_n_tiles = (uint32_t)n_tiles;
+  out->occupancy_histogram = ctx->h_state.p->occ_hist;  // counted by k_occ_histogram, came back with the FrameState
   out->image_w = image ? W : 0;
   out->image_h = image ? H : 0;
   ctx->last_L = L;

@@ -85,6 +85,8 @@ struct FrameState {
   uint32_t n_leaves;                 // L
   uint32_t n_branches;               // B
   int32_t error;                     // FrameError
+  // ---- for the host entropy stage ----
+  uint32_t occ_hist[256];            // how often each occupancy byte value occurs (k_occ_histogram): the range coder's table
 };
 
 }  // namespace pcc

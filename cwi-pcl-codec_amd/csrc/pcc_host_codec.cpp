@@ -30,15 +30,20 @@ constexpr uint32_t kTop = 1u << 24;
 constexpr uint32_t kBottom = 1u << 16;
 constexpr uint32_t kMaxRange = 1u << 16;
 
-inline void cumulative_table(const uint8_t* in, size_t n, uint32_t freq[257]) {
+// `counts`: the histogram of `in` if somebody has it already (the GPU counts the occupancy bytes), else null
+inline void cumulative_table(const uint8_t* in, size_t n, uint32_t freq[257], const uint32_t* counts = nullptr) {
   // four interleaved histograms: avoids store-to-load stalls on runs of equal bytes
   uint32_t h[4][256];
   memset(h, 0, sizeof(h));
-  size_t i = 0;
-  for (; i + 4 <= n; i += 4) {
-    ++h[0][in[i]]; ++h[1][in[i + 1]]; ++h[2][in[i + 2]]; ++h[3][in[i + 3]];
+  if (counts) {
+    memcpy(h[0], counts, 256 * sizeof(uint32_t));
+  } else {
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+      ++h[0][in[i]]; ++h[1][in[i + 1]]; ++h[2][in[i + 2]]; ++h[3][in[i + 3]];
+    }
+    for (; i < n; ++i) ++h[0][in[i]];
   }
-  for (; i < n; ++i) ++h[0][in[i]];
   freq[0] = 0;
   for (int s = 0; s < 256; ++s) {
     const uint64_t c = (uint64_t)h[0][s] + h[1][s] + h[2][s] + h[3][s];
@@ -79,9 +84,9 @@ struct RcStream {
   size_t n = 0;
 
   uint8_t* payload() { return out->data() + start + sizeof(freq); }
-  void begin(const uint8_t* src, size_t count, Bytes& dst) {
+  void begin(const uint8_t* src, size_t count, Bytes& dst, const uint32_t* counts = nullptr) {
     in = src; n = count; out = &dst;
-    cumulative_table(src, count, freq);
+    cumulative_table(src, count, freq, counts);
     for (int s = 0; s < 256; ++s) fw[s] = (uint64_t)freq[s] | ((uint64_t)(freq[s + 1] - freq[s]) << 32);
     magic = InvariantDiv32(freq[256]).magic;  // 256 <= total < 2^16
     start = dst.size();
@@ -193,12 +198,13 @@ void rc_run4(RcStream* a, RcStream* b2, RcStream* c, RcStream* d, size_t i0, siz
 }
 }  // namespace
 
-void StaticRangeCoder::encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[]) {
+void StaticRangeCoder::encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[],
+                                   const uint32_t* const counts[]) {
   RcStream st[kMaxStreams];
   RcStream* order[kMaxStreams];
   if (count > kMaxStreams) count = kMaxStreams;
   for (int i = 0; i < count; ++i) {
-    st[i].begin(in[i], n[i], *out[i]);
+    st[i].begin(in[i], n[i], *out[i], counts ? counts[i] : nullptr);
     order[i] = &st[i];
   }
   // longest first: all streams run together up to the length of the shortest, then one fewer, ...
@@ -1079,17 +1085,20 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
   const uint8_t* src[kMax];
   size_t len[kMax];
   uint64_t got[kMax];
+  const uint32_t* cnt[kMax];  // symbol counts of the stage's input where known, else null
+  for (int i = 0; i < kMax; ++i) cnt[i] = nullptr;
   // a range-coder stage over the frames that take part in it
   auto stage = [&]() {
     const uint8_t* s2[kMax];
     size_t l2[kMax], g2[kMax];
     Bytes* o2[kMax];
+    const uint32_t* c2[kMax];
     int idx[kMax], m = 0;
     for (int i = 0; i < n; ++i) {
       got[i] = 0;
-      if (use[i]) { s2[m] = src[i]; l2[m] = len[i]; o2[m] = out[i]; idx[m] = i; ++m; }
+      if (use[i]) { s2[m] = src[i]; l2[m] = len[i]; o2[m] = out[i]; c2[m] = cnt[i]; idx[m] = i; ++m; }
     }
-    if (m) StaticRangeCoder::encode_many(m, s2, l2, o2, g2);
+    if (m) StaticRangeCoder::encode_many(m, s2, l2, o2, g2, c2);
     for (int k = 0; k < m; ++k) got[idx[k]] = g2[k];
   };
 
@@ -1098,10 +1107,12 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
     write_frame_header(*hot[i], *prm[i], *out[i]);
     put_le<uint64_t>(*out[i], hot[i]->n_branches);
     use[i] = true; src[i] = hot[i]->occupancy; len[i] = (size_t)hot[i]->n_branches;
+    cnt[i] = hot[i]->occupancy_histogram;
   }
   Clock::time_point t0 = Clock::now();
   stage();
   t_occ = us_since(t0);
+  for (int i = 0; i < n; ++i) cnt[i] = nullptr;
   for (int i = 0; i < n; ++i) perf[i][0] = got[i];
 
   // --- centroid bytes (impl.hpp:1700-1710) ---

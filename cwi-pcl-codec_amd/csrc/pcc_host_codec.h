@@ -6,13 +6,25 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
 #include <vector>
 
 #include "../../include/pcc_codec.h"
 
 namespace pcc {
 
-typedef std::vector<uint8_t> Bytes;
+// Byte buffers are resized to a worst case and then written: value-initialising the new bytes (what std::allocator
+// does) would zero megabytes per frame for nothing.  resize() leaves new bytes indeterminate; every user writes
+// before it reads.
+template <typename T>
+struct NoInitAllocator : std::allocator<T> {
+  template <typename U> struct rebind { typedef NoInitAllocator<U> other; };
+  NoInitAllocator() = default;
+  template <typename U> NoInitAllocator(const NoInitAllocator<U>&) {}
+  template <typename U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }  // default-init: no store
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(static_cast<A&&>(a)...); }
+};
+typedef std::vector<uint8_t, NoInitAllocator<uint8_t>> Bytes;
 
 // pcl::StaticRangeCoder (call sites impl.hpp:1694,1706,1719 / 1778,1789,1798)
 class StaticRangeCoder {
@@ -22,7 +34,9 @@ class StaticRangeCoder {
   // up to kMaxStreams independent streams coded in one loop (same bytes as separate encode() calls; see the
   // .cpp); the output vectors must be distinct; got[i] = bytes appended to *out[i]
   static constexpr int kMaxStreams = 4;
-  static void encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[]);
+  // counts[i]: the 256-bin histogram of in[i] if it is known already, else null (counts itself may be null)
+  static void encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[],
+                          const uint32_t* const counts[] = nullptr);
   // two streams
   static void encode2(const uint8_t* in_a, size_t n_a, Bytes& out_a, size_t& len_a,
                       const uint8_t* in_b, size_t n_b, Bytes& out_b, size_t& len_b);

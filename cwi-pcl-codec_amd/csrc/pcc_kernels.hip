@@ -259,6 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
     }
   }
   if (threadIdx.x == 0) s_nfin = 0;
+  st->occ_hist[threadIdx.x] = 0u;  // kBlock = 256 threads: one counter each (filled by k_occ_histogram at the end of the frame)
   const int i0 = block_min_int(first, &s_red);
   nfin = (unsigned)wave_sum_u64(nfin);
   for (int a = 0; a < 3; ++a) { g[a] = wave_min_f(g[a]); g[3 + a] = wave_max_f(g[3 + a]); }
@@ -1548,6 +1549,34 @@ size_t sync_area_bytes(uint32_t n, int passes) {
   return b;
 }
 
+// ---- k_occ_histogram: the range coder's symbol counts of the occupancy stream ----
+// The static range coder starts with a histogram of its input (one more serial pass over ~1 MB on the host, an
+// eighth of the host stage); the bytes are final here, so the counts ride back inside the FrameState for free.
+__global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ st, const uint8_t* __restrict__ occ) {
+  __shared__ uint32_t s_h[4][256];  // four copies: runs of equal bytes do not pile up on one LDS word
+  if (st->error != kErrNone || st->n_epochs == 0) return;
+  for (int k = threadIdx.x; k < 4 * 256; k += 256) (&s_h[0][0])[k] = 0u;
+  __syncthreads();
+  const uint32_t B = st->n_branches;
+  const uint32_t vec = B / 16u;
+  const uint4* v = reinterpret_cast<const uint4*>(occ);
+  const int copy = threadIdx.x & 3;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < vec; i += gridDim.x * 256u) {
+    const uint4 q = v[i];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&s_h[copy][w[k] & 0xffu], 1u); atomicAdd(&s_h[copy][(w[k] >> 8) & 0xffu], 1u);
+      atomicAdd(&s_h[copy][(w[k] >> 16) & 0xffu], 1u); atomicAdd(&s_h[copy][w[k] >> 24], 1u);
+    }
+  }
+  if (blockIdx.x == 0)  // the tail
+    for (uint32_t i = vec * 16u + threadIdx.x; i < B; i += 256u) atomicAdd(&s_h[0][occ[i]], 1u);
+  __syncthreads();
+  const uint32_t c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+  if (c) atomicAdd(&st->occ_hist[threadIdx.x], c);
+}
+
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) {
   const uint32_t n = a.n;
   const uint32_t n_tiles = (n + kTile - 1) / kTile;              // bounding-box chunks (2048 points)
@@ -1581,6 +1610,10 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
                      reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff);
   PCC_STAMP("k_leaf_tile");
+  if (!a.lp.simplify_only) {
+    hipLaunchKernelGGL(k_occ_histogram, dim3(64), dim3(256), 0, stream, a.state, a.occ);
+    PCC_STAMP("k_occ_histogram");
+  }
 }
 
 }  // namespace pcc

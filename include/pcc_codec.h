@@ -88,6 +88,9 @@ typedef struct pcc_hot_result {
    * the bit string, MSB first inside each u32.  NULL if the host Huffman-codes `jpeg_coefs` (or `image`). */
   const uint32_t *jpeg_tiles;
   uint32_t jpeg_tile_words, jpeg_n_tiles;
+  /* 256 counts: how often each byte value occurs in `occupancy` (counted on the GPU; saves the range coder its
+   * histogram pass).  NULL: the host counts. */
+  const uint32_t *occupancy_histogram;
 } pcc_hot_result;
 
 typedef struct pcc_bitstream {

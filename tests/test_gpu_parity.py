@@ -51,6 +51,7 @@ def assert_matches_oracle(pkg, oracle, ctx, pts, **kw):
     assert np.array_equal(hot.bbox, want.bbox)
     assert (hot.n_points_in, hot.n_leaves, hot.n_branches) == (want.n_points_in, want.n_leaves, want.n_branches)
     assert np.array_equal(hot.occupancy, want.occupancy)
+    assert np.array_equal(hot.occupancy_histogram, np.bincount(want.occupancy, minlength=256))   # the range coder's table input
     assert np.array_equal(hot.bgr, want.bgr)
     assert np.array_equal(hot.centroid_bytes, want.centroid_bytes)
     if kw.get("color_coding_type", 1) == 1 and kw.get("color_bits", 8) > 0:
