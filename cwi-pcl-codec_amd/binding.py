@@ -27,14 +27,14 @@ ERR_NAMES = {-1: "PCC_ERR_ARG", -2: "PCC_ERR_HIP", -3: "PCC_ERR_EMPTY", -4: "PCC
 # every symbol include/pcc_codec.h declares
 EXPORTS = [
     "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
-    "pcc_encode_intra", "pcc_encode_intra_device", "pcc_hotpath_launch", "pcc_hotpath_finish",
+    "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra",
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
     "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_contexts",
     "pcc_pipeline_context",
-    "pcc_pipeline_encode", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
+    "pcc_pipeline_encode", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
     "pcc_quality_metrics", "pcc_remove_outliers",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
@@ -157,6 +157,8 @@ def load_library():
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
     lib.pcc_pipeline_encode.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
+    lib.pcc_pipeline_reserve.argtypes = [vp, sz, sz, sz]
+    lib.pcc_reserve.argtypes = [vp, sz, sz]
     lib.pcc_pipeline_gpu_stage_only.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params)]
     lib.pcc_pipeline_stats.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_pipeline_cpu_times.argtypes = [vp, C.POINTER(C.c_double)]
@@ -459,6 +461,12 @@ class Pipeline:
         if rc != PCC_OK:
             raise PccError(rc, self.lib.pcc_pipeline_last_error(self.h).decode())
         return [((_bytes_at(b.data, b.len) if copy else b.len), [int(x) for x in b.perf]) for b in out]
+
+    def reserve(self, n_frames, bytes_per_frame, max_points_per_frame=0):
+        """Set aside the memory for the bitstreams of the coming calls and prepare every context of the ring (optional)."""
+        rc = self.lib.pcc_pipeline_reserve(self.h, int(n_frames), int(bytes_per_frame), int(max_points_per_frame))
+        if rc != PCC_OK:
+            raise PccError(rc, "pipeline reserve")
 
     def gpu_stage_only(self, dev_frames, counts, params, stride=32, rgb_offset=16):
         k, fr, cn = self._arrays(dev_frames, counts)

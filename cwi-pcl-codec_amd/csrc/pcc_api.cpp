@@ -279,6 +279,9 @@ void pcc_destroy(pcc_ctx* c) {
     return;
   }
   (void)hipSetDevice(c->device);
+  if (getenv("PCC_WAIT_STATS") && c->usual_wait_ns[0] > 0)
+    fprintf(stderr, "[pcc_ctx %p] usual waits: kernels %.0f us, copies %.0f us, other %.0f us\n", (void*)c, c->usual_wait_ns[0] / 1e3,
+            c->usual_wait_ns[1] / 1e3, c->usual_wait_ns[2] / 1e3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
@@ -452,6 +455,31 @@ static int wait_frame_state(pcc_ctx* ctx) {
     snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
              st.error, st.depth, kMaxDepth, st.vbits);
     return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
+  }
+  return PCC_OK;
+}
+
+int pcc_reserve(pcc_ctx* ctx, size_t max_points, size_t bitstream_bytes) {
+  if (!ctx) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  if (max_points >= (1ull << 30)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 2^30 points");
+  PCC_HIP(hipSetDevice(ctx->device));
+  if (max_points) {
+    const int rc = reserve(ctx, max_points);
+    if (rc != PCC_OK) return rc;
+    // landing buffers of the usual products (occupancy bytes: about one per point for surfaces; more is fetched on demand)
+    PCC_HIP(ctx->h_occ.ensure(std::max(max_points + max_points / 4, 2 * bitstream_bytes) + 16));
+    PCC_HIP(ctx->h_jpeg_tiles.ensure(((max_points / 256 + 1 + 15) / 16) * (size_t)kJpegTileWords));
+  }
+  if (bitstream_bytes) {
+    const size_t want = 2 * bitstream_bytes + 4096;
+    if (ctx->bitstream.capacity() < want) {
+      ctx->bitstream.reserve(want);
+      const size_t had = ctx->bitstream.size();
+      ctx->bitstream.resize(want);
+      memset(ctx->bitstream.data() + had, 0, want - had);  // first touch now
+      ctx->bitstream.resize(had);
+    }
   }
   return PCC_OK;
 }

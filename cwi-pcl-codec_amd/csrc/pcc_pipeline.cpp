@@ -21,6 +21,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -74,7 +75,24 @@ struct pcc_pipeline {
   std::vector<pcc_ctx*> free_ctx;
   std::deque<Ready> ready;
   // results of the current / last job
-  std::vector<std::vector<uint8_t>> streams;
+  std::vector<std::vector<uint8_t>> streams;  // bitstreams that did not fit the arena (first call, much larger frames)
+  // One block of memory for the bitstreams of a call, kept from call to call: a megabyte per frame from the allocator
+  // means mmap, page faults and munmap for every frame, on 20 threads at once.
+  uint8_t* arena = nullptr;
+  size_t arena_cap = 0;
+  std::atomic<size_t> arena_used{0};
+  size_t seen_max_len = 0;  // longest bitstream so far: sizes the arena of the next call
+
+  bool arena_ensure(size_t bytes) {  // grows (and touches) the arena; false: out of memory, the vectors take over
+    if (bytes <= arena_cap) return true;
+    uint8_t* q = static_cast<uint8_t*>(malloc(bytes));
+    if (!q) return false;
+    memset(q, 0, bytes);  // first touch here, not inside the frame loop
+    free(arena);
+    arena = q;
+    arena_cap = bytes;
+    return true;
+  }
   std::vector<pcc_bitstream> results;
   std::vector<int> status;
   std::string err;
@@ -213,9 +231,17 @@ struct pcc_pipeline {
             double hh[4];
             if (pcc_get_host_times(r[i].ctx, hh) == PCC_OK)
               for (int q = 0; q < 4; ++q) hu[q] += hh[q];
-            streams[r[i].frame].assign(bs[i].data, bs[i].data + bs[i].len);  // the context's buffer is reused by its next frame
+            // the context's buffer is reused by its next frame: the bitstream moves to the call's arena
+            const size_t room = (bs[i].len + 63) & ~(size_t)63;
+            const size_t off = arena_used.fetch_add(room);
             results[r[i].frame] = bs[i];
-            results[r[i].frame].data = streams[r[i].frame].data();
+            if (off + room <= arena_cap) {
+              memcpy(arena + off, bs[i].data, bs[i].len);
+              results[r[i].frame].data = arena + off;
+            } else {
+              streams[r[i].frame].assign(bs[i].data, bs[i].data + bs[i].len);
+              results[r[i].frame].data = streams[r[i].frame].data();
+            }
           }
           note_error(r[i].ctx, rc[i]);
           ++done;
@@ -320,7 +346,20 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   p->cv_work.notify_all();
   for (std::thread& t : p->threads) t.join();
   for (pcc_ctx* c : p->ctxs) pcc_destroy(c);
+  free(p->arena);
   delete p;
+}
+
+int pcc_pipeline_reserve(pcc_pipeline* p, size_t n_frames, size_t bytes_per_frame, size_t max_points_per_frame) {
+  if (!p) return PCC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (max_points_per_frame)
+    for (pcc_ctx* c : p->ctxs) {
+      const int rc = pcc_reserve(c, max_points_per_frame, bytes_per_frame);
+      if (rc != PCC_OK) { p->err = pcc_last_error(c); return rc; }
+    }
+  p->seen_max_len = std::max(p->seen_max_len, bytes_per_frame);
+  return p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63)) ? PCC_OK : PCC_ERR_HIP;
 }
 
 int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }
@@ -339,6 +378,8 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->job.frames = dev_frames; p->job.counts = n_points; p->job.n_frames = n_frames;
     p->job.stride = stride; p->job.rgb_offset = rgb_offset; p->job.params = *params; p->job.mode = mode;
     p->streams.assign(n_frames, std::vector<uint8_t>());
+    if (mode == 0 && p->seen_max_len) p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63));
+    p->arena_used = 0;
     p->results.assign(n_frames, pcc_bitstream());
     p->status.assign(n_frames, PCC_OK);
     p->err.clear();
@@ -364,9 +405,10 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
   if (mode == 0) {
     uint32_t id = params->frame_id;
     for (size_t f = 0; f < n_frames; ++f) {
-      if (p->status[f] != PCC_OK || p->streams[f].size() < 52) continue;
-      memcpy(p->streams[f].data() + 48, &id, sizeof(id));
+      if (p->status[f] != PCC_OK || p->results[f].len < 52) continue;
+      memcpy(const_cast<uint8_t*>(p->results[f].data) + 48, &id, sizeof(id));
       ++id;
+      p->seen_max_len = std::max(p->seen_max_len, p->results[f].len);
     }
   }
   for (size_t f = 0; f < n_frames; ++f)
@@ -390,7 +432,8 @@ int pcc_pipeline_gpu_stage_only(pcc_pipeline* p, const void* const* dev_frames, 
 int pcc_pipeline_stats(pcc_pipeline* p, double out_us[8]) {
   if (!p || !out_us) return PCC_ERR_ARG;
   const double k = p->frames_done ? 1.0 / (double)p->frames_done : 0.0;
-  out_us[0] = p->t_launch * k; out_us[1] = p->t_finish * k; out_us[2] = p->t_entropy * k;
+  const double kg = p->gpu_done ? 1.0 / (double)p->gpu_done : 0.0;  // frames that went through the GPU stage
+  out_us[0] = p->t_launch * kg; out_us[1] = p->t_finish * kg; out_us[2] = p->t_entropy * k;
   for (int i = 0; i < 4; ++i) out_us[3 + i] = p->host_us[i] * k;
   out_us[7] = (double)p->frames_done;
   return PCC_OK;
@@ -399,7 +442,8 @@ int pcc_pipeline_stats(pcc_pipeline* p, double out_us[8]) {
 int pcc_pipeline_cpu_times(pcc_pipeline* p, double out_us[4]) {
   if (!p || !out_us) return PCC_ERR_ARG;
   const double k = p->frames_done ? 1.0 / (double)p->frames_done : 0.0;
-  out_us[0] = p->cpu_launch * k; out_us[1] = p->cpu_finish * k; out_us[2] = p->cpu_entropy * k;
+  const double kg = p->gpu_done ? 1.0 / (double)p->gpu_done : 0.0;
+  out_us[0] = p->cpu_launch * kg; out_us[1] = p->cpu_finish * kg; out_us[2] = p->cpu_entropy * k;
   out_us[3] = (double)p->frames_done;
   return PCC_OK;
 }

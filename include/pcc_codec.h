@@ -134,6 +134,11 @@ int pcc_encode_intra(pcc_ctx *ctx, const void *host_points, size_t n, size_t str
 int pcc_encode_intra_device(pcc_ctx *ctx, const void *dev_points, size_t n, size_t stride, size_t rgb_offset,
                             const pcc_params *params, pcc_bitstream *out);
 
+/* Optional: allocate the context's HBM arena, pinned landing buffers and bitstream buffer for frames of up to
+ * `max_points` points / `bitstream_bytes` bytes now instead of on first use (the first frame on a fresh context pays
+ * some twenty hipMalloc / hipHostMalloc calls otherwise). */
+int pcc_reserve(pcc_ctx *ctx, size_t max_points, size_t bitstream_bytes);
+
 /* ---- the three stages of encodePointCloud, separately (for overlap across frames) ---- */
 /* addPointsFromInputCloud + serializeTree + leaf callbacks (impl.hpp:99,166,1509-1578) on the GPU; asynchronous. */
 int pcc_hotpath_launch(pcc_ctx *ctx, const void *dev_points, size_t n, size_t stride, size_t rgb_offset,
@@ -196,6 +201,11 @@ int pcc_pipeline_contexts(pcc_pipeline *p);
 pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option / pcc_set_profiling / kernel times */
 int pcc_pipeline_encode(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
                         size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
+/* Optional: set aside (and touch) the memory for the bitstreams of `n_frames` frames of up to `bytes_per_frame` bytes
+ * before the frames arrive; otherwise the first call allocates per frame and later calls reuse what the largest call
+ * needed.  With max_points_per_frame > 0 every context of the ring is prepared as well (pcc_reserve): a context used
+ * for the first time in the middle of a sequence otherwise stalls its thread for several milliseconds. */
+int pcc_pipeline_reserve(pcc_pipeline *p, size_t n_frames, size_t bytes_per_frame, size_t max_points_per_frame);
 /* the GPU stage alone (kernels + device->host hand-over), for capacity measurements */
 int pcc_pipeline_gpu_stage_only(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
                                 size_t stride, size_t rgb_offset, const pcc_params *params);
