@@ -139,8 +139,9 @@ def main():
 
     # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
     # without taxing every stream (the free list is a stack: its top context takes part in every round)
-    prof_ctx = pipe.context(pipe.n_contexts - 1)
-    prof_ctx.set_profiling(True)
+    prof_ctxs = [pipe.context(pipe.n_contexts - 1 - k) for k in range(min(4, pipe.n_contexts))]
+    for c in prof_ctxs:
+        c.set_profiling(True)
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
     trace("warm-up done")
     sync_all()
@@ -152,7 +153,8 @@ def main():
     trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
     ktimes, profiled = pipe.kernel_times()
-    prof_ctx.set_profiling(False)
+    for c in prof_ctxs:
+        c.set_profiling(False)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
