@@ -392,9 +392,11 @@ def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
     pipe = b.Pipeline(0, workers=3)
     ctx = pipe.context(0)
     devs = [ctx.upload(f) for f in frames]
-    for rep in range(2):   # the second call reuses every context
+    for rep in range(3):   # the second call reuses every context and the bitstream arena sized by the first
         got = pipe.encode(devs, sizes, b.make_params(frame_id=3, **kw))
         assert [g[0] for g in got] == want
+        if rep == 1:       # contexts and output memory prepared up front (too small on purpose: the rest overflows
+            pipe.reserve(4, 9000, 50_000)   # into per-frame buffers)
     pipe.gpu_stage_only(devs, sizes, b.make_params(frame_id=3, **kw))
     st = pipe.stats()
     assert st["frames"] == 0   # nothing went through the entropy stage in the last call
