@@ -399,10 +399,6 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
   a.max_passes = std::min(std::max(ctx->pass_hint, 1), (int)kMaxPasses);
   {
-    const char* ab = getenv("PCC_ABLATE");  // profiling hook: switch parts of k_leaf_finalize off (results are then wrong)
-    a.lp.ablate = ab ? (uint32_t)atoi(ab) : 0u;
-  }
-  {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
   }

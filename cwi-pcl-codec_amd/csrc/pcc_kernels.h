@@ -30,7 +30,6 @@ struct LeafParams {
   uint32_t color_reduction;  // colorBitReduction_ (only the PCL colour coder, type 0, ever has one)
   uint32_t do_centroid;      // do_voxel_centroid_enDecoding_
   uint32_t write_image;      // colour coding type 1: emit the snake-mapped 256 x H image
-  uint32_t ablate;           // unused
   uint32_t simplify_only;    // simplifyPCloud (impl.hpp:318-403): only the simplified cloud, centre = (key + 0.5) * res + min
 };
 
