@@ -83,10 +83,13 @@ struct pcc_ctx {
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
   DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
-  DevBuf<uint8_t> d_leaf_t, d_occ, d_bgr, d_centroid, d_image, d_sync;
+  DevBuf<uint8_t> d_leaf_t, d_bgr, d_centroid, d_image, d_sync;
+  // the per-MCU-row Huffman records and, right behind them, the occupancy stream: what the host stage needs of a
+  // colour frame is one contiguous piece of HBM and comes back in ONE copy (a copy costs some 40 us to set up)
+  DevBuf<uint8_t> d_occ;
+  size_t out_off = 0;  // bytes of the records region of the frame in flight = offset of its occupancy bytes
   DevBuf<float> d_simplified;  // 4 floats per leaf
   DevBuf<int16_t> d_coefs;     // JPEG coefficients of the snake image
-  DevBuf<uint32_t> d_jpeg_tiles;  // per-MCU-row Huffman records
   DevBuf<JpegHuffTables> d_huff;
   bool huff_uploaded = false;
 
@@ -118,7 +121,6 @@ struct pcc_ctx {
   PinnedBuf<uint8_t> h_occ, h_bgr, h_centroid, h_image;
   PinnedBuf<float> h_simplified;
   PinnedBuf<int16_t> h_coefs;
-  PinnedBuf<uint32_t> h_jpeg_tiles;
   int jpeg_on_gpu = 2;  // 0 host JPEG, 1 coefficients from the GPU, 2 Huffman-coded MCU rows from the GPU
   bool copy_image = true;
   std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
@@ -158,6 +160,9 @@ int hip_fail(pcc_ctx* c, hipError_t e, const char* what) {
     if (ctx->device < 0) return fail(ctx, PCC_ERR_STATE, "host-only context: the hot path needs a GPU"); \
   } while (0)
 
+// bytes of the Huffman records of a cloud of n points (one record per MCU row of the tallest possible snake image)
+size_t tiles_region(size_t n) { return ((n / 256 + 1 + 15) / 16) * (size_t)kJpegTileWords * sizeof(uint32_t); }
+
 int reserve(pcc_ctx* ctx, size_t n) {
   const size_t tiles = (n + kTile - 1) / kTile;
   const size_t stiles = (n + kSortTile - 1) / kSortTile;
@@ -175,13 +180,12 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_leaf_code.ensure(n));
   PCC_HIP(ctx->d_leaf_base.ensure(n));
   PCC_HIP(ctx->d_leaf_t.ensure(n));
-  PCC_HIP(ctx->d_occ.ensure(n * (size_t)kMaxDepth + 64));  // worst case B = L * D
+  PCC_HIP(ctx->d_occ.ensure(tiles_region(n) + n * (size_t)kMaxDepth + 64));  // records + worst case B = L * D
   PCC_HIP(ctx->d_bgr.ensure(3 * n + 16));
   PCC_HIP(ctx->d_centroid.ensure(3 * n + 16));
   PCC_HIP(ctx->d_image.ensure(3 * 256 * (n / 256 + 1) + 16));
   PCC_HIP(ctx->d_simplified.ensure(4 * n));
   PCC_HIP(ctx->d_coefs.ensure((size_t)16 * ((n / 256 + 1 + 15) / 16) * 6 * 64 + 64));
-  PCC_HIP(ctx->d_jpeg_tiles.ensure(((n / 256 + 1 + 15) / 16) * (size_t)kJpegTileWords));
   PCC_HIP(ctx->d_huff.ensure(1));
   if (!ctx->huff_uploaded) {
     JpegHuffTables t;
@@ -287,7 +291,7 @@ void pcc_destroy(pcc_ctx* c) {
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
-  c->d_jpeg_tiles.release(); c->d_huff.release(); c->h_jpeg_tiles.release();
+  c->d_huff.release();
   c->d_qa.release(); c->d_qb.release(); c->d_qkeys.release(); c->d_qheads.release(); c->d_qnext.release();
   c->d_qidx.release(); c->d_qd2.release(); c->d_qpart.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
@@ -407,7 +411,7 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
   a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.tile_prefix0 = ctx->d_tile_prefix0.p; a.sync_area = ctx->d_sync.p;
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
-  a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p; a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
+  a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p + tiles_region(n); a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
   a.simplified = ctx->d_simplified.p;
   a.coefs = nullptr;
   if (a.lp.write_image && ctx->jpeg_on_gpu) {
@@ -416,7 +420,8 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   }
   // the snake image itself only leaves the chip if somebody wants to look at it, or the host does the JPEG
   a.image = (a.lp.write_image && (ctx->copy_image || !a.coefs)) ? ctx->d_image.p : nullptr;
-  a.jpeg_tiles = (a.coefs && ctx->jpeg_on_gpu >= 2) ? ctx->d_jpeg_tiles.p : nullptr;
+  a.jpeg_tiles = (a.coefs && ctx->jpeg_on_gpu >= 2) ? reinterpret_cast<uint32_t*>(ctx->d_occ.p) : nullptr;
+  ctx->out_off = tiles_region(n);
   a.huff = ctx->d_huff.p;
   if (box) a.box = *box;
   a.lp.simplify_only = simplify_only ? 1u : 0u;
@@ -464,8 +469,7 @@ int pcc_reserve(pcc_ctx* ctx, size_t max_points, size_t bitstream_bytes) {
     const int rc = reserve(ctx, max_points);
     if (rc != PCC_OK) return rc;
     // landing buffers of the usual products (occupancy bytes: about one per point for surfaces; more is fetched on demand)
-    PCC_HIP(ctx->h_occ.ensure(std::max(max_points + max_points / 4, 2 * bitstream_bytes) + 16));
-    PCC_HIP(ctx->h_jpeg_tiles.ensure(((max_points / 256 + 1 + 15) / 16) * (size_t)kJpegTileWords));
+    PCC_HIP(ctx->h_occ.ensure(tiles_region(max_points) + std::max(max_points + max_points / 4, 2 * bitstream_bytes) + 16));
   }
   if (bitstream_bytes) {
     const size_t want = 2 * bitstream_bytes + 4096;
@@ -501,8 +505,12 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   const bool image = color && prm.color_coding_type == 1;
   const uint32_t W = 256, H = (uint32_t)(L / 256 + 1);
 
-  PCC_HIP(ctx->h_occ.ensure(B + 16));
-  PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, B, hipMemcpyDeviceToHost, ctx->stream));
+  const size_t off = ctx->out_off;
+  const bool tiles_too = image && ctx->jpeg_on_gpu >= 2;  // records + occupancy bytes in one copy
+  PCC_HIP(ctx->h_occ.ensure(off + B + 16));
+  if (tiles_too) PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, off + B, hipMemcpyDeviceToHost, ctx->stream));
+  else PCC_HIP(hipMemcpyAsync(ctx->h_occ.p + off, ctx->d_occ.p + off, B, hipMemcpyDeviceToHost, ctx->stream));
+  const uint32_t* h_tiles = reinterpret_cast<const uint32_t*>(ctx->h_occ.p);
   const bool want_bgr = color && (prm.color_coding_type != 1 || ctx->copy_image);
   if (want_bgr) {
     PCC_HIP(ctx->h_bgr.ensure(3 * L + 16));
@@ -517,10 +525,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     PCC_HIP(ctx->h_image.ensure((size_t)3 * W * H + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_image.p, ctx->d_image.p, (size_t)3 * W * H, hipMemcpyDeviceToHost, ctx->stream));
   }
-  if (tiles) {  // the Huffman-coded MCU rows; the coefficients only follow if a row did not fit its record
-    PCC_HIP(ctx->h_jpeg_tiles.ensure(n_tiles * kJpegTileWords));
-    PCC_HIP(hipMemcpyAsync(ctx->h_jpeg_tiles.p, ctx->d_jpeg_tiles.p, n_tiles * kJpegTileWords * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, ctx->stream));
+  if (tiles) {  // the Huffman-coded MCU rows came with the occupancy bytes; the coefficients only follow if a row did not fit its record
   } else if (coefs) {
     PCC_HIP(ctx->h_coefs.ensure(n_coefs + 64));
     PCC_HIP(hipMemcpyAsync(ctx->h_coefs.p, ctx->d_coefs.p, n_coefs * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -537,14 +542,14 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->n_points_in = st.n_finite;
   out->n_leaves = L;
   out->n_branches = B;
-  out->occupancy = ctx->h_occ.p;
+  out->occupancy = ctx->h_occ.p + off;
   out->bgr = want_bgr ? ctx->h_bgr.p : nullptr;
   out->centroid = prm.do_voxel_centroid ? ctx->h_centroid.p : nullptr;
   out->image = want_image ? ctx->h_image.p : nullptr;
   bool tiles_ok = tiles;
   if (tiles) {
     for (size_t m = 0; m < n_tiles; ++m)
-      if (ctx->h_jpeg_tiles.p[m * kJpegTileWords + 3] != 0) tiles_ok = false;
+      if (h_tiles[m * kJpegTileWords + 3] != 0) tiles_ok = false;
     if (!tiles_ok) {  // rare: a very busy image; fall back to the coefficients for this frame
       PCC_HIP(ctx->h_coefs.ensure(n_coefs + 64));
       PCC_HIP(hipMemcpyAsync(ctx->h_coefs.p, ctx->d_coefs.p, n_coefs * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -552,7 +557,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     }
   }
   out->jpeg_coefs = (coefs && !tiles_ok) ? ctx->h_coefs.p : nullptr;
-  out->jpeg_tiles = tiles_ok ? ctx->h_jpeg_tiles.p : nullptr;
+  out->jpeg_tiles = tiles_ok ? h_tiles : nullptr;
   out->jpeg_tile_words = kJpegTileWords;
   out->jpeg_n_tiles = (uint32_t)n_tiles;
   out->occupancy_histogram = ctx->h_state.p->occ_hist;  // counted by k_occ_histogram, came back with the FrameState
