@@ -394,8 +394,8 @@ inline void fdct_1d(const int32_t in[8], int32_t out[8], int shift_even_up, int 
   const int32_t t3 = in[3] + in[4], t4 = in[3] - in[4];
   const int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
   if (shift_even_up) {
-    out[0] = (t10 + t11) << shift_even_up;
-    out[4] = (t10 - t11) << shift_even_up;
+    out[0] = (t10 + t11) * (1 << shift_even_up);  // libjpeg shifts the (possibly negative) sum left: same value, defined behaviour
+    out[4] = (t10 - t11) * (1 << shift_even_up);
   } else {
     out[0] = descale(t10 + t11, down_even);
     out[4] = descale(t10 - t11, down_even);
@@ -787,10 +787,10 @@ struct BitSource {
     --n;
     return (acc >> n) & 1;
   }
-  inline int bits(int k) {
-    int v = 0;
-    while (k--) v = (v << 1) | bit();
-    return v;
+  inline int bits(int k) {  // k <= 16 for any valid stream
+    uint32_t v = 0;
+    while (k-- > 0) v = (v << 1) | (uint32_t)bit();
+    return (int)(v & 0x7fffffffu);
   }
   inline int sym(const HuffDec& t) {
     int32_t code = 0;
@@ -803,23 +803,28 @@ struct BitSource {
 };
 inline int extend_sign(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
 
-inline uint8_t idct_clamp(int32_t v) {  // sample_range_limit + CENTERJSAMPLE, index masked to 10 bits
+// The inverse DCT works in 64-bit integers: for a valid stream every value fits 32 bits and the results are libjpeg's;
+// for a corrupt one (coefficient x quantiser up to 2^31) nothing overflows, so garbage in is garbage out and not
+// undefined behaviour.
+typedef int64_t idct_t;
+inline idct_t descale64(idct_t x, int n) { return (x + ((idct_t)1 << (n - 1))) >> n; }
+inline uint8_t idct_clamp(idct_t v) {  // sample_range_limit + CENTERJSAMPLE, index masked to 10 bits
   const int i = (int)(v & 1023);
   if (i < 128) return (uint8_t)(128 + i);
   if (i < 512) return 255;
   if (i < 896) return 0;
   return (uint8_t)(i - 896);
 }
-inline void idct_1d(const int32_t in[8], int32_t o[8]) {  // jidctint.c butterfly, unscaled outputs
-  int32_t z2 = in[2], z3 = in[6];
-  int32_t z1 = (z2 + z3) * PCC_FIX_0_541196100;
-  const int32_t e2 = z1 + z3 * (-PCC_FIX_1_847759065), e3 = z1 + z2 * PCC_FIX_0_765366865;
-  const int32_t e0 = (in[0] + in[4]) * 8192, e1 = (in[0] - in[4]) * 8192;
-  const int32_t t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
-  int32_t t0 = in[7], t1 = in[5], t2 = in[3], t3 = in[1];
+inline void idct_1d(const idct_t in[8], idct_t o[8]) {  // jidctint.c butterfly, unscaled outputs
+  idct_t z2 = in[2], z3 = in[6];
+  idct_t z1 = (z2 + z3) * PCC_FIX_0_541196100;
+  const idct_t e2 = z1 + z3 * (-PCC_FIX_1_847759065), e3 = z1 + z2 * PCC_FIX_0_765366865;
+  const idct_t e0 = (in[0] + in[4]) * 8192, e1 = (in[0] - in[4]) * 8192;
+  const idct_t t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
+  idct_t t0 = in[7], t1 = in[5], t2 = in[3], t3 = in[1];
   z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
-  int32_t z4 = t1 + t3;
-  const int32_t z5 = (z3 + z4) * PCC_FIX_1_175875602;
+  idct_t z4 = t1 + t3;
+  const idct_t z5 = (z3 + z4) * PCC_FIX_1_175875602;
   t0 *= PCC_FIX_0_298631336; t1 *= PCC_FIX_2_053119869; t2 *= PCC_FIX_3_072711026; t3 *= PCC_FIX_1_501321110;
   z1 *= -PCC_FIX_0_899976223; z2 *= -PCC_FIX_2_562915447;
   z3 = z3 * (-PCC_FIX_1_961570560) + z5;
@@ -829,15 +834,15 @@ inline void idct_1d(const int32_t in[8], int32_t o[8]) {  // jidctint.c butterfl
   o[2] = t12 + t1; o[5] = t12 - t1; o[3] = t13 + t0; o[4] = t13 - t0;
 }
 void idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t* dst, int stride) {
-  int32_t ws[64], in[8], o[8];
+  idct_t ws[64], in[8], o[8];
   for (int c = 0; c < 8; ++c) {
-    for (int r = 0; r < 8; ++r) in[r] = (int32_t)coef[8 * r + c] * q[8 * r + c];
+    for (int r = 0; r < 8; ++r) in[r] = (idct_t)coef[8 * r + c] * q[8 * r + c];
     idct_1d(in, o);
-    for (int r = 0; r < 8; ++r) ws[8 * r + c] = descale(o[r], 13 - 2);
+    for (int r = 0; r < 8; ++r) ws[8 * r + c] = descale64(o[r], 13 - 2);
   }
   for (int r = 0; r < 8; ++r) {
     idct_1d(ws + 8 * r, o);
-    for (int c = 0; c < 8; ++c) dst[(size_t)r * stride + c] = idct_clamp(descale(o[c], 13 + 2 + 3));
+    for (int c = 0; c < 8; ++c) dst[(size_t)r * stride + c] = idct_clamp(descale64(o[c], 13 + 2 + 3));
   }
 }
 }  // namespace
@@ -910,8 +915,9 @@ bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w
   int16_t blk[64];
   auto one_block = [&](int c, uint8_t* dst, int stride) {
     memset(blk, 0, sizeof(blk));
-    const int sz = br.sym(hd[0][tdc[c]]);
-    last_dc[c] += sz ? extend_sign(br.bits(sz), sz) : 0;
+    int sz = br.sym(hd[0][tdc[c]]);
+    if (sz > 16) sz = 0;  // corrupt table: libjpeg treats a bad code as zero as well
+    last_dc[c] = (int16_t)(last_dc[c] + (sz ? extend_sign(br.bits(sz), sz) : 0));  // stays in range on corrupt data too
     blk[0] = (int16_t)last_dc[c];
     for (int k = 1; k < 64; ++k) {
       const int rs = br.sym(hd[1][tac[c]]), r = rs >> 4, s4 = rs & 15;
@@ -1243,7 +1249,7 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
   Bytes cen;
   if (p.do_voxel_centroid) {
     uint32_t n = 0;
-    if (!r.get(n)) return PCC_ERR_STREAM;
+    if (!r.get(n) || n > len * 64 + 64) return PCC_ERR_STREAM;
     cen.resize(n);
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, cen.data(), cen.size());
     if (!used) return PCC_ERR_STREAM;
@@ -1286,6 +1292,7 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
   info.consumed = r.pos;
 
   // deserializeTree: pre-order walk with an explicit stack (Appendix B), leaves in Morton order
+  if (count > 8 * occ_n) return PCC_ERR_STREAM;  // a tree of occ_n branch nodes has at most eight leaves per node: corrupt header
   points.resize((size_t)count);
   const unsigned D = info.depth;
   const unsigned shift = (cct == 0) ? (unsigned)(8 - p.color_bit_resolution) & 7u : 0u;
