@@ -1165,12 +1165,18 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     }
   }
   for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
-  // the points of this tile's leaves are one contiguous run of the sorted arrays: stage their colour words
+  // the points of this tile's leaves are one contiguous run of the sorted arrays: stage their colour words.  The loads
+  // are issued here and land in LDS after the parent search below, whose dependent loads they overlap with.
   const uint32_t run0 = nl ? leaf_start[pos0] : 0u;
   const uint32_t run1 = nl ? leaf_start[pos0 + nl] : 0u;
   const bool staged = colour_pay != nullptr && lp.do_color;
-  if (staged)
-    for (uint32_t k = threadIdx.x; k < min(run1 - run0, (uint32_t)kColourStage); k += kFinThreads) s_col[k] = colour_pay[run0 + k];
+  const uint32_t ncol = staged ? min(run1 - run0, (uint32_t)kColourStage) : 0u;
+  uint32_t colreg[kColourStage / kFinThreads];
+#pragma unroll
+  for (int q = 0; q < kColourStage / kFinThreads; ++q) {
+    const uint32_t k = threadIdx.x + (uint32_t)q * kFinThreads;
+    colreg[q] = k < ncol ? colour_pay[run0 + k] : 0u;
+  }
   // Parents that were opened before this tile: for every v the nearest earlier leaf f with t(f) >= v is
   // the first leaf of the level-(D-v) ancestor of the tile's first leaf, i.e. lower_bound over the sorted
   // leaf codes.  One wave per level, 64 probes per step (4 steps for a million leaves).
@@ -1195,6 +1201,11 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       }
       if (lane == 0) s_far[v] = leaf_base[lo] + (uint32_t)leaf_t[lo] - (uint32_t)v;
     }
+  }
+#pragma unroll
+  for (int q = 0; q < kColourStage / kFinThreads; ++q) {
+    const uint32_t k = threadIdx.x + (uint32_t)q * kFinThreads;
+    if (k < ncol) s_col[k] = colreg[q];
   }
   if (threadIdx.x == 0 && lp.write_image && nl < npos) {  // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
     uint32_t b, g, r;
