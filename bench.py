@@ -227,6 +227,13 @@ def main():
                       "JPEG + range coder, 1 thread), %.1f s" % (frames, args.workload, n_points, cpu_s),
             "host_cpus": os.cpu_count(),
         }
+        try:  # the reference's own CMake hard-wires -g -O0 (CMakeLists.txt:85-87): the same port at -O0, for orientation
+            t0 = time.perf_counter()
+            O.encode_intra(host_frames[0], po, opt0=True, keep=False)
+            O.encode_intra(host_frames[0], po, opt0=True, keep=False)
+            cpu_baseline["value_at_O0"] = round(n_points * 2 / (time.perf_counter() - t0) / 1e6, 4)
+        except Exception:
+            pass
 
     if rank == 0:
         out = {
