@@ -61,7 +61,8 @@ struct Ready {  // a context whose GPU stage is done
 struct pcc_pipeline {
   int device = 0;
   int n_entropy = 0, n_gpu = 0;
-  int batch = PCC_MAX_FRAMES_AT_ONCE;  // frames an entropy thread codes in one loop
+  int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
+  int batch_now = PCC_MAX_FRAMES_AT_ONCE;  // ... for the job at hand: short jobs spread their frames over the threads instead
   std::vector<pcc_ctx*> ctxs;
   std::vector<std::thread> threads;
   std::mutex mu;  // guards everything below up to `stat_mu`
@@ -179,7 +180,7 @@ struct pcc_pipeline {
             free_ctx.push_back(r.ctx);
             cv_free.notify_one();
           }
-          wake_one = ready.size() >= (size_t)batch;  // a full batch is waiting: one entropy thread is enough
+          wake_one = ready.size() >= (size_t)batch_now;  // a full batch is waiting: one entropy thread is enough
           wake_all = gpu_done >= job.n_frames;
         }
         if (wake_all) cv_ready.notify_all();
@@ -208,8 +209,8 @@ struct pcc_pipeline {
           std::unique_lock<std::mutex> lk(mu);
           // Four frames in one coder loop cost 1.5 ms of CPU per frame, one frame alone 3.3 ms (tools/rc_speed.py), and
           // the CPU is what limits the pipeline: wait for a full batch unless the GPU stage has nothing more to give.
-          cv_ready.wait(lk, [&] { return ready.size() >= (size_t)batch || gpu_done >= job.n_frames; });
-          while (nr < kAtOnce && nr < batch && !ready.empty()) { r[nr++] = ready.front(); ready.pop_front(); }
+          cv_ready.wait(lk, [&] { return ready.size() >= (size_t)batch_now || gpu_done >= job.n_frames; });
+          while (nr < kAtOnce && nr < batch_now && !ready.empty()) { r[nr++] = ready.front(); ready.pop_front(); }
           if (nr == 0) break;  // every frame went through the GPU stage and the queue is empty
         }
         pcc_bitstream bs[kAtOnce];
@@ -380,6 +381,9 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->streams.assign(n_frames, std::vector<uint8_t>());
     if (mode == 0 && p->seen_max_len) p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63));
     p->arena_used = 0;
+    // Four frames in one coder loop use the least CPU per frame but take four times as long to come out: worth it when
+    // the frames outnumber the threads (throughput), wrong for a short call (latency) -- there every thread takes one.
+    p->batch_now = (int)std::min<size_t>((size_t)p->batch, std::max<size_t>(1, n_frames / (2 * (size_t)p->n_entropy)));
     p->results.assign(n_frames, pcc_bitstream());
     p->status.assign(n_frames, PCC_OK);
     p->err.clear();
