@@ -222,3 +222,22 @@ def test_delta_other_macroblock_sizes_and_big_blocks(pkg, ctx, pair, mb, on_orig
         assert (conv and fitness < 2 * RES) == bool(b["converged"])
         diff = np.abs(D.transform_points(src, final) - D.transform_points(src, b["rt"].reshape(4, 4))).max()
         assert diff < 0.5 * RES
+
+
+def test_delta_many_blocks_uses_both_icp_shapes(pkg, ctx):
+    """More than 2048 macroblocks: the heavy blocks go to the workgroup-per-block ICP kernel, the light ones to the
+    wave-per-block kernel, on two streams.  Everything around the ICP stays bit-exact given its transforms."""
+    i_cloud, p_cloud = pkg.synthetic.delta_pair(260_000, 31, grid=512)
+    res = 1.0 / 512
+    prm = pkg.binding.make_params(octree_bits=9, color_bits=8, color_coding_type=1, jpeg_quality=85)
+    got = ctx.encode_delta(i_cloud, p_cloud, prm)
+    assert got["macro_block_count"] > 2048
+    work = got["blocks"]["n_i"].astype(np.int64) * got["blocks"]["n_p"] * (got["blocks"]["do_icp"] != 0)
+    assert (work >= 128 * 128).any() and ((work > 0) & (work < 128 * 128)).any()      # both kinds present
+    want = D.encode_delta(i_cloud, p_cloud, res, res, icp_fn=_replay(got))
+    assert got["p_stream"] == want["p_stream"] and got["i_stream"] == want["i_stream"]
+    assert got["out_cloud"].tobytes() == want["out_cloud"].tobytes()
+    icp = got["blocks"][got["blocks"]["do_icp"] != 0]
+    assert (icp["iterations"] > 0).all()          # every gated block was visited by one of the two kernels
+    dec = ctx.decode_delta(i_cloud, got["i_stream"], got["p_stream"], prm)
+    assert dec.tobytes() == D.decode_delta(i_cloud, got["i_stream"], got["p_stream"], res).tobytes()
