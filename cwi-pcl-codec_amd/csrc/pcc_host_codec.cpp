@@ -121,8 +121,8 @@ struct RcStream {
 // PCL writes it.
 #define PCC_RC_STEP(S)                                                                              \
   {                                                                                                 \
-    const uint64_t fw = fw##S[in##S[i]];                                                            \
-    range##S = (uint32_t)(((unsigned __int128)magic##S * range##S) >> 64); /* range /= total */     \
+    const uint64_t fw = sb[S].fw[in##S[i]];                                                         \
+    range##S = (uint32_t)(((unsigned __int128)sb[S].magic * range##S) >> 64); /* range /= total */  \
     low##S += (uint32_t)fw * range##S;                                                              \
     range##S *= (uint32_t)(fw >> 32);                                                               \
     const uint32_t x = low##S ^ (low##S + range##S);                                                \
@@ -147,8 +147,6 @@ struct RcStream {
   }
 #define PCC_RC_LOAD(S, st)                                                                          \
   const uint8_t* in##S = (st)->in;                                                                  \
-  const uint64_t* fw##S = (st)->fw;                                                                 \
-  const uint64_t magic##S = (st)->magic;                                                            \
   uint32_t low##S = (st)->low, range##S = (st)->range;                                              \
   uint8_t* p##S = (st)->payload() + (st)->pos;
 #define PCC_RC_STORE(S, st)                                                                         \
@@ -160,40 +158,42 @@ constexpr size_t kRcBlockBytes = 4 * kRcBlock + 16;   // a symbol emits at most 
 // symbols [i0, i1) of 1..4 streams in one loop: every symbol is a chain of dependent multiplies, shifts and a
 // count-leading-zeros (about a dozen cycles), so one coder leaves most of the core idle; several independent
 // coders in the same loop fill it.  The bytes of each stream do not depend on how many run together.
-void rc_run1(RcStream* a, size_t i0, size_t i1) {
+// `sb` = the streams of the loop, consecutive in memory: tables and reciprocals are addressed from the one base
+// pointer (constant offsets), which leaves the registers to the coder states.
+void rc_run1(RcStream* sb, size_t i0, size_t i1) {
   for (size_t b = i0; b < i1; b += kRcBlock) {
     const size_t e = std::min(b + kRcBlock, i1);
-    a->ensure(kRcBlockBytes);
-    PCC_RC_LOAD(0, a)
+    sb[0].ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, &sb[0])
     for (size_t i = b; i < e; ++i) PCC_RC_STEP(0)
-    PCC_RC_STORE(0, a)
+    PCC_RC_STORE(0, &sb[0])
   }
 }
-void rc_run2(RcStream* a, RcStream* b2, size_t i0, size_t i1) {
+void rc_run2(RcStream* sb, size_t i0, size_t i1) {
   for (size_t b = i0; b < i1; b += kRcBlock) {
     const size_t e = std::min(b + kRcBlock, i1);
-    a->ensure(kRcBlockBytes); b2->ensure(kRcBlockBytes);
-    PCC_RC_LOAD(0, a) PCC_RC_LOAD(1, b2)
+    sb[0].ensure(kRcBlockBytes); sb[1].ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, &sb[0]) PCC_RC_LOAD(1, &sb[1])
     for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) }
-    PCC_RC_STORE(0, a) PCC_RC_STORE(1, b2)
+    PCC_RC_STORE(0, &sb[0]) PCC_RC_STORE(1, &sb[1])
   }
 }
-void rc_run3(RcStream* a, RcStream* b2, RcStream* c, size_t i0, size_t i1) {
+void rc_run3(RcStream* sb, size_t i0, size_t i1) {
   for (size_t b = i0; b < i1; b += kRcBlock) {
     const size_t e = std::min(b + kRcBlock, i1);
-    a->ensure(kRcBlockBytes); b2->ensure(kRcBlockBytes); c->ensure(kRcBlockBytes);
-    PCC_RC_LOAD(0, a) PCC_RC_LOAD(1, b2) PCC_RC_LOAD(2, c)
+    sb[0].ensure(kRcBlockBytes); sb[1].ensure(kRcBlockBytes); sb[2].ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, &sb[0]) PCC_RC_LOAD(1, &sb[1]) PCC_RC_LOAD(2, &sb[2])
     for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) PCC_RC_STEP(2) }
-    PCC_RC_STORE(0, a) PCC_RC_STORE(1, b2) PCC_RC_STORE(2, c)
+    PCC_RC_STORE(0, &sb[0]) PCC_RC_STORE(1, &sb[1]) PCC_RC_STORE(2, &sb[2])
   }
 }
-void rc_run4(RcStream* a, RcStream* b2, RcStream* c, RcStream* d, size_t i0, size_t i1) {
+void rc_run4(RcStream* sb, size_t i0, size_t i1) {
   for (size_t b = i0; b < i1; b += kRcBlock) {
     const size_t e = std::min(b + kRcBlock, i1);
-    a->ensure(kRcBlockBytes); b2->ensure(kRcBlockBytes); c->ensure(kRcBlockBytes); d->ensure(kRcBlockBytes);
-    PCC_RC_LOAD(0, a) PCC_RC_LOAD(1, b2) PCC_RC_LOAD(2, c) PCC_RC_LOAD(3, d)
+    sb[0].ensure(kRcBlockBytes); sb[1].ensure(kRcBlockBytes); sb[2].ensure(kRcBlockBytes); sb[3].ensure(kRcBlockBytes);
+    PCC_RC_LOAD(0, &sb[0]) PCC_RC_LOAD(1, &sb[1]) PCC_RC_LOAD(2, &sb[2]) PCC_RC_LOAD(3, &sb[3])
     for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) PCC_RC_STEP(2) PCC_RC_STEP(3) }
-    PCC_RC_STORE(0, a) PCC_RC_STORE(1, b2) PCC_RC_STORE(2, c) PCC_RC_STORE(3, d)
+    PCC_RC_STORE(0, &sb[0]) PCC_RC_STORE(1, &sb[1]) PCC_RC_STORE(2, &sb[2]) PCC_RC_STORE(3, &sb[3])
   }
 }
 }  // namespace
@@ -201,28 +201,26 @@ void rc_run4(RcStream* a, RcStream* b2, RcStream* c, RcStream* d, size_t i0, siz
 void StaticRangeCoder::encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[],
                                    const uint32_t* const counts[]) {
   RcStream st[kMaxStreams];
-  RcStream* order[kMaxStreams];
   if (count > kMaxStreams) count = kMaxStreams;
-  for (int i = 0; i < count; ++i) {
-    st[i].begin(in[i], n[i], *out[i], counts ? counts[i] : nullptr);
-    order[i] = &st[i];
-  }
   // longest first: all streams run together up to the length of the shortest, then one fewer, ...
-  std::sort(order, order + count, [](const RcStream* x, const RcStream* y) { return x->n > y->n; });
+  int idx[kMaxStreams];
+  for (int i = 0; i < count; ++i) idx[i] = i;
+  std::stable_sort(idx, idx + count, [&](int x, int y) { return n[x] > n[y]; });
+  for (int k = 0; k < count; ++k) st[k].begin(in[idx[k]], n[idx[k]], *out[idx[k]], counts ? counts[idx[k]] : nullptr);
   size_t done = 0;
   for (int live = count; live > 0; --live) {
-    const size_t upto = order[live - 1]->n;  // the shortest stream still running ends here
+    const size_t upto = st[live - 1].n;  // the shortest stream still running ends here
     if (upto > done) {
-      if (live == 4) rc_run4(order[0], order[1], order[2], order[3], done, upto);
-      else if (live == 3) rc_run3(order[0], order[1], order[2], done, upto);
-      else if (live == 2) rc_run2(order[0], order[1], done, upto);
-      else rc_run1(order[0], done, upto);
+      if (live == 4) rc_run4(st, done, upto);
+      else if (live == 3) rc_run3(st, done, upto);
+      else if (live == 2) rc_run2(st, done, upto);
+      else rc_run1(st, done, upto);
       done = upto;
     }
   }
-  for (int i = 0; i < count; ++i) {
-    st[i].ensure(8);
-    got[i] = st[i].finish();
+  for (int k = 0; k < count; ++k) {
+    st[k].ensure(8);
+    got[idx[k]] = st[k].finish();
   }
 }
 
