@@ -241,3 +241,24 @@ def test_delta_many_blocks_uses_both_icp_shapes(pkg, ctx):
     assert (icp["iterations"] > 0).all()          # every gated block was visited by one of the two kernels
     dec = ctx.decode_delta(i_cloud, got["i_stream"], got["p_stream"], prm)
     assert dec.tobytes() == D.decode_delta(i_cloud, got["i_stream"], got["p_stream"], res).tobytes()
+
+
+def test_delta_clouds_outside_the_unit_cube(pkg, ctx, pair):
+    """Clouds that were not normalised: the defined box [0,1]^3 of the macroblock trees and of the simplification grows
+    around them (each tree on its own, as in the reference); still bit-exact given the transforms."""
+    i_cloud, p_cloud = pair
+    i2, p2 = i_cloud.copy(), p_cloud.copy()
+    for c in (i2, p2):
+        c["x"] = c["x"] * np.float32(2.5) - np.float32(0.7)
+        c["y"] = c["y"] * np.float32(2.5) + np.float32(0.4)
+        c["z"] = c["z"] * np.float32(2.5) - np.float32(1.2)
+    res = 2.5 / 256
+    prm = pkg.binding.make_params(octree_resolution=res, point_resolution=res, color_bits=8, color_coding_type=1, jpeg_quality=85)
+    got = ctx.encode_delta(i2, p2, prm)
+    want = D.encode_delta(i2, p2, res, res, icp_fn=_replay(got))
+    assert [tuple(b["key"][:3]) for b in got["blocks"]] == [b["key"] for b in want["blocks"]]
+    assert got["p_stream"] == want["p_stream"] and got["i_stream"] == want["i_stream"]
+    assert got["out_cloud"].tobytes() == want["out_cloud"].tobytes()
+    # (each tree grows its own box, so the keys of the two frames rarely meet: the reference app only predicts between
+    # frames whose bounding boxes were aligned, eval.hpp:854)
+    assert got["shared_macroblock_count"] == sum(1 for b in want["blocks"] if b["shared"])
