@@ -207,6 +207,22 @@ def main():
             "path_frac": round(path_bytes / (seq_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if seq_ms > 0 else 0.0,
         }
 
+    # the same kernel with nothing else on the GPU (one frame at a time on one stream, HIP events between the launches):
+    # what the kernel itself achieves, next to the figure above that it achieves while sharing the GPU with five other frames
+    if roofline is not None and rank == 0:
+        ctx0.set_profiling(True)
+        alone = []
+        for _ in range(12):
+            ctx0.hotpath_launch(dev_frames[0], n_points, params)
+            ctx0.hotpath_finish(copy=False)
+            alone += [ms for name, ms in ctx0.kernel_times() if name == roofline["kernel"]]
+        ctx0.set_profiling(False)
+        alone = alone[len(alone) // 3:]   # the first frames warm the context up
+        if alone:
+            a_ms = sum(alone) / len(alone)
+            roofline["alone"] = {"kernel_avg_ms": round(a_ms, 5), "achieved": round(roofline["kernel_bytes_per_launch"] / (a_ms * 1e-3) / 1e9, 2),
+                                 "frac": round(roofline["kernel_bytes_per_launch"] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+
     # ---- CPU baseline: the pointer-octree oracle, single thread, bounded sample ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
