@@ -281,6 +281,7 @@ def main():
         print(json.dumps(out))
     pipe.close()
     if dist is not None:
+        dist.barrier()   # rank 0 has a little more to do after the timed region: leave together
         dist.destroy_process_group()
 
 
