@@ -36,7 +36,7 @@ EXPORTS = [
     "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
-    "pcc_quality_metrics", "pcc_remove_outliers",
+    "pcc_quality_metrics", "pcc_remove_outliers", "pcc_device_range_encode",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
@@ -166,6 +166,7 @@ def load_library():
     lib.pcc_pipeline_last_error.restype = C.c_char_p
     lib.pcc_pipeline_last_error.argtypes = [vp]
     lib.pcc_quality_metrics.argtypes = [vp, vp, sz, vp, sz, C.c_double, C.POINTER(Quality)]
+    lib.pcc_device_range_encode.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_float)]
     lib.pcc_remove_outliers.argtypes = [vp, vp, sz, i32, C.c_double, vp, C.POINTER(sz)]
     lib.pcc_encode_delta.argtypes = [vp, vp, sz, vp, sz, C.POINTER(DeltaParams), C.POINTER(DeltaResult)]
     lib.pcc_delta_blocks.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -348,6 +349,18 @@ class Context:
         d = {k: getattr(q, k) for k, _ in Quality._fields_ if k != "psnr_yuv"}
         d["psnr_yuv"] = list(q.psnr_yuv)
         return d
+
+    def device_range_encode(self, streams):
+        """The static range coder on the GPU, one wave per stream: [bytes] -> ([bytes], kernel milliseconds)."""
+        k = len(streams)
+        ins = [np.frombuffer(s, dtype=np.uint8) for s in streams]
+        outs = [np.zeros(1028 + len(a) + len(a) // 2 + 64, dtype=np.uint8) for a in ins]
+        lens = (C.c_size_t * k)()
+        ms = C.c_float()
+        self._check(self.lib.pcc_device_range_encode(
+            self.h, k, (C.c_void_p * k)(*[a.ctypes.data if len(a) else None for a in ins]), (C.c_size_t * k)(*[len(a) for a in ins]),
+            (C.c_void_p * k)(*[o.ctypes.data for o in outs]), lens, C.byref(ms)))
+        return [o[:lens[i]].tobytes() for i, o in enumerate(outs)], float(ms.value)
 
     def remove_outliers(self, cloud: np.ndarray, min_points: int, radius: float):
         """remove_outliers for one cloud (codec.h:216-217): the kept points, in order."""

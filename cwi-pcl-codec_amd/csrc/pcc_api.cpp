@@ -18,6 +18,7 @@
 #include "pcc_kernels.h"
 #include "pcc_quality.h"
 #include "pcc_delta.h"
+#include "pcc_rc_device.h"
 
 using namespace pcc;
 
@@ -104,6 +105,7 @@ struct pcc_ctx {
   // inter-frame path: sub-contexts for the simplified cloud and the two macroblock trees, block scratch
   pcc_ctx* sub[4] = {nullptr, nullptr, nullptr, nullptr};  // simplification, I blocks, P blocks, residual intra coder
   DevBuf<uint8_t> d_delta_i, d_delta_p, d_delta_intra, d_delta_out;
+  DevBuf<uint8_t> d_rc;  // pcc_device_range_encode: inputs, outputs, lengths, jobs
   DevBuf<uint64_t> d_ifull, d_pfull;
   DevBuf<float4> d_ixyzc, d_pxyzc, d_cur;
   DevBuf<uint32_t> d_nn, d_dst_intra, d_dst_out, d_fake_start, d_work, d_order, d_counts;
@@ -299,7 +301,7 @@ void pcc_destroy(pcc_ctx* c) {
   for (pcc_ctx*& sc : c->sub) { if (sc) pcc_destroy(sc); sc = nullptr; }
   c->d_delta_i.release(); c->d_delta_p.release(); c->d_delta_intra.release(); c->d_delta_out.release(); c->d_ifull.release();
   c->d_pfull.release(); c->d_ixyzc.release(); c->d_pxyzc.release(); c->d_cur.release(); c->d_nn.release(); c->d_dst_intra.release();
-  c->d_dst_out.release(); c->d_fake_start.release(); c->d_work.release(); c->d_order.release(); c->d_counts.release(); c->d_blocks.release(); c->d_mdec.release();
+  c->d_rc.release(); c->d_dst_out.release(); c->d_fake_start.release(); c->d_work.release(); c->d_order.release(); c->d_counts.release(); c->d_blocks.release(); c->d_mdec.release();
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -795,6 +797,59 @@ int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud*
   out->points = ctx->dec_points.data();
   out->n = ctx->dec_points.size();
   if (rc != PCC_OK) return fail(ctx, rc, "decode: frame header not found, or stream truncated/corrupt");
+  return PCC_OK;
+}
+
+int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* in, const size_t* n, uint8_t* const* out, size_t* out_len,
+                            float* gpu_ms) {
+  if (!ctx || n_streams < 0 || (n_streams && (!in || !n || !out || !out_len))) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  PCC_HIP(hipSetDevice(ctx->device));
+  if (gpu_ms) *gpu_ms = 0.f;
+  if (n_streams == 0) return PCC_OK;
+  // one device buffer: [inputs | outputs | lengths | jobs]
+  std::vector<size_t> in_off((size_t)n_streams), out_off((size_t)n_streams);
+  size_t at = 0;
+  for (int i = 0; i < n_streams; ++i) {
+    if (n[i] >= (1ull << 31) || (n[i] && !in[i]) || !out[i]) return fail(ctx, PCC_ERR_ARG, "pcc_device_range_encode: stream arguments");
+    in_off[(size_t)i] = at;
+    at += (n[i] + 63) & ~(size_t)63;
+  }
+  const size_t in_bytes = at;
+  for (int i = 0; i < n_streams; ++i) {
+    out_off[(size_t)i] = at;
+    at += (1028 + n[i] + n[i] / 2 + 64 + 63) & ~(size_t)63;
+  }
+  const size_t len_off = at;
+  at += ((size_t)n_streams * sizeof(uint32_t) + 63) & ~(size_t)63;
+  const size_t job_off = at;
+  at += (size_t)n_streams * sizeof(RcJob);
+  PCC_HIP(ctx->d_rc.ensure(at));
+  std::vector<RcJob> jobs((size_t)n_streams);
+  for (int i = 0; i < n_streams; ++i) {
+    if (n[i]) PCC_HIP(hipMemcpyAsync(ctx->d_rc.p + in_off[(size_t)i], in[i], n[i], hipMemcpyHostToDevice, ctx->stream));
+    RcJob& j = jobs[(size_t)i];
+    j.in = ctx->d_rc.p + in_off[(size_t)i];
+    j.n = (uint32_t)n[i];
+    j.hist = nullptr;
+    j.out = ctx->d_rc.p + out_off[(size_t)i];
+    j.out_len = reinterpret_cast<uint32_t*>(ctx->d_rc.p + len_off) + i;
+  }
+  (void)in_bytes;
+  PCC_HIP(hipMemcpyAsync(ctx->d_rc.p + job_off, jobs.data(), jobs.size() * sizeof(RcJob), hipMemcpyHostToDevice, ctx->stream));
+  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+  launch_range_encode(reinterpret_cast<const RcJob*>(ctx->d_rc.p + job_off), (uint32_t)n_streams, ctx->stream);
+  PCC_HIP(hipGetLastError());
+  PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+  std::vector<uint32_t> lens((size_t)n_streams);
+  PCC_HIP(hipMemcpyAsync(lens.data(), ctx->d_rc.p + len_off, lens.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  for (int i = 0; i < n_streams; ++i) {
+    out_len[i] = lens[(size_t)i];
+    PCC_HIP(hipMemcpyAsync(out[i], ctx->d_rc.p + out_off[(size_t)i], lens[(size_t)i], hipMemcpyDeviceToHost, ctx->stream));
+  }
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  if (gpu_ms) (void)hipEventElapsedTime(gpu_ms, ctx->ev_begin, ctx->ev_end);
   return PCC_OK;
 }
 

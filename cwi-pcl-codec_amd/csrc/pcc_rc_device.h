@@ -1,0 +1,18 @@
+// pcc_rc_device.h -- the static range coder for many independent streams on the GPU (pcc_rc_device.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pcc {
+
+struct RcJob {            // one stream (device pointers)
+  const uint8_t* in;      // symbols
+  uint32_t n;
+  const uint32_t* hist;   // 256 symbol counts if somebody has them already (k_occ_histogram), else null
+  uint8_t* out;           // 1028-byte table + payload + 4 flush bytes; room for 1028 + n + n / 2 + 64 bytes, 4-byte aligned
+  uint32_t* out_len;      // bytes written
+};
+
+void launch_range_encode(const RcJob* dev_jobs, uint32_t n_jobs, hipStream_t stream);
+
+}  // namespace pcc

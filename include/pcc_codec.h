@@ -291,6 +291,14 @@ int pcc_delta_blocks(pcc_ctx *ctx, const pcc_delta_block **blocks, size_t *n); /
 int pcc_decode_delta(pcc_ctx *ctx, const pcc_point_xyzrgb *i_cloud, size_t n_i, const uint8_t *i_stream, size_t i_len,
                      const uint8_t *p_stream, size_t p_len, const pcc_delta_params *params, pcc_cloud *out);
 
+/* ---- the static range coder for MANY independent streams on the GPU (csrc/pcc_rc_device.hip) ----
+ * One wave per stream, coder state in scalar registers: roughly ten times slower per stream than a CPU core, but a
+ * thousand streams run side by side -- for pipelines whose host has fewer cores than the GPUs can feed.  Same bytes as
+ * pcc_host_range_encode.  Host pointers in and out (out[i]: room for 1028 + n[i] + n[i]/2 + 64 bytes); this entry point
+ * is the measurement / test harness of the kernel, the frame pipeline does not use it yet. */
+int pcc_device_range_encode(pcc_ctx *ctx, int n_streams, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
+                            size_t *out_len, float *gpu_ms);
+
 /* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
 /* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).
  * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */
