@@ -17,6 +17,8 @@
 // double operations (no FMA contraction, no fast-math): explicit __d*_rn intrinsics are
 // used and the file is compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <float.h>
 #include <stdint.h>
 
@@ -1622,7 +1624,9 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff);
   PCC_STAMP("k_leaf_tile");
   if (!a.lp.simplify_only) {
-    hipLaunchKernelGGL(k_occ_histogram, dim3(64), dim3(256), 0, stream, a.state, a.occ);
+    // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64
+    const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));
+    hipLaunchKernelGGL(k_occ_histogram, dim3(hist_wgs), dim3(256), 0, stream, a.state, a.occ);
     PCC_STAMP("k_occ_histogram");
   }
 }
