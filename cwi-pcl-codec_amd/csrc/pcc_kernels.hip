@@ -549,27 +549,28 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
 }
 
 // column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
-// One workgroup per 64 columns, 16 row groups (contiguous row ranges) per column, LDS combine.
+// One workgroup per 16 columns, 64 row groups (contiguous row ranges) per column, LDS combine: the grid is a few
+// hundred workgroups however many tiles there are, and a thread walks rows / 64 of them.
 // For pass 0 the input order of the sort is the tile order of k_make_keys, so the same kernel also
 // writes the exclusive prefix over the tiles (tile_prefix0[tile][digit]): pass 0 needs no look-back.
+constexpr uint32_t kDtCols = 16, kDtGroups = 1024 / kDtCols;
 __global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
                                                        const uint32_t* __restrict__ hist_rows,
                                                        uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0) {
-  __shared__ uint32_t s_part[16][64];
-  const uint32_t c = threadIdx.x & 63u;
-  const uint32_t col = blockIdx.x * 64u + c;
+  __shared__ uint32_t s_part[kDtGroups][kDtCols];
+  const uint32_t c = threadIdx.x % kDtCols;
+  const uint32_t col = blockIdx.x * kDtCols + c;
   const uint32_t pass = col / kMaxBins;
   if ((int)pass >= st->npasses) return;  // uniform per workgroup (512 columns per pass)
-  const uint32_t g = threadIdx.x >> 6;
-  const uint32_t per = (n_rows + 15u) / 16u;
+  const uint32_t g = threadIdx.x / kDtCols;
+  const uint32_t per = (n_rows + kDtGroups - 1u) / kDtGroups;
   const uint32_t r0 = min(g * per, n_rows), r1 = min(r0 + per, n_rows);
   uint32_t acc = 0;
   for (uint32_t r = r0; r < r1; ++r) acc += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
   s_part[g][c] = acc;
   __syncthreads();
   uint32_t before = 0, all = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < 16; ++k) {
+  for (uint32_t k = 0; k < kDtGroups; ++k) {
     const uint32_t v = s_part[k][c];
     if (k < g) before += v;
     all += v;
@@ -1607,7 +1608,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("k_bbox_events");
   hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows);
   PCC_STAMP("k_make_keys");
-  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / 64u), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0);
+  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0);
   PCC_STAMP("k_digit_totals");
   for (int pass = 0; pass < passes; ++pass) {
     hipLaunchKernelGGL(k_sort_pass, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
