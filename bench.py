@@ -96,7 +96,20 @@ def main():
         if share_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL prints a banner ("Hostname : ...", "Librccl path : ...") on STDOUT when the communicator is made;
+            # stdout is for the one JSON line: send it to stderr while the communicator comes up
+            import ctypes
+            saved = os.dup(1)
+            sys.stdout.flush()
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                ctypes.CDLL(None).fflush(None)
+                os.dup2(saved, 1)
+                os.close(saved)
 
     import __graft_entry__ as G
     pkg = G.load_package()
