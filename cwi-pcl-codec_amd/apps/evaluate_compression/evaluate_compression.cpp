@@ -463,11 +463,11 @@ struct App {
     for (CloudPtr& c : group) working_group.push_back(CloudPtr(new Cloud(*c)));  // deep copy (eval.hpp:804-808)
     if (opt.integer("K_outlier_filter") > 0)  // do_outlier_removal (eval.hpp:430-435)
       Codec::remove_outliers(working_group, opt.integer("K_outlier_filter"), opt.real("radius"), (unsigned)opt.integer("debug_level"));
-    pcl::io::BoundingBox bb;
-    memset(&bb, 0, sizeof(bb));
-    std::vector<pcl::io::BoundingBox> boxes;
+    pcl::io::BoundingBox bb;  // do_bounding_box_normalization (eval.hpp:438-444), with the reference's vector type
+    std::vector<float> dyn_range, offset;
+    std::vector<pcl::io::BoundingBox, Eigen::aligned_allocator<pcl::io::BoundingBox> > boxes(working_group.size());
     const double f = opt.real("bb_expand_factor");
-    if (f > 0.0) bb = Codec::normalize_pointclouds(working_group, boxes, f);
+    if (f > 0.0) bb = Codec::normalize_pointclouds(working_group, boxes, f, dyn_range, offset, (unsigned)opt.integer("debug_level"));
     const double res = opt.integer("octree_bits") > 0 ? std::pow(2.0, -1.0 * opt.integer("octree_bits")) : opt.real("octree_resolution");
     for (size_t i = 0; i < working_group.size(); ++i) {
       CloudPtr pc = working_group[i];

@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcc_hip.so")
+# PCC_LIB: developer builds of the same library (e.g. libpcc_hip_ktime.so); there is no fallback either way
+LIB_PATH = os.environ.get("PCC_LIB") or os.path.join(_HERE, "libpcc_hip.so")
 
 POINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("rgba", "<u4"), ("pad", "<u4", (3,))]
@@ -39,7 +40,7 @@ EXPORTS = [
     "pcc_quality_metrics", "pcc_remove_outliers", "pcc_device_range_encode",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
-    "pcc_host_snake_position", "pcc_normalize_group", "pcc_restore_scaling",
+    "pcc_host_snake_position", "pcc_normalize_group", "pcc_normalize_group_boxes", "pcc_restore_scaling",
 ]
 
 

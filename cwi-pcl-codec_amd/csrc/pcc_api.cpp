@@ -9,6 +9,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -140,6 +141,10 @@ struct pcc_ctx {
   size_t last_L = 0;
   double usual_wait_ns[3] = {0, 0, 0};  // how long the waits took lately: kernels of a frame, copies, anything else
   pcc_hot_result last_hot{};
+  // the occupancy byte counts of the last finished frame.  They arrive inside the pinned FrameState, which the NEXT
+  // pcc_hotpath_launch overwrites asynchronously; this copy is only rewritten by pcc_hotpath_finish, like the other
+  // products a pcc_hot_result points to
+  uint32_t occ_hist[256] = {0};
 };
 
 namespace {
@@ -562,7 +567,8 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->jpeg_tiles = tiles_ok ? h_tiles : nullptr;
   out->jpeg_tile_words = kJpegTileWords;
   out->jpeg_n_tiles = (uint32_t)n_tiles;
-  out->occupancy_histogram = ctx->h_state.p->occ_hist;  // counted by k_occ_histogram, came back with the FrameState
+  memcpy(ctx->occ_hist, ctx->h_state.p->occ_hist, sizeof(ctx->occ_hist));  // counted by k_occ_histogram, came back with the FrameState
+  out->occupancy_histogram = ctx->occ_hist;
   out->image_w = image ? W : 0;
   out->image_h = image ? H : 0;
   ctx->last_L = L;
@@ -793,7 +799,13 @@ int pcc_remove_outliers(pcc_ctx* ctx, const pcc_point_xyzrgb* cloud, size_t n, i
 
 int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud* out) {
   if (!ctx || !out || (!stream && len)) return PCC_ERR_ARG;
-  const int rc = decode_frame(stream, len, ctx->dec_points, *out);
+  int rc;
+  try {  // a corrupt header can ask for more memory than there is: that must not leave the C ABI as an exception
+    rc = decode_frame(stream, len, ctx->dec_points, *out);
+  } catch (const std::bad_alloc&) {
+    ctx->dec_points.clear();
+    rc = PCC_ERR_STREAM;
+  }
   out->points = ctx->dec_points.data();
   out->n = ctx->dec_points.size();
   if (rc != PCC_OK) return fail(ctx, rc, "decode: frame header not found, or stream truncated/corrupt");
@@ -873,7 +885,11 @@ size_t pcc_host_jpeg_encode(const uint8_t* rgb, int w, int h, int quality, uint8
 }
 int pcc_host_jpeg_decode(const uint8_t* jpg, size_t len, uint8_t* rgb, size_t rgb_cap, int* w, int* h) {
   Bytes b;
-  if (!w || !h || !BaselineJpeg::decode_rgb(jpg, len, b, *w, *h)) return PCC_ERR_STREAM;
+  try {
+    if (!w || !h || !BaselineJpeg::decode_rgb(jpg, len, b, *w, *h)) return PCC_ERR_STREAM;
+  } catch (const std::bad_alloc&) {
+    return PCC_ERR_STREAM;
+  }
   if (b.size() > rgb_cap) return PCC_ERR_ARG;
   memcpy(rgb, b.data(), b.size());
   return PCC_OK;
@@ -882,6 +898,11 @@ uint32_t pcc_host_snake_position(uint32_t i, uint32_t w, uint32_t h) { return sn
 
 int pcc_normalize_group(pcc_point_xyzrgb** clouds, const size_t* sizes, size_t n_clouds, double f, float bb_min[3],
                         float bb_max[3]) {
+  return pcc_normalize_group_boxes(clouds, sizes, n_clouds, f, bb_min, bb_max, nullptr);
+}
+
+int pcc_normalize_group_boxes(pcc_point_xyzrgb** clouds, const size_t* sizes, size_t n_clouds, double f, float bb_min[3],
+                              float bb_max[3], float* per_cloud) {
   // normalize_pointclouds (impl.hpp:1871-1967): a running box that is re-initialised from a
   // frame's own extent whenever that frame does not fit strictly inside it
   if (!clouds || !sizes || !bb_min || !bb_max) return PCC_ERR_ARG;
@@ -906,6 +927,8 @@ int pcc_normalize_group(pcc_point_xyzrgb** clouds, const size_t* sizes, size_t n
       init = true;
     }
     const float dyn[3] = {mxb[0] - mnb[0], mxb[1] - mnb[1], mxb[2] - mnb[2]};
+    if (per_cloud)  // bounding_boxes[k] = the box in force for cloud k (impl.hpp:1928-1929)
+      for (int a = 0; a < 3; ++a) { per_cloud[6 * k + a] = mnb[a]; per_cloud[6 * k + 3 + a] = mxb[a]; }
     for (size_t i = 0; i < sizes[k]; ++i) {
       c[i].x -= mnb[0]; c[i].y -= mnb[1]; c[i].z -= mnb[2];
       c[i].x /= dyn[0]; c[i].y /= dyn[1]; c[i].z /= dyn[2];
@@ -1264,7 +1287,13 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   }
   if (i_len) {  // the intra coded points follow the predicted ones (impl.hpp:1207-1229)
     pcc_cloud ic;
-    const int rc = decode_frame(i_stream, i_len, ctx->dec_points, ic);
+    int rc;
+    try {
+      rc = decode_frame(i_stream, i_len, ctx->dec_points, ic);
+    } catch (const std::bad_alloc&) {
+      ctx->dec_points.clear();
+      rc = PCC_ERR_STREAM;
+    }
     if (rc != PCC_OK) return fail(ctx, rc, "decode: intra part of the delta frame: header not found, or stream truncated/corrupt");
     out->params = ic.params; out->depth = ic.depth; out->consumed = ic.consumed;
     for (int a = 0; a < 6; ++a) out->bbox[a] = ic.bbox[a];

@@ -738,9 +738,9 @@ void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Byt
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct HuffDec {
-  int32_t maxcode[18];
-  int32_t valoff[17];
-  uint8_t vals[256];
+  int32_t maxcode[18] = {};
+  int32_t valoff[17] = {};
+  uint8_t vals[256] = {};
   bool ok = false;
   void build(const uint8_t bits[16], const uint8_t* v, int n) {
     memcpy(vals, v, (size_t)n);
@@ -893,6 +893,7 @@ bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w
     } else if (m == 0xC2 || (m > 0xC4 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
       return false;
     } else if (m == 0xDD) {
+      if (n < 2) return false;
       restart = (s[0] << 8) | s[1];
     } else if (m == 0xDA) {
       if (n < 10 || s[0] != 3) return false;
@@ -902,6 +903,11 @@ bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w
     pos += seg;
   }
   if (!sos || w <= 0 || h <= 0 || samp[0] != 0x22 || samp[1] != 0x11 || samp[2] != 0x11) return false;
+  for (int c = 0; c < 3; ++c)  // a scan that names a table no DHT segment defined
+    if (!hd[0][tdc[c]].ok || !hd[1][tac[c]].ok) return false;
+  // An MCU of six blocks takes at least six bits of entropy data per block pair ... in any case more than one byte: a
+  // header that promises more MCUs than the payload has bytes is corrupt (and would ask for gigabytes below)
+  if ((uint64_t)((w + 15) / 16) * (uint64_t)((h + 15) / 16) > (uint64_t)len) return false;
 
   const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
   const int cw = (w + 1) / 2, chh = (h + 1) / 2;
@@ -1266,8 +1272,9 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
       int w = 0, h = 0;
       if (BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h) && w % 8 == 0) {
         col.resize(img.size());
-        for (uint32_t i = 0; i < (uint32_t)(w * h); ++i) {
-          const uint32_t px = snake_position(i, (uint32_t)w, (uint32_t)h);
+        const uint64_t npix = (uint64_t)w * (uint64_t)h;  // < 2^32 (two 16-bit fields of the frame header)
+        for (uint64_t i = 0; i < npix; ++i) {
+          const uint32_t px = snake_position((uint32_t)i, (uint32_t)w, (uint32_t)h);
           col[3 * i] = img[3 * px]; col[3 * i + 1] = img[3 * px + 1]; col[3 * i + 2] = img[3 * px + 2];
         }
       }

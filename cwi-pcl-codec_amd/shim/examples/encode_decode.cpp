@@ -6,6 +6,13 @@
 #include <cmath>
 #include <cstdio>
 #include <sstream>
+#include <streambuf>
+
+// a stream that can only be read forwards (a socket, a pipe): tellg() is -1 and seekg() fails
+struct forward_only_buf : std::streambuf {
+  std::string data;
+  explicit forward_only_buf(const std::string& s) : data(s) { setg(&data[0], &data[0], &data[0] + data.size()); }
+};
 
 typedef pcl::PointXYZRGB PointT;
 typedef pcl::io::OctreePointCloudCodecV2<PointT> Codec;
@@ -39,5 +46,28 @@ int main(int argc, char** argv) {
   std::printf("points in %d, compressed %zu bytes (octree %llu, centroid %llu, colour %llu), decoded voxels %zu\n", n,
               stream.str().size(), (unsigned long long)sizes[0], (unsigned long long)sizes[1],
               (unsigned long long)sizes[2], out->points.size());
-  return out->points.size() == encoder.getOutputCloud()->points.size() ? 0 : 1;
+  if (out->points.size() != encoder.getOutputCloud()->points.size()) return 1;
+
+  // Several frames in ONE stream (the reference decodes them one call at a time, each call consuming exactly one
+  // frame, impl.hpp:224-310): once through a seekable stream, once through a forward-only one, with garbage in front.
+  std::stringstream many;
+  many << "junk before the first header";
+  const int kFrames = 3;
+  for (int f = 0; f < kFrames; ++f) encoder.encodePointCloud(cloud, many);
+  const std::string all = many.str();
+  forward_only_buf fb(all);
+  std::istream forward(&fb);
+  std::istream* inputs[2] = {&many, &forward};
+  for (int k = 0; k < 2; ++k) {
+    for (int f = 0; f < kFrames; ++f) {
+      pcl::PointCloud<PointT>::Ptr o(new pcl::PointCloud<PointT>());
+      decoder.decodePointCloud(*inputs[k], o);
+      if (o->points.size() != out->points.size()) { std::printf("stream %d frame %d: %zu voxels\n", k, f, o->points.size()); return 2; }
+    }
+    pcl::PointCloud<PointT>::Ptr none(new pcl::PointCloud<PointT>());
+    decoder.decodePointCloud(*inputs[k], none);  // nothing left: output untouched (impl.hpp:231)
+    if (!none->points.empty()) return 3;
+  }
+  std::printf("%d frames decoded one by one from a seekable and from a forward-only stream\n", kFrames);
+  return 0;
 }

@@ -13,19 +13,24 @@
 //   decodePointCloud             -> pcc_decode_intra      (codec.h:177-178, impl.hpp:224-310)
 //   getPerformanceMetrics        -> pcc_bitstream.perf    (codec.h:193-197)
 //   getOutputCloud               -> pcc_get_output_cloud  (used at eval.hpp:862)
-//   normalize_pointclouds / restore_scaling -> pcc_normalize_group / pcc_restore_scaling (codec.h:216-227)
-//   encodePointCloudDeltaFrame / decodePointCloudDeltaFrame: the inter-frame path is outside this
-//   round's scope; they throw std::logic_error rather than silently differ.
+//   normalize_pointclouds / restore_scaling -> pcc_normalize_group_boxes / pcc_restore_scaling (codec.h:216-227)
+//   remove_outliers              -> pcc_remove_outliers   (codec.h:216-217)
+//   encodePointCloudDeltaFrame / generatePointCloudDeltaFrame / decodePointCloudDeltaFrame
+//                                -> pcc_encode_delta / pcc_decode_delta (codec.h:181-191)
+// The GPU is chosen with the environment variable PCC_DEVICE (default 0): the reference's constructor has no
+// argument for it, and its signature is kept.
 #pragma once
 #ifndef PCL_POINT_TYPES_H_
 #include "../pcl_lite.h"
 #endif
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <iostream>
 #include <istream>
+#include <iterator>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -36,10 +41,15 @@
 namespace pcl {
 namespace io {
 
-struct BoundingBox {  // codec.h:64-68 (Eigen::Vector4f there; four floats here)
-  float min_xyz[4];
-  float max_xyz[4];
+struct BoundingBox {  // codec.h:64-68
+  Eigen::Vector4f min_xyz;
+  Eigen::Vector4f max_xyz;
 };
+
+inline int pcc_shim_device() {  // which GPU the codec objects of this process use
+  const char* e = getenv("PCC_DEVICE");
+  return e ? atoi(e) : 0;
+}
 
 template <typename PointT>
 class OctreePointCloudCodecV2 {
@@ -75,8 +85,10 @@ class OctreePointCloudCodecV2 {
     prm_.jpeg_quality = jpeg_quality_arg;
     prm_.macroblock_size = 16;     // codec.h:138
     prm_.do_icp_color_offset = 0;  // codec.h:141
+    icp_max_iterations_ = 50;      // codec.h:139-142
+    transformationepsilon_ = 1e-8f;
     perf_[0] = perf_[1] = perf_[2] = 0;
-    ctx_ = pcc_create(0);
+    ctx_ = pcc_create(pcc_shim_device());
     if (!ctx_) throw std::runtime_error("OctreePointCloudCodecV2: no usable MI355X/HIP device (there is no CPU fallback)");
   }
   ~OctreePointCloudCodecV2() { pcc_destroy(ctx_); }
@@ -85,7 +97,10 @@ class OctreePointCloudCodecV2 {
 
   void initialization() {}                                     // codec.h:145
   void setMacroblockSize(int size) { prm_.macroblock_size = size; }  // codec.h:149
+  void setColorVarThreshold(int size) { prm_.macroblock_size = size; }  // codec.h:154-157: the reference assigns macroblock_size_ here
+  void setMaxIterations(int max_in) { icp_max_iterations_ = max_in; }  // codec.h:159-162
   void setDoICPColorOffset(bool doit) { prm_.do_icp_color_offset = doit; }  // codec.h:164
+  void setDoICPColorOffset(float tfeps) { transformationepsilon_ = tfeps; }  // codec.h:169-172: the float overload sets transformationepsilon_
 
   // codec.h:174-175
   void encodePointCloud(const PointCloudConstPtr& cloud_arg, std::ostream& compressed_tree_data_out_arg) {
@@ -103,19 +118,15 @@ class OctreePointCloudCodecV2 {
     compressed_tree_data_out_arg.flush();
   }
 
-  // codec.h:177-178.  Reads the rest of the stream, decodes the first frame found and leaves the
-  // read position right behind it (the reference consumes exactly one frame as well).
+  // codec.h:177-178.  Consumes exactly one frame, like the reference (syncToHeader, impl.hpp:1660-1676, then the
+  // pieces of impl.hpp:1766-1835).  The range-coded pieces do not state their coded length, so the frame is read in
+  // a bounded piece sized from its header (doubled if the decoder runs out of bytes) and what was read beyond the
+  // frame is given back to the stream: a concatenation of frames costs every byte a constant number of times.
+  // A stream that cannot seek keeps the surplus inside this object; it is used first at the next call on that stream.
   void decodePointCloud(std::istream& compressed_tree_data_in_arg, PointCloudPtr& cloud_arg) {
-    const std::streampos start = compressed_tree_data_in_arg.tellg();
-    std::vector<char> buf((std::istreambuf_iterator<char>(compressed_tree_data_in_arg)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> buf;
     pcc_cloud out;
-    const int rc = pcc_decode_intra(ctx_, reinterpret_cast<const uint8_t*>(buf.data()), buf.size(), &out);
-    compressed_tree_data_in_arg.clear();
-    if (rc != PCC_OK) {  // impl.hpp:231: header not found -> output untouched
-      compressed_tree_data_in_arg.seekg(start);
-      return;
-    }
-    compressed_tree_data_in_arg.seekg(start + (std::streamoff)out.consumed);
+    if (!read_and_decode(compressed_tree_data_in_arg, buf, out)) return;  // impl.hpp:231: no header -> output untouched
     cloud_arg->points.resize(out.n);
     if (out.n) memcpy(static_cast<void*>(cloud_arg->points.data()), out.points, out.n * sizeof(PointT));
     cloud_arg->height = 1;  // impl.hpp:284-286
@@ -140,18 +151,44 @@ class OctreePointCloudCodecV2 {
   // codec.h:181-186 / impl.hpp:787-1118
   virtual void encodePointCloudDeltaFrame(const PointCloudConstPtr& icloud_arg, const PointCloudConstPtr& pcloud_arg, PointCloudPtr& out_cloud_arg,
                                           std::ostream& i_coded_data, std::ostream& p_coded_data, bool icp_on_original = false,
-                                          bool write_out_cloud = true) {
+                                          bool write_out_cloud = false) {
+    delta_frame(icloud_arg, pcloud_arg, out_cloud_arg, i_coded_data, p_coded_data, icp_on_original, write_out_cloud, true);
+  }
+  // codec.h:177-179 / impl.hpp:579-777: the serial predecessor of encodePointCloudDeltaFrame.  Same blocks, gates, ICP and
+  // intra part; its p_coded_data chunks have no leading size byte (impl.hpp:657-662 against :1021-1027), and it resets
+  // out_cloud_arg's width/height before the blocks are visited (impl.hpp:603-604).
+  virtual void generatePointCloudDeltaFrame(const PointCloudConstPtr& icloud_arg, const PointCloudConstPtr& pcloud_arg, PointCloudPtr& out_cloud_arg,
+                                            std::ostream& i_coded_data, std::ostream& p_coded_data, bool icp_on_original = false,
+                                            bool write_out_cloud = true) {
+    out_cloud_arg->height = 1;
+    out_cloud_arg->width = 0;
+    delta_frame(icloud_arg, pcloud_arg, out_cloud_arg, i_coded_data, p_coded_data, icp_on_original, write_out_cloud, false);
+  }
+
+ private:
+  void delta_frame(const PointCloudConstPtr& icloud_arg, const PointCloudConstPtr& pcloud_arg, PointCloudPtr& out_cloud_arg,
+                   std::ostream& i_coded_data, std::ostream& p_coded_data, bool icp_on_original, bool write_out_cloud, bool chunk_sizes) {
     pcc_delta_params dp;
     memset(&dp, 0, sizeof(dp));
     dp.codec = prm_;
     dp.icp_on_original = icp_on_original;
     dp.write_out_cloud = write_out_cloud;
+    dp.icp_max_iterations = icp_max_iterations_;
+    dp.transformation_epsilon = transformationepsilon_;
     pcc_delta_result r;
     const int rc = pcc_encode_delta(ctx_, reinterpret_cast<const pcc_point_xyzrgb*>(icloud_arg->points.data()), icloud_arg->points.size(),
                                     reinterpret_cast<const pcc_point_xyzrgb*>(pcloud_arg->points.data()), pcloud_arg->points.size(), &dp, &r);
     if (rc != PCC_OK) throw std::runtime_error(std::string("encodePointCloudDeltaFrame: ") + pcc_last_error(ctx_));
     i_coded_data.write(reinterpret_cast<const char*>(r.i_data), (std::streamsize)r.i_len);
-    p_coded_data.write(reinterpret_cast<const char*>(r.p_data), (std::streamsize)r.p_len);
+    if (chunk_sizes) {
+      p_coded_data.write(reinterpret_cast<const char*>(r.p_data), (std::streamsize)r.p_len);
+    } else {
+      for (size_t at = 0; at < r.p_len;) {  // u8 size | chunk
+        const size_t len = r.p_data[at];
+        p_coded_data.write(reinterpret_cast<const char*>(r.p_data + at + 1), (std::streamsize)len);
+        at += 1 + len;
+      }
+    }
     if (write_out_cloud && out_cloud_arg) {  // push_back onto whatever the caller had in it (impl.hpp:899-935)
       const size_t before = out_cloud_arg->points.size();
       out_cloud_arg->points.resize(before + r.out_n);
@@ -162,10 +199,17 @@ class OctreePointCloudCodecV2 {
     shared_macroblock_percentage_ = r.shared_macroblock_percentage;
     shared_macroblock_convergence_percentage_ = r.shared_macroblock_convergence_percentage;
   }
-  // codec.h:188-191 / impl.hpp:1120-1235
+
+ public:
+  // codec.h:188-191 / impl.hpp:1120-1235.  Like the reference: the chunk list is read to the end of p_coded_data
+  // (impl.hpp:1144-1150 loops until the stream is exhausted) and exactly one intra frame is taken from i_coded_data.
   virtual void decodePointCloudDeltaFrame(const PointCloudConstPtr& icloud_arg, PointCloudPtr& cloud_out_arg, std::istream& i_coded_data,
                                           std::istream& p_coded_data) {
-    std::vector<char> ib((std::istreambuf_iterator<char>(i_coded_data)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> ib;
+    {
+      pcc_cloud unused;
+      read_and_decode(i_coded_data, ib, unused);  // exactly one intra frame leaves i_coded_data; it is decoded again below with the chunks
+    }
     std::vector<char> pb((std::istreambuf_iterator<char>(p_coded_data)), std::istreambuf_iterator<char>());
     pcc_delta_params dp;
     memset(&dp, 0, sizeof(dp));
@@ -188,7 +232,7 @@ class OctreePointCloudCodecV2 {
   // the function is static in the reference as well)
   static void remove_outliers(std::vector<PointCloudPtr>& point_clouds, int min_points, double radius, unsigned int debug_level = 0) {
     if (min_points <= 0) return;
-    pcc_ctx* c = pcc_create(0);
+    pcc_ctx* c = pcc_create(pcc_shim_device());  // one context for the whole group (the function is static: there is no object to keep it in)
     if (!c) throw std::runtime_error("remove_outliers: no usable MI355X/HIP device (there is no CPU fallback)");
     for (auto& pc : point_clouds) {
       std::vector<uint8_t> keep(pc->points.size() + 1);
@@ -212,8 +256,11 @@ class OctreePointCloudCodecV2 {
     pcc_destroy(c);
   }
 
-  // codec.h:223-227 (vectors of dyn_range/offset are unused by the reference as well)
-  static BoundingBox normalize_pointclouds(std::vector<PointCloudPtr>& point_clouds, std::vector<BoundingBox>& bounding_boxes,
+  // codec.h:223-227 / impl.hpp:1871-1967.  The box vector's allocator is a template parameter: the reference declares
+  // vector<BoundingBox, Eigen::aligned_allocator<BoundingBox>> and the app passes exactly that (eval.hpp:442-443).
+  // dyn_range / offset are unused by the reference as well.  bounding_boxes[k] = the box in force for cloud k.
+  template <class BoxAlloc>
+  static BoundingBox normalize_pointclouds(std::vector<PointCloudPtr>& point_clouds, std::vector<BoundingBox, BoxAlloc>& bounding_boxes,
                                            double bb_expand_factor, std::vector<float> = std::vector<float>(),
                                            std::vector<float> = std::vector<float>(), unsigned int = 0) {
     std::vector<pcc_point_xyzrgb*> ptrs;
@@ -222,20 +269,98 @@ class OctreePointCloudCodecV2 {
       ptrs.push_back(reinterpret_cast<pcc_point_xyzrgb*>(c->points.data()));
       sizes.push_back(c->points.size());
     }
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    std::vector<float> per_cloud(6 * point_clouds.size() + 6);
+    pcc_normalize_group_boxes(ptrs.data(), sizes.data(), ptrs.size(), bb_expand_factor, mn, mx, per_cloud.data());
     BoundingBox bb;
-    memset(&bb, 0, sizeof(bb));
-    pcc_normalize_group(ptrs.data(), sizes.data(), ptrs.size(), bb_expand_factor, bb.min_xyz, bb.max_xyz);
-    bounding_boxes.assign(point_clouds.size(), bb);
+    for (int a = 0; a < 3; ++a) { bb.min_xyz[a] = mn[a]; bb.max_xyz[a] = mx[a]; }
+    bb.min_xyz[3] = 0.f;  // impl.hpp:1874: min_pt_bb(0,0,0,0); max_pt_bb[3] is never set there
+    bb.max_xyz[3] = 0.f;
+    if (bounding_boxes.size() < point_clouds.size()) bounding_boxes.resize(point_clouds.size());
+    for (size_t k = 0; k < point_clouds.size(); ++k)
+      for (int a = 0; a < 3; ++a) {
+        bounding_boxes[k].min_xyz[a] = per_cloud[6 * k + a];
+        bounding_boxes[k].max_xyz[a] = per_cloud[6 * k + 3 + a];
+      }
     return bb;
   }
   static void restore_scaling(PointCloudPtr& point_cloud, const BoundingBox& bb) {
-    pcc_restore_scaling(reinterpret_cast<pcc_point_xyzrgb*>(point_cloud->points.data()), point_cloud->points.size(), bb.min_xyz,
-                        bb.max_xyz);
+    const float mn[3] = {bb.min_xyz[0], bb.min_xyz[1], bb.min_xyz[2]}, mx[3] = {bb.max_xyz[0], bb.max_xyz[1], bb.max_xyz[2]};
+    pcc_restore_scaling(reinterpret_cast<pcc_point_xyzrgb*>(point_cloud->points.data()), point_cloud->points.size(), mn, mx);
   }
 
  private:
+  // bytes from the carry-over of `in` first, then from `in` itself
+  size_t pull(std::istream& in, std::vector<uint8_t>& buf, size_t n) {
+    size_t got = 0;
+    if (carry_stream_ == &in && !carry_.empty()) {
+      got = n < carry_.size() ? n : carry_.size();
+      buf.insert(buf.end(), carry_.begin(), carry_.begin() + (std::ptrdiff_t)got);
+      carry_.erase(carry_.begin(), carry_.begin() + (std::ptrdiff_t)got);
+    }
+    if (got < n) {
+      const size_t at = buf.size();
+      buf.resize(at + (n - got));
+      in.read(reinterpret_cast<char*>(buf.data() + at), (std::streamsize)(n - got));
+      const size_t r = (size_t)in.gcount();
+      buf.resize(at + r);
+      got += r;
+    }
+    return got;
+  }
+  // one frame off the stream, decoded into the context's cloud buffer; `buf` holds exactly the frame afterwards
+  bool read_and_decode(std::istream& in, std::vector<uint8_t>& buf, pcc_cloud& out) {
+    static const char kId[] = "<PCL-OCT-CODECV2-COMPRESSED>";  // codec.h:371; 28 bytes on the wire
+    const size_t id_len = sizeof(kId) - 1;
+    if (carry_stream_ != &in) carry_.clear();
+    size_t matched = 0;
+    std::vector<uint8_t> one;
+    while (matched < id_len) {  // syncToHeader: byte by byte until the identifier has gone by
+      one.clear();
+      if (pull(in, one, 1) != 1) return false;
+      const char ch = (char)one[0];
+      matched = (ch == kId[matched]) ? matched + 1 : ((ch == kId[0]) ? 1 : 0);
+    }
+    buf.assign(kId, kId + id_len);
+    // 20-byte base identifier, frame id, flags, then the voxel count at byte 55: the size of the frame follows it loosely
+    if (pull(in, buf, 140 - id_len) != 140 - id_len) return false;
+    uint64_t voxels = 0;
+    memcpy(&voxels, buf.data() + 55, sizeof(voxels));
+    size_t want = 8192 + (size_t)(voxels < (1ull << 32) ? voxels : (1ull << 32)) * 2;
+    for (;;) {
+      const size_t got = pull(in, buf, want);
+      const int rc = pcc_decode_intra(ctx_, buf.data(), buf.size(), &out);
+      if (rc == PCC_OK) {
+        const size_t surplus = buf.size() - out.consumed;
+        if (surplus) {
+          in.clear();  // reading to the end of the stream sets eofbit / failbit
+          if (carry_stream_ == &in && !carry_.empty()) {  // part of the surplus may have come from the carry-over: it goes back there
+            carry_.insert(carry_.begin(), buf.end() - (std::ptrdiff_t)surplus, buf.end());
+          } else if (in.tellg() != std::streampos(-1) && in.seekg(-(std::streamoff)surplus, std::ios_base::cur)) {
+            carry_.clear();
+          } else {
+            in.clear();
+            carry_stream_ = &in;
+            carry_.assign(buf.end() - (std::ptrdiff_t)surplus, buf.end());
+          }
+          buf.resize(out.consumed);
+        }
+        return true;
+      }
+      if (got < want) {  // the stream has no more to give: truncated or corrupt frame (impl.hpp has no error path either)
+        in.clear();
+        return false;
+      }
+      want = buf.size();  // double what has been read
+    }
+  }
+  std::vector<uint8_t> carry_;
+  const std::istream* carry_stream_ = nullptr;
+
   pcc_ctx* ctx_;
   pcc_params prm_;
+  int icp_max_iterations_;
+  float transformationepsilon_;
   bool show_statistics_;
   uint32_t frame_id_;
   uint64_t perf_[3];

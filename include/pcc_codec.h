@@ -318,6 +318,10 @@ int pcc_host_rigid_decompress(const int16_t *comp, size_t count, float tr_out[16
 /* normalize_pointclouds / restore_scaling for one group (codec.h:216-227, impl.hpp:1871-1986), host side */
 int pcc_normalize_group(pcc_point_xyzrgb **clouds, const size_t *sizes, size_t n_clouds, double bb_expand_factor,
                         float bb_min[3], float bb_max[3]);
+/* the same, also reporting the box in force for every cloud (bounding_boxes[k], impl.hpp:1928-1929):
+ * per_cloud_boxes = n_clouds x {min x,y,z, max x,y,z}, or NULL */
+int pcc_normalize_group_boxes(pcc_point_xyzrgb **clouds, const size_t *sizes, size_t n_clouds, double bb_expand_factor,
+                              float bb_min[3], float bb_max[3], float *per_cloud_boxes);
 int pcc_restore_scaling(pcc_point_xyzrgb *cloud, size_t n, const float bb_min[3], const float bb_max[3]);
 
 #ifdef __cplusplus

@@ -333,6 +333,38 @@ def test_cpp_shim_example_runs(pkg):
     r = subprocess.run([exe, "200000", "9"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "decoded voxels" in r.stdout
+    # decodePointCloud consumes exactly one frame per call, from seekable and from forward-only streams
+    assert "3 frames decoded one by one" in r.stdout
+
+
+def test_next_frame_may_be_launched_before_the_entropy_stage(pkg, oracle):
+    """include/pcc_codec.h lets pcc_entropy_encode(other_ctx, hot, ...) run while the context that produced `hot`
+    already works on its next frame: nothing a pcc_hot_result points to may change before the next
+    pcc_hotpath_finish on that context (the occupancy histogram used to live in the pinned FrameState, which the
+    next launch overwrites asynchronously)."""
+    b = pkg.binding
+    gpu, out_ctx = b.Context(0), b.Context(None)
+    try:
+        kw = dict(octree_bits=9, jpeg_quality=85)
+        frames = [pkg.synthetic.sphere_shell(150_000, 0x700 + f) for f in range(2)] + [pkg.synthetic.uniform_volume(150_000, 0x7AA)]
+        devs = [gpu.upload(f) for f in frames]
+        want = [oracle.encode_intra(f, oracle.make_params(frame_id=k + 1, **kw)) for k, f in enumerate(frames)]
+        for rounds in range(3):
+            gpu.hotpath_launch(devs[0], len(frames[0]), b.make_params(frame_id=1, **kw))
+            for k in range(len(frames)):
+                hot = gpu.hotpath_finish(copy=False)
+                nxt = (k + 1) % len(frames)
+                gpu.hotpath_launch(devs[nxt], len(frames[nxt]), b.make_params(frame_id=nxt + 1, **kw))  # frame k+1 is on the GPU ...
+                import time
+                time.sleep(0.002)                                                                       # ... and its FrameState has landed
+                import ctypes
+                hist = np.frombuffer(ctypes.string_at(hot.raw.occupancy_histogram, 1024), dtype=np.uint32)
+                assert np.array_equal(hist, np.bincount(want[k].occupancy, minlength=256))
+                stream, perf = out_ctx.entropy_encode(hot.raw, b.make_params(frame_id=k + 1, **kw))      # ... while frame k is coded
+                assert stream == want[k].bitstream
+            gpu.hotpath_finish(copy=False)
+    finally:
+        gpu.close(); out_ctx.close()
 
 
 @pytest.mark.parametrize("L", [1, 255, 256, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 9000, 40000])
