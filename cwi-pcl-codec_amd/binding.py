@@ -29,13 +29,14 @@ ERR_NAMES = {-1: "PCC_ERR_ARG", -2: "PCC_ERR_HIP", -3: "PCC_ERR_EMPTY", -4: "PCC
 EXPORTS = [
     "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
+    "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
     "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra",
-    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_host_times",
+    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
     "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_contexts",
     "pcc_pipeline_context",
-    "pcc_pipeline_encode", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
+    "pcc_pipeline_encode", "pcc_pipeline_encode_host", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
     "pcc_quality_metrics", "pcc_remove_outliers", "pcc_device_range_encode",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
@@ -135,6 +136,15 @@ def load_library():
     lib.pcc_encode_intra_device.argtypes = [vp, vp, sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_hotpath_launch.argtypes = [vp, vp, sz, sz, sz, C.POINTER(Params)]
     lib.pcc_hotpath_finish.argtypes = [vp, C.POINTER(HotResult)]
+    lib.pcc_hotpath_launch_host.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(Params)]
+    lib.pcc_upload_lane_create.restype = vp
+    lib.pcc_upload_lane_create.argtypes = [i32]
+    lib.pcc_upload_lane_destroy.argtypes = [vp]
+    lib.pcc_upload_lane_destroy.restype = None
+    lib.pcc_host_alloc.restype = vp
+    lib.pcc_host_alloc.argtypes = [sz]
+    lib.pcc_host_free.argtypes = [vp]
+    lib.pcc_host_free.restype = None
     lib.pcc_entropy_encode.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_entropy_encode2.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream),
                                         vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
@@ -145,6 +155,7 @@ def load_library():
     lib.pcc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.pcc_device_free.argtypes = [vp, vp]
     lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
+    lib.pcc_get_kernel_spans.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_get_host_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_set_profiling.argtypes = [vp, i32]
@@ -157,6 +168,7 @@ def load_library():
     lib.pcc_pipeline_contexts.argtypes = [vp]
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
+    lib.pcc_pipeline_encode_host.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_pipeline_encode.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_pipeline_reserve.argtypes = [vp, sz, sz, sz]
     lib.pcc_reserve.argtypes = [vp, sz, sz]
@@ -282,6 +294,14 @@ class Context:
     # ---- stages ----
     def hotpath_launch(self, dev_ptr, n, params, stride=32, rgb_offset=16):
         self._check(self.lib.pcc_hotpath_launch(self.h, dev_ptr, n, stride, rgb_offset, C.byref(params)))
+
+    def hotpath_launch_host(self, points: np.ndarray, params, lane=None, stride=None, rgb_offset=16):
+        """The frame is in host memory (a numpy array): asynchronous upload, then the kernels.  Keep `points` alive
+        and untouched until hotpath_finish has returned."""
+        pts = np.ascontiguousarray(points)
+        stride = stride or pts.dtype.itemsize
+        self._check(self.lib.pcc_hotpath_launch_host(self.h, lane, pts.ctypes.data, len(pts), stride, rgb_offset, C.byref(params)))
+        self._host_frame = pts
 
     def hotpath_finish(self, copy=True):
         hr = HotResult()
@@ -423,6 +443,24 @@ class Context:
         self._check(self.lib.pcc_get_kernel_times(self.h, C.byref(kt)))
         return [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
 
+    def kernel_spans(self):
+        """[(kernel, ms)] of the last profiled frame, measured on the GPU's own clock (first workgroup start to last wave end)."""
+        kt = KernelTimes()
+        self._check(self.lib.pcc_get_kernel_spans(self.h, C.byref(kt)))
+        return [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
+
+
+def pinned_array(lib, template: np.ndarray):
+    """A copy of `template` in page-locked host memory (pcc_host_alloc); free with lib.pcc_host_free(arr.ctypes.data)."""
+    nbytes = template.nbytes
+    ptr = lib.pcc_host_alloc(nbytes)
+    if not ptr:
+        raise MemoryError("pcc_host_alloc(%d)" % nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=template.dtype, count=len(template))
+    arr[:] = template
+    return arr
+
 
 class _BorrowedContext(Context):
     """A pcc_ctx owned by a pipeline (never destroyed from here)."""
@@ -472,6 +510,18 @@ class Pipeline:
         k, fr, cn = self._arrays(dev_frames, counts)
         out = (Bitstream * k)()
         rc = self.lib.pcc_pipeline_encode(self.h, fr, cn, k, stride, rgb_offset, C.byref(params), out)
+        if rc != PCC_OK:
+            raise PccError(rc, self.lib.pcc_pipeline_last_error(self.h).decode())
+        return [((_bytes_at(b.data, b.len) if copy else b.len), [int(x) for x in b.perf]) for b in out]
+
+    def encode_host(self, host_frames, params, stride=32, rgb_offset=16, copy=True):
+        """Like encode(), with the frames in host memory (numpy arrays of POINT_DTYPE, pageable or pinned)."""
+        frames = [np.ascontiguousarray(f) for f in host_frames]
+        k = len(frames)
+        fr = (C.c_void_p * k)(*[f.ctypes.data for f in frames])
+        cn = (C.c_size_t * k)(*[len(f) for f in frames])
+        out = (Bitstream * k)()
+        rc = self.lib.pcc_pipeline_encode_host(self.h, fr, cn, k, stride, rgb_offset, C.byref(params), out)
         if rc != PCC_OK:
             raise PccError(rc, self.lib.pcc_pipeline_last_error(self.h).decode())
         return [((_bytes_at(b.data, b.len) if copy else b.len), [int(x) for x in b.perf]) for b in out]

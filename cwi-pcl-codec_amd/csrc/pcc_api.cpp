@@ -9,6 +9,8 @@
 #include <time.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -74,14 +76,23 @@ struct pcc_ctx {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_wait = nullptr;  // blocking-sync event: a host thread that waits for the GPU sleeps instead of
                                  // spinning, so its core is free for the entropy stage of another frame
+  hipEvent_t ev_h2d = nullptr;   // the frame's points have arrived (recorded on an upload lane's stream)
+  const void* locked_host = nullptr;  // host range page-locked for the frame in flight (released by pcc_hotpath_finish)
   std::string err;
   bool profiling = false;
   KernelTimer timer;
   std::vector<std::pair<const char*, float>> times;
+  // device-side launch spans (first workgroup start .. last wave end on the GPU's real-time clock), profiling only
+  DevBuf<unsigned long long> d_spans;
+  PinnedBuf<unsigned long long> h_spans;
+  std::vector<const char*> span_names;
+  std::vector<std::pair<const char*, float>> span_times;
+  double wall_clock_khz = 100000.0;
 
   // HBM arena (see pcc_device.h for the layout)
   DevBuf<uint8_t> d_points;  // only for the host-input entry point
-  DevBuf<ChunkBox> d_boxes;
+  DevBuf<uint64_t> d_boxes;   // eight self-describing words per chunk (k_boxes_events)
+  uint32_t frame_seq = 0;     // sequence number of the last enqueued frame; stamps its chunk boxes
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
   DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
@@ -173,7 +184,10 @@ size_t tiles_region(size_t n) { return ((n / 256 + 1 + 15) / 16) * (size_t)kJpeg
 int reserve(pcc_ctx* ctx, size_t n) {
   const size_t tiles = (n + kTile - 1) / kTile;
   const size_t stiles = (n + kSortTile - 1) / kSortTile;
-  PCC_HIP(ctx->d_boxes.ensure(tiles));
+  if (ctx->d_boxes.cap < 8 * tiles) {  // a fresh array must not hold anything that looks like a chunk box of a coming frame
+    PCC_HIP(ctx->d_boxes.ensure(8 * tiles));
+    PCC_HIP(hipMemsetAsync(ctx->d_boxes.p, 0, ctx->d_boxes.cap * sizeof(uint64_t), ctx->stream));
+  }
   PCC_HIP(ctx->d_state.ensure(1));
   PCC_HIP(ctx->d_keys_a.ensure(n));
   PCC_HIP(ctx->d_keys_b.ensure(n));
@@ -247,16 +261,81 @@ int wait_stream(pcc_ctx* ctx, int site = 2) {
 
 // the kernel sequence of one frame + the FrameState read-back, all asynchronous on the context's stream
 int enqueue(pcc_ctx* ctx) {
+  if (++ctx->frame_seq == 0) ctx->frame_seq = 1;
+  ctx->args.frame_seq = ctx->frame_seq;
+  ctx->args.spans = nullptr;
+  ctx->args.span_names = nullptr;
+  if (ctx->profiling) {
+    PCC_HIP(ctx->d_spans.ensure(kSpanWords));
+    PCC_HIP(ctx->h_spans.ensure(kSpanWords));
+    PCC_HIP(hipMemsetAsync(ctx->d_spans.p, 0xFF, kSpanWords * sizeof(unsigned long long), ctx->stream));
+    ctx->span_names.clear();
+    ctx->args.spans = ctx->d_spans.p;
+    ctx->args.span_names = &ctx->span_names;
+  }
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
   if (ctx->profiling) ctx->timer.reset(); else ctx->times.clear();
   launch_hot_path(ctx->args, ctx->stream, ctx->profiling ? &ctx->timer : nullptr);
-  PCC_HIP(hipGetLastError());
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
+  }
   PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
   PCC_HIP(hipMemcpyAsync(ctx->h_state.p, ctx->d_state.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->profiling)
+    PCC_HIP(hipMemcpyAsync(ctx->h_spans.p, ctx->d_spans.p, kSpanWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   return PCC_OK;
 }
 
+// ---- host ranges page-locked on behalf of frames in flight ----
+// A frame that arrives in ordinary (pageable) host memory is page-locked for the time of its upload, so that the
+// copy is an asynchronous DMA at PCIe speed (hipHostRegister of 32 MB: 0.075 ms, tools/ubench/h2d.cpp; an upload from
+// pageable memory blocks the calling thread for the 0.6 ms it takes).  The same buffer may be in flight on several
+// contexts at once (a sequence that repeats its frames), hence the reference counts.
+struct LockedRange { size_t bytes; int refs; };
+std::mutex g_lock_mu;
+std::map<const void*, LockedRange> g_locked;
+
+// 0: the range is (now) page-locked and must be released with unlock_host_range; 1: it was page-locked by the caller;
+// 2: could not be locked (the copy goes the pageable way)
+int lock_host_range(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_lock_mu);
+  auto it = g_locked.find(p);
+  if (it != g_locked.end()) {
+    if (bytes > it->second.bytes) return 2;
+    ++it->second.refs;
+    return 0;
+  }
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost) return 1;
+  (void)hipGetLastError();  // an unknown pointer is reported as an error
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return 2;
+  }
+  g_locked[p] = LockedRange{bytes, 1};
+  return 0;
+}
+void unlock_host_range(const void* p) {
+  std::lock_guard<std::mutex> lk(g_lock_mu);
+  auto it = g_locked.find(p);
+  if (it == g_locked.end()) return;
+  if (--it->second.refs == 0) {
+    (void)hipHostUnregister(const_cast<void*>(p));
+    g_locked.erase(it);
+  }
+}
+
 }  // namespace
+
+// One stream that carries the host-to-device copies of a GPU, one after the other: copies issued side by side on
+// several streams share the link and finish later in total (51 GB/s with eight in flight against 56 GB/s one at a
+// time, tools/ubench/h2d.cpp), and a frame's kernels should start when ITS points are there, not when everybody's are.
+struct pcc_upload_lane {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+};
 
 extern "C" {
 
@@ -268,9 +347,14 @@ pcc_ctx* pcc_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   pcc_ctx* c = new pcc_ctx();
   c->device = device;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -294,7 +378,8 @@ void pcc_destroy(pcc_ctx* c) {
     fprintf(stderr, "[pcc_ctx %p] usual waits: kernels %.0f us, copies %.0f us, other %.0f us\n", (void*)c, c->usual_wait_ns[0] / 1e3,
             c->usual_wait_ns[1] / 1e3, c->usual_wait_ns[2] / 1e3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->d_points.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
+  if (c->locked_host) { unlock_host_range(c->locked_host); c->locked_host = nullptr; }
+  c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
@@ -310,6 +395,7 @@ void pcc_destroy(pcc_ctx* c) {
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
+  if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -336,6 +422,16 @@ int pcc_get_kernel_times(pcc_ctx* ctx, pcc_kernel_times* out) {
   for (int i = 0; i < out->count; ++i) {
     out->name[i] = ctx->times[i].first;
     out->ms[i] = ctx->times[i].second;
+  }
+  return PCC_OK;
+}
+
+int pcc_get_kernel_spans(pcc_ctx* ctx, pcc_kernel_times* out) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  out->count = (int32_t)std::min(ctx->span_times.size(), (size_t)PCC_MAX_KERNEL_TIMES);
+  for (int i = 0; i < out->count; ++i) {
+    out->name[i] = ctx->span_times[i].first;
+    out->ms[i] = ctx->span_times[i].second;
   }
   return PCC_OK;
 }
@@ -445,6 +541,66 @@ int pcc_hotpath_launch(pcc_ctx* ctx, const void* dev_points, size_t n, size_t st
   return launch_frame(ctx, dev_points, n, stride, rgb_offset, prm, nullptr, 0, 0);
 }
 
+pcc_upload_lane* pcc_upload_lane_create(int device) {
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  pcc_upload_lane* l = new pcc_upload_lane();
+  l->device = device;
+  if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete l;
+    return nullptr;
+  }
+  return l;
+}
+void pcc_upload_lane_destroy(pcc_upload_lane* l) {
+  if (!l) return;
+  (void)hipSetDevice(l->device);
+  (void)hipStreamSynchronize(l->stream);
+  (void)hipStreamDestroy(l->stream);
+  delete l;
+}
+
+void* pcc_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void pcc_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int pcc_hotpath_launch_host(pcc_ctx* ctx, pcc_upload_lane* lane, const void* host_points, size_t n, size_t stride, size_t rgb_offset,
+                            const pcc_params* prm) {
+  if (!ctx || !prm) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  if (n && !host_points) return fail(ctx, PCC_ERR_ARG, "null point array");
+  if (lane && lane->device != ctx->device) return fail(ctx, PCC_ERR_ARG, "upload lane and context belong to different GPUs");
+  if (n == 0) return launch_frame(ctx, nullptr, 0, stride, rgb_offset, prm, nullptr, 0, 0);
+  PCC_HIP(hipSetDevice(ctx->device));
+  const size_t bytes = n * stride;
+  PCC_HIP(ctx->d_points.ensure(bytes + 16));
+  if (ctx->locked_host) { unlock_host_range(ctx->locked_host); ctx->locked_host = nullptr; }  // a frame that was never finished
+  if (lock_host_range(host_points, bytes) == 0) ctx->locked_host = host_points;
+  hipError_t e;
+  if (lane) {
+    std::lock_guard<std::mutex> lk(lane->mu);
+    e = hipMemcpyAsync(ctx->d_points.p, host_points, bytes, hipMemcpyHostToDevice, lane->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_h2d, lane->stream);
+  } else {
+    e = hipMemcpyAsync(ctx->d_points.p, host_points, bytes, hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e == hipSuccess && lane) e = hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0);
+  int rc = e == hipSuccess ? launch_frame(ctx, ctx->d_points.p, n, stride, rgb_offset, prm, nullptr, 0, 0) : hip_fail(ctx, e, "upload of the frame");
+  if (rc != PCC_OK && ctx->locked_host) {
+    (void)hipStreamSynchronize(lane ? lane->stream : ctx->stream);
+    unlock_host_range(ctx->locked_host);
+    ctx->locked_host = nullptr;
+  }
+  return rc;
+}
+
 // wait for the frame's kernels and its FrameState; a frame that needs more sort passes than were enqueued runs again
 static int wait_frame_state(pcc_ctx* ctx) {
   { const int wrc = wait_stream(ctx, 0); if (wrc != PCC_OK) return wrc; }
@@ -456,14 +612,24 @@ static int wait_frame_state(pcc_ctx* ctx) {
     if (rc != PCC_OK) return rc;
     { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   }
-  if (st.n_epochs != 0 && st.error == kErrNone) ctx->pass_hint = st.npasses;
-  if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
+  if (st.error == kErrSpin) {
+    // A bounded poll ran out: a workgroup this frame waited for was held up for tens of milliseconds (another process
+    // on the GPU, a debugger).  Nothing is wrong with the frame: run it once more before giving up.
+    const int rc = enqueue(ctx);
+    if (rc != PCC_OK) return rc;
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    if (st.error == kErrSpin) {
+      return fail(ctx, PCC_ERR_HIP, "the GPU did not make progress on this frame (look-back poll timed out twice)");
+    }
+  }
   if (st.error != kErrNone) {
     char buf[160];
     snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
              st.error, st.depth, kMaxDepth, st.vbits);
     return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
   }
+  if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
+  ctx->pass_hint = st.npasses;
   return PCC_OK;
 }
 
@@ -500,11 +666,29 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   if (ctx->n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
   PCC_HIP(hipSetDevice(ctx->device));
   const int src = wait_frame_state(ctx);
+  if (ctx->locked_host) {  // the upload was over before the first kernel started
+    unlock_host_range(ctx->locked_host);
+    ctx->locked_host = nullptr;
+  }
   const FrameState& st = *ctx->h_state.p;
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end);
   out->gpu_ms = ms;
-  if (ctx->profiling) ctx->timer.collect(ctx->times);
+  if (ctx->profiling) {
+    ctx->timer.collect(ctx->times);
+    ctx->span_times.clear();
+    int sort_seen = 0;
+    for (size_t i = 0; i < ctx->span_names.size() && i < (size_t)kMaxSpans; ++i) {
+      const unsigned long long* w = ctx->h_spans.p + i * 2 * kSpanShards;
+      unsigned long long t0 = ~0ull, e1 = ~0ull;
+      for (int k = 0; k < kSpanShards; ++k) { t0 = std::min(t0, w[k]); e1 = std::min(e1, w[kSpanShards + k]); }
+      const unsigned long long t1 = ~e1;
+      const bool is_sort = !strcmp(ctx->span_names[i], "k_sort_pass");
+      if (is_sort && ++sort_seen > st.npasses) continue;  // enqueued, but the frame did not need the pass
+      if (t0 == ~0ull || t1 < t0) continue;
+      ctx->span_times.emplace_back(ctx->span_names[i], (float)((double)(t1 - t0) / ctx->wall_clock_khz));
+    }
+  }
   if (src != PCC_OK) return src;
   const size_t L = st.n_leaves, B = st.n_branches;
   const pcc_params& prm = ctx->params;

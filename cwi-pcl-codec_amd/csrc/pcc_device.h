@@ -79,7 +79,7 @@ struct FrameState {
   int32_t npasses;                   // radix passes actually needed (>= 1)
   int32_t pass_bits[kMaxPasses];     // digit width of each pass
   int32_t pass_shift[kMaxPasses];    // bit position of each digit inside the code (add ibits for the packed key)
-  int32_t passes_launched;           // what the host enqueued (k_bbox_events checks npasses against it)
+  int32_t passes_launched;           // what the host enqueued (k_boxes_events checks npasses against it)
   uint32_t prefix[3];                // constant high key bits per axis (in place)
   // ---- leaves ----
   uint32_t n_leaves;                 // L

@@ -63,7 +63,8 @@ struct HotPathArgs {
   int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
   FixedBox box;    // defineBoundingBox before addPointsFromInputCloud
   int stop_after_leaf_scan;  // macroblock trees: only the sorted points and the leaf (= block) arrays are wanted
-  ChunkBox* boxes;
+  uint64_t* boxes;     // eight {value, frame_seq} words per 2048-point chunk (zeroed when allocated)
+  uint32_t frame_seq;  // never 0, different from the frame before on this arena: tells this frame's chunk boxes from older ones
   FrameState* state;
   uint64_t* keys_a;
   uint64_t* keys_b;
@@ -72,7 +73,7 @@ struct HotPathArgs {
   uint32_t* hist_rows;  // [sort tiles][kMaxPasses][kMaxBins] digit counts from k_make_keys
   uint32_t* digit_tot;  // [kMaxPasses][kMaxBins]
   uint32_t* tile_prefix0;  // [sort tiles][kMaxBins] exclusive tile prefix of the pass-0 digit counts
-  uint8_t* sync_area;   // tickets | leaf scan status | sort status (sync_area_bytes), zeroed by k_chunk_boxes
+  uint8_t* sync_area;   // tickets | leaf scan status | sort status (sync_area_bytes), zeroed by k_boxes_events
   uint32_t* leaf_start;
   uint64_t* leaf_code;
   uint32_t* leaf_base;
@@ -86,7 +87,12 @@ struct HotPathArgs {
   JpegQuant jq;
   uint32_t* jpeg_tiles;          // per-MCU-row Huffman records (null: Huffman coding on the host)
   const JpegHuffTables* huff;    // device copy of the standard tables
+  std::vector<const char*>* span_names;  // profiling: kernel name of every span slot, in launch order (host side)
+  unsigned long long* spans;     // profiling: kMaxSpans x 2 x kSpanShards words {workgroup starts | ~(wave ends)} in launch order, preset to ~0 (null: off)
 };
+constexpr int kMaxSpans = 24;
+constexpr int kSpanShards = 256;
+constexpr size_t kSpanWords = (size_t)kMaxSpans * 2 * kSpanShards;
 
 // Optional per-kernel timing: one HIP event after every launch, on the launch stream.
 class KernelTimer {

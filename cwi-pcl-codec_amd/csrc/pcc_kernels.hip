@@ -2,7 +2,7 @@
 // hot path of the CWI point-cloud codec.  They replace, with breadth-first array passes,
 // what the reference does with a pointer octree:
 //
-//   P1/P2  addPointsFromInputCloud + adoptBoundingBoxToPoint   -> k_chunk_boxes, k_bbox_events
+//   P1/P2  addPointsFromInputCloud + adoptBoundingBoxToPoint   -> k_boxes_events (chunk boxes + growth replay in one launch)
 //   P3     genOctreeKeyforPoint                                -> k_make_keys
 //   P4     createLeafRecursive + addPointIndex                 -> LSD radix sort (k_make_keys histograms, k_digit_totals, k_sort_pass)
 //   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_scan + k_leaf_finalize
@@ -163,17 +163,66 @@ __device__ unsigned long long g_ktime[(7 + 2) * 1024 * 8];
 #endif
 #define PCC_KT(slot) PCC_KTR(pass, slot)
 
+// Optional device-side span of a launch: [earliest workgroup start, latest wave end] on the GPU's real-time clock.
+// HIP events between launches add a few microseconds to each short kernel; this is what a kernel trace reports.
+// A launch owns 2 x kSpanShards words, preset to ~0 and only ever lowered (ends are stored inverted); workgroups and
+// waves spread over the shards, so the recording itself does not queue thousands of atomics on one word (that
+// tripled the duration of the short kernels when tried).  The host takes the minimum of each half.  Null: nothing.
+struct KSpan {
+  unsigned long long* p;
+  __device__ explicit KSpan(unsigned long long* q) : p(q) {
+    if (p && threadIdx.x == 0) atomicMin(p + (blockIdx.x % kSpanShards), wall_clock64());
+  }
+  __device__ ~KSpan() {
+    if (p && (threadIdx.x & 63u) == 0u)
+      atomicMin(p + kSpanShards + ((blockIdx.x * 16u + (threadIdx.x >> 6)) % kSpanShards), ~wall_clock64());
+  }
+};
+
 // ------------------------------------------------------------------------------------------
-// Stage 0: per-chunk bounding boxes (first read of the cloud: 16 of every 32 bytes per point)
+// Stage 0 + 1 in ONE launch: per-chunk bounding boxes (first read of the cloud: 16 of every 32 bytes per point)
+// by workgroups 1..n_chunks, and the adaptive bounding box (P2) -- sequential and order dependent by
+// definition -- by workgroup 0, which
+//   * replays the growth events of chunk 0 straight away (with points in random order the box reaches its
+//     final size within the first few points), while the other workgroups stream the cloud;
+//   * then collects the chunk boxes as they appear, skips every chunk whose box fits the current bounding box
+//     (all of them, usually), and writes the epoch table and the sort plan.
+// Workgroup 0 waits for workgroups that never wait themselves, so the launch makes progress in whatever
+// order the workgroups are dispatched.  Hand-off: a chunk box is eight self-describing 8-byte words
+// {value, frame sequence number}, each written by one agent-scope store and read by one agent-scope load
+// (cdna_hip_programming.md guideline 16, form R2: no fence, no flag, the writer does not wait for anything).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_chunk_boxes(PointView pv, uint32_t n, ChunkBox* __restrict__ boxes,
-                                                        uint4* __restrict__ sync_area, uint32_t sync_vec16) {
-  __shared__ float s_mn[3][kBlock / 64], s_mx[3][kBlock / 64];
-  __shared__ int s_first[kBlock / 64], s_cnt[kBlock / 64];
+constexpr int kBoxWords = 8;  // mn xyz, mx xyz, first finite index, finite count
+
+__device__ __forceinline__ void publish_box(uint64_t* dst, const ChunkBox& b, uint32_t seq) {
+  uint32_t v[kBoxWords];
+  __builtin_memcpy(v, &b, sizeof(b));
+#pragma unroll
+  for (int k = 0; k < kBoxWords; ++k) publish_u64(dst + k, ((uint64_t)seq << 32) | v[k]);
+}
+__device__ __forceinline__ bool fetch_box(const uint64_t* src, uint32_t seq, ChunkBox& b) {
+  uint32_t v[kBoxWords];
+  bool all = true;
+#pragma unroll
+  for (int k = 0; k < kBoxWords; ++k) {
+    const uint64_t w = poll_u64(src + k);
+    all &= (uint32_t)(w >> 32) == seq;
+    v[k] = (uint32_t)w;
+  }
+  __builtin_memcpy(&b, v, sizeof(b));
+  return all;
+}
+
+__device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n, uint32_t c, uint32_t n_chunks, uint64_t* __restrict__ boxes,
+                                                uint32_t seq, uint4* __restrict__ sync_area, uint32_t sync_vec16, float* s_f, int* s_i) {
+  float(*s_mn)[kBlock / 64] = reinterpret_cast<float(*)[kBlock / 64]>(s_f);
+  float(*s_mx)[kBlock / 64] = reinterpret_cast<float(*)[kBlock / 64]>(s_f + 3 * (kBlock / 64));
+  int* s_first = s_i;
+  int* s_cnt = s_i + kBlock / 64;
   // every word another workgroup polls later in this frame (tile tickets, look-back status) starts at zero
-  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < sync_vec16; k += gridDim.x * kBlock)
+  for (uint32_t k = c * kBlock + threadIdx.x; k < sync_vec16; k += n_chunks * kBlock)
     sync_area[k] = make_uint4(0, 0, 0, 0);
-  const uint32_t base = blockIdx.x * kTile;
+  const uint32_t base = c * kTile;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   int first = 0x7fffffff, cnt = 0;
 #pragma unroll
@@ -203,43 +252,29 @@ __global__ __launch_bounds__(kBlock) void k_chunk_boxes(PointView pv, uint32_t n
   __syncthreads();
   if (threadIdx.x == 0) {
     ChunkBox b;
-    int c = 0, f = 0x7fffffff;
+    int cc = 0, f = 0x7fffffff;
     for (int a = 0; a < 3; ++a) { b.mn[a] = FLT_MAX; b.mx[a] = -FLT_MAX; }
     for (int w = 0; w < kBlock / 64; ++w) {
       for (int a = 0; a < 3; ++a) { b.mn[a] = fminf(b.mn[a], s_mn[a][w]); b.mx[a] = fmaxf(b.mx[a], s_mx[a][w]); }
-      f = min(f, s_first[w]); c += s_cnt[w];
+      f = min(f, s_first[w]); cc += s_cnt[w];
     }
-    b.first_finite = c ? f : -1;
-    b.n_finite = c;
-    boxes[blockIdx.x] = b;
+    b.first_finite = cc ? f : -1;
+    b.n_finite = cc;
+    publish_box(boxes + (size_t)c * kBoxWords, b, seq);
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Stage 1: the adaptive bounding box (P2) -- sequential and order dependent by definition.
-// One workgroup walks the cloud in order, but skips every chunk whose AABB already fits the
-// current box, so only chunks that contain a growth event are ever re-read (typically one).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int block_min_int(int v, int* s_red) {
-  if (threadIdx.x == 0) *s_red = 0x7fffffff;
-  __syncthreads();
-  v = wave_min_i(v);
-  if (lane_id() == 0 && v != 0x7fffffff) atomicMin(s_red, v);
-  __syncthreads();
-  const int r = *s_red;
-  __syncthreads();
-  return r;
-}
-
-__global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n, uint32_t n_chunks,
-                                                        const ChunkBox* __restrict__ boxes, double res,
-                                                        int force_pairs, int passes_launched, int do_color, FixedBox box,
-                                                        FrameState* __restrict__ st) {
-  __shared__ float s_p[3][kTile];
-  __shared__ int s_red;
-  __shared__ int s_red2[2][kBlock / 64];
-  __shared__ double s_mn[3], s_mx[3];
-  __shared__ int s_depth;
+__global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
+                                                         uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
+                                                         int force_pairs, int passes_launched, int do_color, FixedBox box,
+                                                         FrameState* __restrict__ st, unsigned long long* span) {
+  const KSpan kspan(span);
+  __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction
+  __shared__ int s_redi[2][kBlock / 64];
+  if (blockIdx.x != 0) {
+    chunk_box_block(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0]);
+    return;
+  }
   __shared__ int ev_index[kMaxEpochs], ev_lowered[kMaxEpochs], ev_depth_before[kMaxEpochs];
   __shared__ double ev_mn[kMaxEpochs][3];
   __shared__ float s_g[6][kBlock / 64];
@@ -247,46 +282,51 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
 
   PCC_KTR(6, 0);
   const double eps = (double)FLT_EPSILON;  // PCL: const float minValue = numeric_limits<float>::epsilon()
+  int parity = 0;
+  // one barrier per reduction; the result buffers alternate so that a fast wave cannot overwrite a pending read
+  auto block_min1 = [&](int v) {
+    v = wave_min_i(v);
+    if (lane_id() == 0) s_redi[parity][wave_id()] = v;
+    __syncthreads();
+    const int r = min(min(s_redi[parity][0], s_redi[parity][1]), min(s_redi[parity][2], s_redi[parity][3]));
+    parity ^= 1;
+    return r;
+  };
 
-  // ---- A: first finite point, finite count, global AABB (from the chunk boxes) ----
-  int first = 0x7fffffff;
-  unsigned nfin = 0;
-  float g[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (uint32_t c = threadIdx.x; c < n_chunks; c += kBlock) {
-    const ChunkBox b = boxes[c];
-    if (b.n_finite > 0) {
-      first = min(first, b.first_finite);
-      nfin += (unsigned)b.n_finite;
-      for (int a = 0; a < 3; ++a) { g[a] = fminf(g[a], b.mn[a]); g[3 + a] = fmaxf(g[3 + a], b.mx[a]); }
+  // the bounding box, replayed identically by every thread in registers: a growth event costs one barrier.
+  // Points and chunk boxes are floats: p < mn  <=>  p < RU(mn) and p >= mx  <=>  p >= RU(mx) with RU = the double
+  // rounded up to float, so the tests run on floats and give what PCL's double comparisons give.
+  double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  float fmn[3] = {0, 0, 0}, fmx[3] = {0, 0, 0};
+  int depth = 0, nev = 0, err = kErrNone;
+  bool have_box = false;
+  int i0 = 0x7fffffff, cur = 0, loaded = -1;
+  auto float_bounds = [&]() {
+    for (int a = 0; a < 3; ++a) { fmn[a] = __double2float_ru(mn[a]); fmx[a] = __double2float_ru(mx[a]); }
+  };
+  auto violates = [&](float x, float y, float z) {
+    return (x < fmn[0]) | (y < fmn[1]) | (z < fmn[2]) | (x >= fmx[0]) | (y >= fmx[1]) | (z >= fmx[2]);
+  };
+
+  auto load_chunk = [&](int c) {  // into LDS; NaN never violates: non-finite points are skipped
+    __syncthreads();              // nobody reads the chunk before any more
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int e = k * kBlock + (int)threadIdx.x;
+      const uint32_t i = (uint32_t)c * kTile + (uint32_t)e;
+      float x = __builtin_nanf(""), y = x, z = x;
+      if (i < n) {
+        load_xyz(pv, i, x, y, z);
+        if (!finite3(x, y, z)) { x = y = z = __builtin_nanf(""); }
+      }
+      s_p[0][e] = x; s_p[1][e] = y; s_p[2][e] = z;
     }
-  }
-  if (threadIdx.x == 0) s_nfin = 0;
-  st->occ_hist[threadIdx.x] = 0u;  // kBlock = 256 threads: one counter each (filled by k_occ_histogram at the end of the frame)
-  const int i0 = block_min_int(first, &s_red);
-  nfin = (unsigned)wave_sum_u64(nfin);
-  for (int a = 0; a < 3; ++a) { g[a] = wave_min_f(g[a]); g[3 + a] = wave_max_f(g[3 + a]); }
-  if (lane_id() == 0) {
-    atomicAdd(&s_nfin, nfin);
-    for (int a = 0; a < 6; ++a) s_g[a][wave_id()] = g[a];
-  }
-  __syncthreads();
-
-  if (i0 == 0x7fffffff) {  // no finite point: the reference drops the frame (impl.hpp:206-212)
-    if (threadIdx.x == 0) {
-      st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
-      st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-      st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0;
-      st->passes_launched = passes_launched;
-    }
-    return;
-  }
-
-  PCC_KTR(6, 1);
-  // ---- B: box from the first point (adoptBoundingBoxToPoint, empty-tree branch + getKeyBitSize) ----
-  if (threadIdx.x == 0) {
-    float p[3];
-    load_xyz(pv, (uint32_t)i0, p[0], p[1], p[2]);
-    double mn[3], mx[3];
+    loaded = c;
+    __syncthreads();
+  };
+  // adoptBoundingBoxToPoint, empty-tree branch + getKeyBitSize: the box around the first finite point
+  auto first_box = [&](float fx, float fy, float fz, int index) {
+    const float p[3] = {fx, fy, fz};
     for (int a = 0; a < 3; ++a) {
       mn[a] = __dsub_rn((double)p[a], __ddiv_rn(res, 2.0));
       mx[a] = __dadd_rn((double)p[a], __ddiv_rn(res, 2.0));
@@ -297,188 +337,257 @@ __global__ __launch_bounds__(kBlock) void k_bbox_events(PointView pv, uint32_t n
       const unsigned k = (unsigned)ceil(__ddiv_rn(__dsub_rn(__dsub_rn(mx[a], mn[a]), eps), res));
       max_voxels = max(max_voxels, k);
     }
-    int depth = (int)ceil(__dsub_rn(log2((double)max_voxels), eps));
+    depth = (int)ceil(__dsub_rn(log2((double)max_voxels), eps));
     depth = min(depth, 32);
     const double side = __dmul_rn((double)(1u << depth), res);
     for (int a = 0; a < 3; ++a) {
       const double over = __ddiv_rn(__dsub_rn(side, __dsub_rn(mx[a], mn[a])), 2.0);
       if (over > eps) { mn[a] = __dsub_rn(mn[a], over); mx[a] = __dadd_rn(mx[a], over); }
     }
-    for (int a = 0; a < 3; ++a) { s_mn[a] = mn[a]; s_mx[a] = mx[a]; ev_mn[0][a] = mn[a]; }
-    s_depth = depth;
-    ev_index[0] = i0; ev_lowered[0] = 0; ev_depth_before[0] = 0;
-  }
-  __syncthreads();
-
-  PCC_KTR(6, 2);
-  // ---- C: walk forward; only chunks whose AABB violates the current box are opened ----
-  // Every thread keeps the same copy of the box in registers and replays the growth itself, so one
-  // growth event costs a single barrier (the one inside the block-wide minimum).
-  double mn[3] = {s_mn[0], s_mn[1], s_mn[2]}, mx[3] = {s_mx[0], s_mx[1], s_mx[2]};
-  int depth = s_depth, nev = 1, err = kErrNone;
-  int cur = box.enabled ? i0 : i0 + 1, loaded = -1, parity = 0;  // a given box has to be checked against the first point too
-  float px[kItems], py[kItems], pz[kItems];
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) px[k] = py[k] = pz[k] = __builtin_nanf("");
-  auto block_min1 = [&](int v) {  // one barrier; the result buffers alternate so that a fast wave cannot overwrite a pending read
-    v = wave_min_i(v);
-    if (lane_id() == 0) s_red2[parity][wave_id()] = v;
-    __syncthreads();
-    const int r = min(min(s_red2[parity][0], s_red2[parity][1]), min(s_red2[parity][2], s_red2[parity][3]));
-    parity ^= 1;
-    return r;
+    float_bounds();
+    if (threadIdx.x == 0) {
+      for (int a = 0; a < 3; ++a) ev_mn[0][a] = mn[a];
+      ev_index[0] = index; ev_lowered[0] = 0; ev_depth_before[0] = 0;
+    }
+    nev = 1;
+    have_box = true;
+    i0 = index;
+    cur = box.enabled ? index : index + 1;  // a given box has to be checked against the first point too
   };
+  // all growth events of the loaded chunk from `cur` on (adoptBoundingBoxToPoint, bounding_box_defined_ branch)
+#ifdef PCC_KTIME
+  int dbg_round = 0;
+#endif
+  auto replay_loaded_chunk = [&]() {
+    while (err == kErrNone) {
+      const int start_e = max(cur - loaded * kTile, 0);
+      int ce = 0x7fffffff;
+#pragma unroll
+      for (int k = kItems - 1; k >= 0; --k) {
+        const int e = k * kBlock + (int)threadIdx.x;
+        if (e >= start_e && violates(s_p[0][e], s_p[1][e], s_p[2][e])) ce = e;
+      }
+      const int emin = block_min1(ce);
+#ifdef PCC_KTIME
+      if (dbg_round < 8) { PCC_KTR(8, dbg_round); ++dbg_round; }
+#endif
+      if (emin == 0x7fffffff) {  // nothing (left) in this chunk: go on with the chunks behind it
+        cur = (loaded + 1) * kTile;
+        return;
+      }
+      const double p[3] = {(double)s_p[0][emin], (double)s_p[1][emin], (double)s_p[2][emin]};
+      for (;;) {
+        bool up[3], any = false;
+        for (int a = 0; a < 3; ++a) { up[a] = p[a] >= mx[a]; any |= (p[a] < mn[a]) | up[a]; }
+        if (!any) break;
+        if (nev >= kMaxEpochs || depth >= 31) { err = kErrEpochs; break; }
+        double side = __dmul_rn((double)(1u << depth), res);
+        int lowered = 0;
+        for (int a = 0; a < 3; ++a)
+          if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
+        if (threadIdx.x == 0) {
+          ev_depth_before[nev] = depth;
+          ev_index[nev] = loaded * kTile + emin;
+          ev_lowered[nev] = lowered;
+          for (int a = 0; a < 3; ++a) ev_mn[nev][a] = mn[a];
+        }
+        ++depth;
+        side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
+        for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
+        ++nev;
+      }
+      float_bounds();
+      cur = loaded * kTile + emin + 1;
+    }
+  };
+
+  // ---- early: chunk 0, while the other workgroups read the cloud ----
+  load_chunk(0);
+  {
+    int ce = 0x7fffffff;
+#pragma unroll
+    for (int k = kItems - 1; k >= 0; --k) {
+      const int e = k * kBlock + (int)threadIdx.x;
+      const float x = s_p[0][e];
+      if (x == x) ce = e;
+    }
+    const int f = block_min1(ce);
+    PCC_KTR(6, 1);
+    if (f != 0x7fffffff) {
+      first_box(s_p[0][f], s_p[1][f], s_p[2][f], f);
+      replay_loaded_chunk();
+    }
+  }
+  PCC_KTR(6, 2);
+
+  // ---- A: the chunk boxes as they appear (workgroups 1..n_chunks never wait, so this terminates): first finite
+  //         point, finite count, global AABB; in the same sweep, the first chunk behind the loaded one whose box
+  //         does not fit the bounding box as it stands.  A thread takes its chunks in ascending order and comes back
+  //         to the first one that was not there yet.
+  if (threadIdx.x == 0) s_nfin = 0;
+  st->occ_hist[threadIdx.x] = 0u;  // kBlock = 256 threads: one counter each (filled by k_occ_histogram at the end of the frame)
+  int first = 0x7fffffff, cand = 0x7fffffff;
+  unsigned nfin = 0;
+  float g[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  auto box_violates = [&](const ChunkBox& b) { return violates(b.mn[0], b.mn[1], b.mn[2]) | violates(b.mx[0], b.mx[1], b.mx[2]); };
+  {
+    uint32_t c = threadIdx.x, spins = 0;
+    for (;;) {
+      while (c < n_chunks) {
+        ChunkBox b;
+        if (!fetch_box(boxes + (size_t)c * kBoxWords, seq, b)) break;
+        if (b.n_finite > 0) {
+          first = min(first, b.first_finite);
+          nfin += (unsigned)b.n_finite;
+          for (int a = 0; a < 3; ++a) { g[a] = fminf(g[a], b.mn[a]); g[3 + a] = fmaxf(g[3 + a], b.mx[a]); }
+          if (have_box && (int)c > loaded && cand == 0x7fffffff && box_violates(b)) cand = (int)c;  // ascending per thread
+        }
+        c += kBlock;
+      }
+      if (__syncthreads_and(c >= n_chunks)) break;
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > kSpinLimit) { err = kErrSpin; break; }  // uniform: every thread counts the same rounds
+    }
+  }
+  PCC_KTR(6, 3);
+  nfin = (unsigned)wave_sum_u64(nfin);
+  for (int a = 0; a < 3; ++a) { g[a] = wave_min_f(g[a]); g[3 + a] = wave_max_f(g[3 + a]); }
+  if (lane_id() == 0) {
+    atomicAdd(&s_nfin, nfin);
+    for (int a = 0; a < 6; ++a) s_g[a][wave_id()] = g[a];
+  }
+  int pending = block_min1(have_box ? cand : first);  // (its barrier also covers s_nfin and s_g)
+  bool pending_valid = have_box;
+  if (!have_box && err == kErrNone) {
+    if (pending == 0x7fffffff) {  // no finite point: the reference drops the frame (impl.hpp:206-212)
+      if (threadIdx.x == 0) {
+        st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
+        st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
+        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0;
+        st->passes_launched = passes_launched;
+      }
+      return;
+    }
+    float fx, fy, fz;  // chunk 0 held no finite point: the first one of the cloud comes from the chunk boxes
+    load_xyz(pv, (uint32_t)pending, fx, fy, fz);
+    first_box(fx, fy, fz, pending);
+  }
+  PCC_KTR(6, 4);
+
+  // ---- C: walk forward; only chunks whose AABB violates the current box are opened ----
   while (cur < (int)n && err == kErrNone) {
     const int c0 = cur / kTile;
     if (c0 != loaded) {
-      int cand = 0x7fffffff;
-      for (int c = c0 + (int)threadIdx.x; c < (int)n_chunks; c += kBlock) {
-        const ChunkBox b = boxes[c];
-        if (b.n_finite > 0) {
-          const bool viol = ((double)b.mn[0] < mn[0]) | ((double)b.mn[1] < mn[1]) | ((double)b.mn[2] < mn[2]) |
-                            ((double)b.mx[0] >= mx[0]) | ((double)b.mx[1] >= mx[1]) | ((double)b.mx[2] >= mx[2]);
-          if (viol) { cand = c; break; }  // ascending per thread: the first hit is this thread's minimum
+      int cmin;
+      if (pending_valid) {
+        cmin = pending;  // found during the sweep above, for exactly this box and this range of chunks
+      } else {
+        int cd = 0x7fffffff;
+        for (int c = c0 + (int)threadIdx.x; c < (int)n_chunks; c += kBlock) {
+          ChunkBox b;
+          (void)fetch_box(boxes + (size_t)c * kBoxWords, seq, b);  // all there since the sweep
+          if (b.n_finite > 0 && box_violates(b)) { cd = c; break; }  // ascending per thread: the first hit is this thread's minimum
         }
+        cmin = block_min1(cd);
       }
-      const int cmin = block_min1(cand);
       if (cmin == 0x7fffffff) break;  // everything that is left fits
-#pragma unroll
-      for (int k = 0; k < kItems; ++k) {
-        const int e = k * kBlock + (int)threadIdx.x;
-        const uint32_t i = (uint32_t)cmin * kTile + (uint32_t)e;
-        float x = __builtin_nanf(""), y = x, z = x;  // NaN never violates: non-finite points are skipped
-        if (i < n) {
-          load_xyz(pv, i, x, y, z);
-          if (!finite3(x, y, z)) { x = y = z = __builtin_nanf(""); }
-        }
-        px[k] = x; py[k] = y; pz[k] = z;
-        s_p[0][e] = x; s_p[1][e] = y; s_p[2][e] = z;  // read back (by everybody) once the first violator is known
-      }
-      loaded = cmin;
-      PCC_KTR(6, 3);
+      load_chunk(cmin);
+      cur = max(cur, cmin * kTile);
     }
-    const int start_e = max(cur - loaded * kTile, 0);
-    int ce = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-      const int e = k * kBlock + (int)threadIdx.x;
-      const double x = (double)px[k], y = (double)py[k], z = (double)pz[k];
-      const bool viol = (x < mn[0]) | (y < mn[1]) | (z < mn[2]) | (x >= mx[0]) | (y >= mx[1]) | (z >= mx[2]);
-      if (viol && e >= start_e && ce == 0x7fffffff) ce = e;
-    }
-    const int emin = block_min1(ce);  // the barrier inside also orders the s_p writes above
-    if (emin == 0x7fffffff) {  // nothing (left) in this chunk: go on with the chunks behind it
-      cur = (loaded + 1) * kTile;
-      continue;
-    }
-    // grow until the point fits (adoptBoundingBoxToPoint, bounding_box_defined_ branch)
-    const double p[3] = {(double)s_p[0][emin], (double)s_p[1][emin], (double)s_p[2][emin]};
-    for (;;) {
-      bool up[3], any = false;
-      for (int a = 0; a < 3; ++a) { up[a] = p[a] >= mx[a]; any |= (p[a] < mn[a]) | up[a]; }
-      if (!any) break;
-      if (nev >= kMaxEpochs || depth >= 31) { err = kErrEpochs; break; }
-      double side = __dmul_rn((double)(1u << depth), res);
-      int lowered = 0;
-      for (int a = 0; a < 3; ++a)
-        if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
-      if (threadIdx.x == 0) {
-        ev_depth_before[nev] = depth;
-        ev_index[nev] = loaded * kTile + emin;
-        ev_lowered[nev] = lowered;
-        for (int a = 0; a < 3; ++a) ev_mn[nev][a] = mn[a];
-      }
-      ++depth;
-      side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
-      for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
-      ++nev;
-    }
-    cur = loaded * kTile + emin + 1;
+    pending_valid = false;
+    replay_loaded_chunk();
   }
+  __syncthreads();  // ev_* complete
+  PCC_KTR(6, 5);
 
-  PCC_KTR(6, 4);
-  // ---- D: epoch table, sort geometry ----
-  if (threadIdx.x == 0) {
-    // an epoch = a run of point indices with one box origin; the key offset of an epoch is the sum of the
-    // re-rootings that came after it: walk the events backwards with a running sum
-    int ne = 0;
-    for (int k = 0; k < nev; ++k)
-      if (!(k + 1 < nev && ev_index[k + 1] == ev_index[k])) ++ne;  // the same point may grow the box several times
-    unsigned shift[3] = {0, 0, 0};
-    int w = ne;
-    for (int k = nev - 1; k >= 0; --k) {
-      if (!(k + 1 < nev && ev_index[k + 1] == ev_index[k])) {
-        --w;
-        st->ep_index[w] = ev_index[k];
-        for (int a = 0; a < 3; ++a) { st->ep_mn[w][a] = ev_mn[k][a]; st->ep_shift[w][a] = shift[a]; }
-      }
-      for (int a = 0; a < 3; ++a)
-        if (ev_lowered[k] & (1 << a)) shift[a] += 1u << ev_depth_before[k];
-    }
-    st->n_epochs = ne;
-    st->n_growth_events = nev - 1;
-    st->depth = depth;
-    st->first_finite = i0;
-    st->n_finite = s_nfin;
-    for (int a = 0; a < 3; ++a) { st->mn[a] = mn[a]; st->mx[a] = mx[a]; s_mn[a] = mn[a]; }
-    if (depth > kMaxDepth) err = kErrDepth;
-
-    // varying key bits from the global AABB under the final origin, +-1 voxel of slack
-    float gmin[3], gmax[3];
+  // ---- D: epoch table (one thread per growth event), sort geometry ----
+  // an epoch = a run of point indices with one box origin; the same point may grow the box several times, the last
+  // growth of such a run stands for the epoch.  The key offset of an epoch is the sum of the re-rootings that came
+  // after it.
+  if (wave_id() == 0) {
+    const int k = lane_id();  // kMaxEpochs <= 64
+    const bool live = k < nev;
+    const bool last_of_run = live && !(k + 1 < nev && ev_index[k + 1] == ev_index[k]);
+    const uint64_t runs = __ballot(last_of_run);
+    const int ne = __popcll(runs);
+    const int w = __popcll(runs & (k ? (~0ull >> (64 - k)) : 0ull));
+    uint32_t later[3];
     for (int a = 0; a < 3; ++a) {
-      gmin[a] = FLT_MAX; gmax[a] = -FLT_MAX;
-      for (int w = 0; w < kBlock / 64; ++w) { gmin[a] = fminf(gmin[a], s_g[a][w]); gmax[a] = fmaxf(gmax[a], s_g[3 + a][w]); }
+      const uint32_t add = (live && (ev_lowered[k] & (1 << a))) ? (1u << ev_depth_before[k]) : 0u;
+      const uint32_t incl = wave_incl_scan_u32(add);
+      later[a] = __shfl(incl, 63) - incl;  // growths after event k
     }
+    if (last_of_run) {
+      st->ep_index[w] = ev_index[k];
+      for (int a = 0; a < 3; ++a) { st->ep_mn[w][a] = ev_mn[k][a]; st->ep_shift[w][a] = later[a]; }
+    }
+    if (k == 0) {
+      st->n_epochs = ne;
+      st->n_growth_events = nev - 1;
+      st->depth = depth;
+      st->first_finite = i0;
+      st->n_finite = s_nfin;
+      for (int a = 0; a < 3; ++a) { st->mn[a] = mn[a]; st->mx[a] = mx[a]; }
+      st->passes_launched = passes_launched;
+      st->n_leaves = 0;
+      st->n_branches = 0;
+    }
+  } else if (wave_id() == 1) {
+    if (depth > kMaxDepth && err == kErrNone) err = kErrDepth;
+    // varying key bits from the global AABB under the final origin, +-1 voxel of slack
     int vb = 0;
-    unsigned kmin[3], kmax[3];
+    unsigned kmin[3];
     const unsigned klim = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u);
     for (int a = 0; a < 3; ++a) {
-      const double lo = __ddiv_rn(__dsub_rn((double)gmin[a], s_mn[a]), res);
-      const double hi = __ddiv_rn(__dsub_rn((double)gmax[a], s_mn[a]), res);
+      float gmin = FLT_MAX, gmax = -FLT_MAX;
+      for (int w = 0; w < kBlock / 64; ++w) { gmin = fminf(gmin, s_g[a][w]); gmax = fmaxf(gmax, s_g[3 + a][w]); }
+      const double lo = __ddiv_rn(__dsub_rn((double)gmin, mn[a]), res);
+      const double hi = __ddiv_rn(__dsub_rn((double)gmax, mn[a]), res);
       unsigned kl = lo > 0.0 ? (unsigned)lo : 0u;
       unsigned kh = hi > 0.0 ? (unsigned)hi : 0u;
       kl = kl > 0 ? kl - 1 : 0;
       kh = kh < klim ? kh + 1 : klim;
-      kmin[a] = kl; kmax[a] = kh;
+      kmin[a] = kl;
       const unsigned x = kl ^ kh;
       const int nb = x ? 32 - __clz((int)x) : 0;
       vb = max(vb, nb);
     }
-    for (int a = 0; a < 3; ++a) st->prefix[a] = vb >= 32 ? 0u : ((kmin[a] >> vb) << vb);
     int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
     // code + index in one u64 when they fit (8 B/key/pass); otherwise u64 code keys with a u32
     // index payload (12 B/key/pass).  The stable sort makes both orders identical.
     const int packed = (3 * vb + ibits <= 64 && !force_pairs) ? 1 : 0;
     if (!packed) ibits = 0;
-    st->vbits_axis = vb;
-    st->vbits = 3 * vb;
-    st->ibits = ibits;
-    st->packed = packed;
-    st->payload = packed ? (do_color ? 2 : 0) : 1;
     // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
     const int vbits = 3 * vb;
     int np = (vbits + kMaxDigitBits - 1) / kMaxDigitBits;
     if (np < 1) np = 1;
-    int sh = 0;
-    for (int p = 0; p < kMaxPasses; ++p) {
-      int b = 0;
-      if (p < np) {
-        b = vbits / np + (p < vbits % np ? 1 : 0);
-        if (b < 1) b = 1;
-      }
-      st->pass_bits[p] = b;
-      st->pass_shift[p] = sh;
-      sh += b;
-    }
-    st->passes_launched = passes_launched;
     if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
-    st->npasses = np;
-    if (err != kErrNone) st->npasses = 0;
-    st->error = err;
-    st->n_leaves = 0;
-    st->n_branches = 0;
+    const int p = lane_id();
+    if (p < kMaxPasses) {
+      int bits = 0, sh = 0;
+      for (int q = 0; q <= p; ++q) {
+        int bq = 0;
+        if (q < np) {
+          bq = vbits / np + (q < vbits % np ? 1 : 0);
+          if (bq < 1) bq = 1;
+        }
+        if (q < p) sh += bq; else bits = bq;
+      }
+      st->pass_bits[p] = bits;
+      st->pass_shift[p] = sh;
+    }
+    if (p == 8) {
+      for (int a = 0; a < 3; ++a) st->prefix[a] = vb >= 32 ? 0u : ((kmin[a] >> vb) << vb);
+      st->vbits_axis = vb;
+      st->vbits = vbits;
+      st->ibits = ibits;
+      st->packed = packed;
+      st->payload = packed ? (do_color ? 2 : 0) : 1;
+      st->npasses = err != kErrNone ? 0 : np;
+      st->error = err;
+    }
   }
-  PCC_KTR(6, 5);
+  PCC_KTR(6, 6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -491,7 +600,8 @@ constexpr uint64_t kInvalidKey = ~0ull;
 
 __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows) {
+                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows, unsigned long long* span) {
+  const KSpan kspan(span);
   __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
@@ -556,7 +666,8 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
 constexpr uint32_t kDtCols = 16, kDtGroups = 1024 / kDtCols;
 __global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
                                                        const uint32_t* __restrict__ hist_rows,
-                                                       uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0) {
+                                                       uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0, unsigned long long* span) {
+  const KSpan kspan(span);
   __shared__ uint32_t s_part[kDtGroups][kDtCols];
   const uint32_t c = threadIdx.x % kDtCols;
   const uint32_t col = blockIdx.x * kDtCols + c;
@@ -592,20 +703,23 @@ __global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restr
 // (tile, digit): flag | count), then scatters.  Tile ids come from a ticket counter, so a tile only
 // ever waits for tiles that have already started.  Passes beyond st->npasses return at once.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
                                                             uint64_t* out_a, uint64_t* out_b,
                                                             uint32_t* idx_a, uint32_t* idx_b, uint32_t n, int pass,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
                                                             const uint32_t* __restrict__ tile_prefix0,
                                                             uint32_t* status_all, uint32_t* tickets,
-                                                            uint32_t n_tiles_max) {
+                                                            uint32_t n_tiles_max, unsigned long long* span) {
+  const KSpan kspan(span);
   PCC_KT(0);
   if (pass >= st->npasses) return;
-  constexpr int NW = kSortThreads / 64;
+  constexpr int NW = THREADS / 64;
+  static_assert(THREADS * ITEMS == kSortTile && THREADS >= kMaxBins, "a tile is 4096 keys (the histogram rows of k_make_keys); one thread per digit");
   // s_raw is used twice: while ranking, one 64-bit lane mask per (wave, digit); afterwards the tile's
   // keys (and payload) in digit order, so that the global writes are runs
-  __shared__ __attribute__((aligned(16))) uint64_t s_raw[NW * kMaxBins];
-  static_assert(sizeof(uint64_t) * NW * kMaxBins >= (sizeof(uint64_t) + sizeof(uint32_t)) * kSortTile, "reorder buffers must fit");
+  constexpr int kRawWords = NW * kMaxBins > kSortTile * 3 / 2 ? NW * kMaxBins : kSortTile * 3 / 2;
+  __shared__ __attribute__((aligned(16))) uint64_t s_raw[kRawWords];
   uint64_t* s_match = s_raw;
   uint64_t* s_keys = s_raw;
   uint32_t* s_pay = reinterpret_cast<uint32_t*>(s_raw + kSortTile);
@@ -619,22 +733,29 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   const uint32_t count = pass == 0 ? n : st->n_finite;  // pass 0 still holds the non-finite markers
   const uint32_t out_count = st->n_finite;
   const uint32_t n_tiles = (count + kSortTile - 1) / kSortTile;
+  const int bits = st->pass_bits[pass];
+  const uint32_t nbins = 1u << bits, mask = nbins - 1u;
+  const uint32_t d_me = threadIdx.x;  // thread = digit in the per-digit steps
   // Tile id = a ticket: a tile only ever waits for lower tile ids, and those belong to workgroups that have
   // started.  (blockIdx would do only if the whole grid were co-resident; with several frames in flight on
   // other streams it is not, and workgroups are dispatched per XCD: a resident workgroup could then wait for
-  // one that cannot start because of workgroups waiting the other way round.)
-  const bool ticketed = true;
-  if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[pass], 1u);
-  for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += kSortThreads) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
-  for (int k = threadIdx.x; k < NW * kMaxBins; k += kSortThreads) s_match[k] = 0ull;
-  for (int k = threadIdx.x; k < kMaxBins; k += kSortThreads) s_hist[k] = 0u;
-  __syncthreads();
-  const uint32_t tile = ticketed ? s_tile : blockIdx.x;
+  // one that cannot start because of workgroups waiting the other way round.)  Pass 0 waits for nobody -- its
+  // tile prefixes come from k_digit_totals -- and keeps blockIdx.  The ticket, 245 workgroups queueing on one
+  // word, takes a microsecond or two to come back: the digit totals are fetched meanwhile.
+  uint32_t ticket = blockIdx.x;
+  if (pass != 0 && threadIdx.x == 0) ticket = atomicAdd(&tickets[pass], 1u);
+  const uint32_t dtot = d_me < nbins ? digit_tot[(size_t)pass * kMaxBins + d_me] : 0u;
+  for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
+  for (int k = threadIdx.x; k < NW * kMaxBins; k += THREADS) s_match[k] = 0ull;
+  for (int k = threadIdx.x; k < kMaxBins; k += THREADS) s_hist[k] = 0u;
+  if (threadIdx.x == 0) s_tile = ticket;
+  // global start of every digit = exclusive scan of the digit totals (its barriers also cover the LDS set up above)
+  uint32_t gsum;
+  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
+  const uint32_t tile = s_tile;
   PCC_KT(1);
   if (tile >= n_tiles) return;
 
-  const int bits = st->pass_bits[pass];
-  const uint32_t nbins = 1u << bits, mask = nbins - 1u;
   const bool with_payload = st->payload != 0;
   const int shift = st->ibits + st->pass_shift[pass];
   const uint64_t* in = (pass & 1) ? buf_b : buf_a;  // ping-pong: pass 0 reads a writes b
@@ -648,16 +769,15 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
   const uint32_t g = tile / kLookBackGroup, q = tile % kLookBackGroup;
   const bool closes_group = q == kLookBackGroup - 1;
-  const uint32_t d_me = threadIdx.x;  // thread = digit in the per-digit steps
   uint32_t spins = 0;
 
   // Tile order = (wave, round, lane): every wave owns consecutive keys, read as rows of 64.
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
-  uint64_t key[kSortItems];
-  uint32_t pay[kSortItems];
-  uint16_t lrank[kSortItems];
+  uint64_t key[ITEMS];
+  uint32_t pay[ITEMS];
+  uint16_t lrank[ITEMS];
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
     key[r] = i < count ? in[i] : kInvalidKey;
     pay[r] = (with_payload && i < count) ? pay_in[i] : 0u;
@@ -666,7 +786,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   // (the digit of the row's first key is counted with one ballot: the most significant digit of a clustered
   // cloud has few values, and 64 lanes adding to one LDS word would serialise)
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const bool valid = key[r] != kInvalidKey;
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
     const uint64_t vm = __ballot(valid);
@@ -678,10 +798,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
       else if (valid && d != d0) atomicAdd(&s_hist[d], 1u);
     }
   }
-  // global start of every digit = exclusive scan of the digit totals (its barriers also cover s_hist)
-  uint32_t gsum;
-  const uint32_t dtot = d_me < nbins ? digit_tot[(size_t)pass * kMaxBins + d_me] : 0u;
-  const uint32_t gbase = block_excl_scan<NW, uint32_t>(dtot, s_scan, gsum);
+  __syncthreads();
   const uint32_t run = d_me < nbins ? s_hist[d_me] : 0u;
   if (pass != 0 && d_me < nbins) publish_u32(status + (size_t)tile * kMaxBins + d_me, kStatusAggregate | run);
   uint32_t tile_valid;
@@ -738,7 +855,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   // the wave's digit counter (LDS operations of one wave execute in program order, so no barrier is needed).
   uint64_t* wmatch = s_match + (size_t)wave * kMaxBins;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const bool valid = key[r] != kInvalidKey;
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
     // the peers of the row's first key come from one ballot (see the histogram above), the others through LDS
@@ -834,7 +951,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   PCC_KT(7);
   // keys into digit order in LDS ...
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     if (key[r] != kInvalidKey) {
       const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
       const uint32_t lp = (uint32_t)s_dstart[d] + s_cnt[wave][d] + lrank[r];
@@ -845,8 +962,8 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint64_t* buf_
   __syncthreads();
   // ... and out in runs: consecutive lanes hold consecutive keys of (mostly) the same digit
 #pragma unroll
-  for (int k = 0; k < kSortItems; ++k) {
-    const uint32_t lp = (uint32_t)k * kSortThreads + threadIdx.x;
+  for (int k = 0; k < ITEMS; ++k) {
+    const uint32_t lp = (uint32_t)k * THREADS + threadIdx.x;
     if (lp < tile_valid) {
       const uint64_t kk = s_keys[lp];
       const uint32_t d = (uint32_t)(kk >> shift) & mask;
@@ -880,7 +997,8 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
                                                             uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
-                                                            uint8_t* __restrict__ occ) {
+                                                            uint8_t* __restrict__ occ, unsigned long long* span) {
+  const KSpan kspan(span);
   constexpr int NW = kSortThreads / 64;
   constexpr uint64_t kFlagAgg = 1ull << 62, kFlagIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
   __shared__ uint64_t s_w[NW];
@@ -1100,7 +1218,8 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
                                                            uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
                                                            uint8_t* __restrict__ image, float4* __restrict__ simplified,
                                                            JpegQuant jq, int16_t* __restrict__ coefs,
-                                                           uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff) {
+                                                           uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff, unsigned long long* span) {
+  const KSpan kspan(span);
   PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
   if (L == 0 || st->error != kErrNone) return;  // after an error upstream the leaf arrays are not to be trusted
@@ -1125,6 +1244,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   __shared__ uint32_t s_blen[96], s_boff[96];
   __shared__ unsigned long long s_slotbits[kMaxDepth + 2];  // per level v: which slots hold a leaf with t >= v
   __shared__ uint32_t s_far[kMaxDepth + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
+  __shared__ uint64_t s_probe[64];
   uint32_t* s_base = s_scratch;
   uint32_t* s_occ = s_scratch + kFinTile;
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
@@ -1145,33 +1265,34 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
   if (threadIdx.x < kMaxDepth + 2) s_slotbits[threadIdx.x] = 0ull;
   __syncthreads();
+  PCC_KTR(7, 0);
+  // first probes of the parent search below (the same for every level): requested together with the leaf records
+  uint64_t probe_code = ~0ull;
+  const bool probes_here = wave == kFinThreads / 64 - 1 && nl && pos0 > 255u;
+  if (probes_here) {
+    const uint32_t step = (pos0 + 63u) / 64u, probe = (uint32_t)lane * step;
+    if (probe < pos0) probe_code = leaf_code[probe];
+  }
+  // every load that does not depend on another one is requested first (leaf records of all four rounds, the ends of
+  // the tile's run of points, the code the parent search starts from), then the LDS work
   int t[kFinRounds];
   uint32_t base[kFinRounds], ls[kFinRounds], le[kFinRounds];
   uint64_t code[kFinRounds];
 #pragma unroll
   for (int r = 0; r < kFinRounds; ++r) {
-    const uint32_t slot = (uint32_t)wave * kFinRounds + r, lj = slot * 64u + (uint32_t)lane, j = pos0 + lj;
+    const uint32_t lj = ((uint32_t)wave * kFinRounds + r) * 64u + (uint32_t)lane, j = pos0 + lj;
     const bool is_leaf = lj < nl;
     t[r] = is_leaf ? (int)leaf_t[j] : 0;
     base[r] = is_leaf ? leaf_base[j] : 0u;
     code[r] = is_leaf ? leaf_code[j] : 0ull;
     ls[r] = is_leaf ? leaf_start[j] : 0u;
     le[r] = is_leaf ? leaf_start[j + 1] : 0u;
-    s_t[lj] = (uint8_t)t[r];
-    s_base[lj] = base[r];
-    for (int v = 1; v <= D; ++v) {
-      const uint64_t mk = __ballot(is_leaf && t[r] >= v);
-      if (lane == 0) {
-        s_mask[slot * kMaskStride + v] = mk;
-        if (mk) atomicOr(&s_slotbits[v], 1ull << slot);
-      }
-    }
   }
-  for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
-  // the points of this tile's leaves are one contiguous run of the sorted arrays: stage their colour words.  The loads
-  // are issued here and land in LDS after the parent search below, whose dependent loads they overlap with.
+  // the points of this tile's leaves are one contiguous run of the sorted arrays: their colour words are staged in LDS
   const uint32_t run0 = nl ? leaf_start[pos0] : 0u;
   const uint32_t run1 = nl ? leaf_start[pos0 + nl] : 0u;
+  const uint64_t code0 = (nl && pos0) ? leaf_code[pos0] : 0ull;
+  for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
   const bool staged = colour_pay != nullptr && lp.do_color;
   const uint32_t ncol = staged ? min(run1 - run0, (uint32_t)kColourStage) : 0u;
   uint32_t colreg[kColourStage / kFinThreads];
@@ -1180,31 +1301,72 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     const uint32_t k = threadIdx.x + (uint32_t)q * kFinThreads;
     colreg[q] = k < ncol ? colour_pay[run0 + k] : 0u;
   }
+#pragma unroll
+  for (int r = 0; r < kFinRounds; ++r) {
+    const uint32_t slot = (uint32_t)wave * kFinRounds + r, lj = slot * 64u + (uint32_t)lane;
+    const bool is_leaf = lj < nl;
+    s_t[lj] = (uint8_t)t[r];
+    s_base[lj] = base[r];
+    // t >= v thins out quickly with v (64 consecutive leaves rarely open a node more than three or four levels up):
+    // all levels are cleared with one store, then only the levels that have a leaf are visited
+    if (lane <= D) s_mask[slot * kMaskStride + lane] = 0ull;
+    for (int v = 1; v <= D; ++v) {
+      const uint64_t mk = __ballot(is_leaf && t[r] >= v);
+      if (mk == 0ull) break;
+      if (lane == 0) {
+        s_mask[slot * kMaskStride + v] = mk;
+        atomicOr(&s_slotbits[v], 1ull << slot);
+      }
+    }
+  }
+  PCC_KTR(7, 1);
+  if (probes_here) s_probe[lane] = probe_code;
+  __syncthreads();
+  PCC_KTR(7, 2);
   // Parents that were opened before this tile: for every v the nearest earlier leaf f with t(f) >= v is
   // the first leaf of the level-(D-v) ancestor of the tile's first leaf, i.e. lower_bound over the sorted
-  // leaf codes.  One wave per level, 64 probes per step (4 steps for a million leaves).
+  // leaf codes.  One wave per level.  The first round of 64 probes does not depend on the level: it was
+  // requested at the top of the kernel (s_probe); the last round takes a whole range of <= 256 leaves at once,
+  // four per lane, together with their stream offsets, so that a level costs two dependent round trips.
   if (nl && pos0) {
-    const uint64_t code0 = leaf_code[pos0];
     for (int v = wave + 1; v <= D; v += kFinThreads / 64) {
       const int sh = 3 * v;
       const uint64_t pcode = sh >= 64 ? 0ull : ((code0 >> sh) << sh);
+      // invariant: the answer (first leaf with code >= pcode) lies in [lo, hi]; leaf hi has code >= pcode
       uint32_t lo = 0, hi = pos0;
-      while (hi > lo) {
+      bool first_round = true;
+      while (hi - lo > 255u) {
         const uint32_t step = (hi - lo + 63u) / 64u;
         const uint32_t probe = lo + (uint32_t)lane * step;
-        const bool less = probe < hi && leaf_code[probe] < pcode;
+        const uint64_t pc = first_round ? s_probe[lane] : (probe < hi ? leaf_code[probe] : ~0ull);
+        first_round = false;
+        const bool less = probe < hi && pc < pcode;
         const int cnt = __popcll(__ballot(less));  // the probes are ascending, so `less` holds for a prefix of the lanes
         if (cnt == 0) {
           hi = lo;
         } else {
-          const uint32_t nlo = lo + (uint32_t)(cnt - 1) * step + 1u;
-          hi = min(lo + (uint32_t)cnt * step, hi);
-          lo = nlo;
+          const uint32_t nhi = min(lo + (uint32_t)cnt * step, hi);
+          lo = lo + (uint32_t)(cnt - 1) * step + 1u;
+          hi = nhi;
         }
       }
-      if (lane == 0) s_far[v] = leaf_base[lo] + (uint32_t)leaf_t[lo] - (uint32_t)v;
+      uint32_t below = 0, fb[4], ft[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t i = lo + 4u * (uint32_t)lane + (uint32_t)k;
+        const bool in = i <= hi;
+        const uint64_t c = in ? leaf_code[i] : ~0ull;
+        fb[k] = in ? leaf_base[i] : 0u;
+        ft[k] = in ? (uint32_t)leaf_t[i] : 0u;
+        below += (uint32_t)__popcll(__ballot(i < hi && c < pcode));
+      }
+      const uint32_t at = below;  // answer = lo + below
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (at == 4u * (uint32_t)lane + (uint32_t)k) s_far[v] = fb[k] + ft[k] - (uint32_t)v;
     }
   }
+  PCC_KTR(7, 3);
 #pragma unroll
   for (int q = 0; q < kColourStage / kFinThreads; ++q) {
     const uint32_t k = threadIdx.x + (uint32_t)q * kFinThreads;
@@ -1566,7 +1728,8 @@ size_t sync_area_bytes(uint32_t n, int passes) {
 // ---- k_occ_histogram: the range coder's symbol counts of the occupancy stream ----
 // The static range coder starts with a histogram of its input (one more serial pass over ~1 MB on the host, an
 // eighth of the host stage); the bytes are final here, so the counts ride back inside the FrameState for free.
-__global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ st, const uint8_t* __restrict__ occ) {
+__global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ st, const uint8_t* __restrict__ occ, unsigned long long* span) {
+  const KSpan kspan(span);
   __shared__ uint32_t s_h[4][256];  // four copies: runs of equal bytes do not pile up on one LDS word
   if (st->error != kErrNone || st->n_epochs == 0) return;
   for (int k = threadIdx.x; k < 4 * 256; k += 256) (&s_h[0][0])[k] = 0u;
@@ -1591,7 +1754,15 @@ __global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ 
   if (c) atomicAdd(&st->occ_hist[threadIdx.x], c);
 }
 
+constexpr uint32_t kSortSmallGridTiles = 512;  // up to two tiles per CU the wide workgroup is used
+
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) {
+  int span_slot = 0;
+  auto span = [&](const char* name) -> unsigned long long* {  // the next launch's pair of words, while there are any
+    if (!a.spans || span_slot >= kMaxSpans) return nullptr;
+    if (a.span_names) a.span_names->push_back(name);
+    return a.spans + (size_t)2 * kSpanShards * (span_slot++);
+  };
   const uint32_t n = a.n;
   const uint32_t n_tiles = (n + kTile - 1) / kTile;              // bounding-box chunks (2048 points)
   const uint32_t s_tiles = (n + kSortTile - 1) / kSortTile;      // sort / scan tiles (4096 keys)
@@ -1602,32 +1773,39 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + 64 + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
-  hipLaunchKernelGGL(k_chunk_boxes, dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.boxes, reinterpret_cast<uint4*>(sync), sync_vec16);
-  PCC_STAMP("k_chunk_boxes");
-  hipLaunchKernelGGL(k_bbox_events, dim3(1), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.res, a.force_pairs, passes, (int)a.lp.do_color, a.box, a.state);
-  PCC_STAMP("k_bbox_events");
-  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows);
+  hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
+                     a.res, a.force_pairs, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
+  PCC_STAMP("k_boxes_events");
+  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
   PCC_STAMP("k_make_keys");
-  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0);
+  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
   PCC_STAMP("k_digit_totals");
+  // Few tiles (every tile has a CU to itself): 16 waves share a tile's latency-bound steps.  Many tiles: 8 waves with
+  // twice the keys per thread need 62 KB of LDS instead of 87 KB, so two tiles share a CU and one loads or waits for
+  // its predecessors while the other ranks and writes.
+  const bool many_tiles = s_tiles > kSortSmallGridTiles;
   for (int pass = 0; pass < passes; ++pass) {
-    hipLaunchKernelGGL(k_sort_pass, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
-                       n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles);
+    if (many_tiles)
+      hipLaunchKernelGGL((k_sort_pass<512, 8>), dim3(s_tiles), dim3(512), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+                         n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass"));
+    else
+      hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+                         n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass"));
     PCC_STAMP("k_sort_pass");
   }
   hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
-                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ);
+                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
   PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
-                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff);
+                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff, span("k_leaf_tile"));
   PCC_STAMP("k_leaf_tile");
   if (!a.lp.simplify_only) {
     // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64
     const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));
-    hipLaunchKernelGGL(k_occ_histogram, dim3(hist_wgs), dim3(256), 0, stream, a.state, a.occ);
+    hipLaunchKernelGGL(k_occ_histogram, dim3(hist_wgs), dim3(256), 0, stream, a.state, a.occ, span("k_occ_histogram"));
     PCC_STAMP("k_occ_histogram");
   }
 }

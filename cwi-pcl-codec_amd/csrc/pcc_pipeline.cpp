@@ -48,6 +48,7 @@ struct Job {  // one pcc_pipeline_encode call
   size_t n_frames = 0, stride = 0, rgb_offset = 0;
   pcc_params params{};
   int mode = 0;  // 0 full encode, 1 GPU stage only (launch + finish)
+  bool host_input = false;  // the frames are host pointers: upload through the pipeline's lane, then as above
 };
 
 struct Ready {  // a context whose GPU stage is done
@@ -61,6 +62,7 @@ struct Ready {  // a context whose GPU stage is done
 struct pcc_pipeline {
   int device = 0;
   int n_entropy = 0, n_gpu = 0;
+  pcc_upload_lane* lane = nullptr;  // host-to-device copies of host-input jobs, one after the other
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
   int batch_now = PCC_MAX_FRAMES_AT_ONCE;  // ... for the job at hand: short jobs spread their frames over the threads instead
   std::vector<pcc_ctx*> ctxs;
@@ -146,7 +148,9 @@ struct pcc_pipeline {
         r.prm.frame_id = job.params.frame_id + (uint32_t)r.frame;  // frame_ID_ by sequence index
         Clock::time_point t0 = Clock::now();
         double c0 = thread_cpu_us();
-        int rc = pcc_hotpath_launch(r.ctx, job.frames[r.frame], job.counts[r.frame], job.stride, job.rgb_offset, &r.prm);
+        int rc = job.host_input
+                     ? pcc_hotpath_launch_host(r.ctx, lane, job.frames[r.frame], job.counts[r.frame], job.stride, job.rgb_offset, &r.prm)
+                     : pcc_hotpath_launch(r.ctx, job.frames[r.frame], job.counts[r.frame], job.stride, job.rgb_offset, &r.prm);
         tl += us_since(t0);
         cl += thread_cpu_us() - c0;
         if (rc == PCC_OK) {
@@ -316,6 +320,7 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     }
     p->ctxs.push_back(c);
   }
+  p->lane = pcc_upload_lane_create(device);
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p] { p->gpu_thread(); });
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p] { p->entropy_thread(); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
@@ -347,6 +352,7 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   p->cv_work.notify_all();
   for (std::thread& t : p->threads) t.join();
   for (pcc_ctx* c : p->ctxs) pcc_destroy(c);
+  pcc_upload_lane_destroy(p->lane);
   free(p->arena);
   delete p;
 }
@@ -372,12 +378,13 @@ pcc_ctx* pcc_pipeline_context(pcc_pipeline* p, int index) {
 }
 
 static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t* n_points, size_t n_frames, size_t stride,
-                   size_t rgb_offset, const pcc_params* params, int mode) {
+                   size_t rgb_offset, const pcc_params* params, int mode, bool host_input = false) {
   if (!p || !params || (n_frames && (!dev_frames || !n_points))) return PCC_ERR_ARG;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     p->job.frames = dev_frames; p->job.counts = n_points; p->job.n_frames = n_frames;
     p->job.stride = stride; p->job.rgb_offset = rgb_offset; p->job.params = *params; p->job.mode = mode;
+    p->job.host_input = host_input;
     p->streams.assign(n_frames, std::vector<uint8_t>());
     if (mode == 0 && p->seen_max_len) p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63));
     p->arena_used = 0;
@@ -423,6 +430,14 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
 int pcc_pipeline_encode(pcc_pipeline* p, const void* const* dev_frames, const size_t* n_points, size_t n_frames,
                         size_t stride, size_t rgb_offset, const pcc_params* params, pcc_bitstream* out) {
   const int rc = run_job(p, dev_frames, n_points, n_frames, stride, rgb_offset, params, 0);
+  if (out && p)
+    for (size_t f = 0; f < n_frames && f < p->results.size(); ++f) out[f] = p->results[f];
+  return rc;
+}
+
+int pcc_pipeline_encode_host(pcc_pipeline* p, const void* const* host_frames, const size_t* n_points, size_t n_frames,
+                             size_t stride, size_t rgb_offset, const pcc_params* params, pcc_bitstream* out) {
+  const int rc = run_job(p, host_frames, n_points, n_frames, stride, rgb_offset, params, 0, true);
   if (out && p)
     for (size_t f = 0; f < n_frames && f < p->results.size(); ++f) out[f] = p->results[f];
   return rc;

@@ -143,6 +143,20 @@ int pcc_reserve(pcc_ctx *ctx, size_t max_points, size_t bitstream_bytes);
 /* addPointsFromInputCloud + serializeTree + leaf callbacks (impl.hpp:99,166,1509-1578) on the GPU; asynchronous. */
 int pcc_hotpath_launch(pcc_ctx *ctx, const void *dev_points, size_t n, size_t stride, size_t rgb_offset,
                        const pcc_params *params);
+/* The same for a cloud in HOST memory (the reference's timed span starts there, eval.hpp:462-464): the points are
+ * copied to the context's HBM arena asynchronously, the kernels start when they have arrived.  Ordinary (pageable)
+ * memory is page-locked for the time of the copy; memory from pcc_host_alloc is used as it is.  `lane` (may be NULL)
+ * is a stream shared by the contexts of one GPU that carries the uploads one after the other, at full PCIe rate,
+ * while the kernels of earlier frames run; with NULL the copy is queued in front of the kernels on the context's own
+ * stream.  The caller's buffer must stay untouched until pcc_hotpath_finish returns. */
+typedef struct pcc_upload_lane pcc_upload_lane;
+pcc_upload_lane *pcc_upload_lane_create(int device);
+void pcc_upload_lane_destroy(pcc_upload_lane *lane);
+int pcc_hotpath_launch_host(pcc_ctx *ctx, pcc_upload_lane *lane, const void *host_points, size_t n, size_t stride,
+                            size_t rgb_offset, const pcc_params *params);
+/* page-locked host memory for callers that fill their frames themselves (capture, file readers) */
+void *pcc_host_alloc(size_t bytes);
+void pcc_host_free(void *p);
 /* wait for the kernels, bring occupancy bytes / colour image / centroid bytes to the host */
 int pcc_hotpath_finish(pcc_ctx *ctx, pcc_hot_result *out);
 /* writeFrameHeader + entropyEncoding (impl.hpp:175-178, 1472-1486, 1682-1760): host only, no GPU calls;
@@ -172,6 +186,10 @@ int pcc_device_alloc(pcc_ctx *ctx, size_t bytes, void **dev_ptr);
 int pcc_device_free(pcc_ctx *ctx, void *dev_ptr);
 int pcc_device_upload(pcc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int pcc_get_kernel_times(pcc_ctx *ctx, pcc_kernel_times *out);
+/* The same launches measured on the GPU itself: from the start of a launch's first workgroup to the end of its last
+ * wave, on the device's real-time clock (what a kernel trace reports; the events above sit BETWEEN the launches and
+ * add a few microseconds of their own to every short kernel).  Sort passes a frame did not need are left out. */
+int pcc_get_kernel_spans(pcc_ctx *ctx, pcc_kernel_times *out);
 /* wall time of the last pcc_entropy_encode on this context, microseconds: occupancy range coder, JPEG
  * stage, colour range coder, whole stage */
 int pcc_get_host_times(pcc_ctx *ctx, double out_us[4]);
@@ -201,6 +219,11 @@ int pcc_pipeline_contexts(pcc_pipeline *p);
 pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option / pcc_set_profiling / kernel times */
 int pcc_pipeline_encode(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
                         size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
+/* The same sequence with the frames in HOST memory -- the call the reference app's frame loop maps to (eval.hpp:818-835
+ * encodes clouds that sit in std::vectors): upload of frame k+1 (PCIe, one frame at a time through the pipeline's
+ * upload lane), kernels of frame k and the host entropy stage of frame k-1 overlap.  Same bitstreams. */
+int pcc_pipeline_encode_host(pcc_pipeline *p, const void *const *host_frames, const size_t *n_points, size_t n_frames,
+                             size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
 /* Optional: set aside (and touch) the memory for the bitstreams of `n_frames` frames of up to `bytes_per_frame` bytes
  * before the frames arrive; otherwise the first call allocates per frame and later calls reuse what the largest call
  * needed.  With max_points_per_frame > 0 every context of the ring is prepared as well (pcc_reserve): a context used

@@ -432,9 +432,50 @@ def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
     pipe.gpu_stage_only(devs, sizes, b.make_params(frame_id=3, **kw))
     st = pipe.stats()
     assert st["frames"] == 0   # nothing went through the entropy stage in the last call
+    # the same sequence handed over in HOST memory (pcc_pipeline_encode_host): ordinary numpy arrays are page-locked
+    # for the time of their upload, arrays from pcc_host_alloc are used as they are; one buffer twice in one call
+    lib = b.load_library()
+    pinned = [b.pinned_array(lib, f) if i % 2 else f for i, f in enumerate(frames)]
+    for rep in range(2):
+        got = pipe.encode_host(pinned, b.make_params(frame_id=3, **kw))
+        assert [g[0] for g in got] == want
+    twice = [frames[0], frames[2], frames[0], frames[0], frames[2]]
+    got = pipe.encode_host(twice, b.make_params(frame_id=7, **kw))
+    ref = [oracle.encode_intra(f, oracle.make_params(frame_id=7 + i, **kw), keep=False).bitstream for i, f in enumerate(twice)]
+    assert [g[0] for g in got] == ref
+    for i, a in enumerate(pinned):
+        if i % 2:
+            lib.pcc_host_free(a.ctypes.data)
     for d in devs:
         ctx.free(d)
     pipe.close()
+
+
+def test_host_frames_through_one_context(pkg, oracle):
+    """pcc_hotpath_launch_host with and without an upload lane, pageable and pinned memory, an empty cloud."""
+    b = pkg.binding
+    lib = b.load_library()
+    c = b.Context(0)
+    lane = lib.pcc_upload_lane_create(0)
+    assert lane
+    try:
+        kw = dict(octree_bits=9, jpeg_quality=85)
+        pts = pkg.synthetic.sphere_shell(120_000, 0xA11)
+        want = oracle.encode_intra(pts, oracle.make_params(frame_id=1, **kw)).bitstream
+        pin = b.pinned_array(lib, pts)
+        for src in (pts, pin):
+            for ln in (None, lane):
+                c.hotpath_launch_host(src, b.make_params(frame_id=1, **kw), lane=ln)
+                hot = c.hotpath_finish(copy=False)
+                stream, _ = c.entropy_encode(hot.raw, b.make_params(frame_id=1, **kw))
+                assert stream == want
+        c.hotpath_launch_host(np.zeros(0, dtype=b.POINT_DTYPE), b.make_params(frame_id=1, **kw), lane=lane)
+        with pytest.raises(b.PccError):
+            c.hotpath_finish()
+        lib.pcc_host_free(pin.ctypes.data)
+    finally:
+        c.close()
+        lib.pcc_upload_lane_destroy(lane)
 
 
 # ---------------- randomised sweep ----------------

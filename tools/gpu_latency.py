@@ -23,7 +23,7 @@ n = len(pts)
 for prof in (0, 1):
     ctx.set_profiling(prof)
     ms, wall = [], []
-    agg = {}
+    agg, spans = {}, {}
     for k in range(K + 3):
         t = time.perf_counter()
         ctx.hotpath_launch(dev, n, p)
@@ -34,9 +34,14 @@ for prof in (0, 1):
             if prof:
                 for name, v in ctx.kernel_times():
                     e = agg.setdefault(name, [0.0, 0]); e[0] += v; e[1] += 1
+                for name, v in ctx.kernel_spans():
+                    e = spans.setdefault(name, [0.0, 0]); e[0] += v; e[1] += 1
     print("%s N=%d L=%d B=%d D=%d  profiling=%d: gpu %.1f us (min %.1f)  launch+finish wall %.1f us" %
           (wl, n, hot.n_leaves, hot.n_branches, hot.depth, prof, 1e3 * np.mean(ms), 1e3 * np.min(ms), 1e3 * np.mean(wall)))
     if prof:
         for name, (tot, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-            print("   %-22s %5.1f launches/frame  %8.2f us each  %8.2f us/frame" % (name, cnt / K, 1e3 * tot / cnt, 1e3 * tot / K))
+            sp = spans.get(name, [0.0, 1])
+            print("   %-22s %5.1f launches/frame  %8.2f us each  %8.2f us/frame   on the GPU clock: %8.2f us each  %8.2f us/frame" %
+                  (name, cnt / K, 1e3 * tot / cnt, 1e3 * tot / K, 1e3 * sp[0] / max(1, sp[1]), 1e3 * sp[0] / K))
+        print("   sum of the launch spans on the GPU clock: %.1f us/frame" % (1e3 * sum(v[0] for v in spans.values()) / K))
 ctx.close()

@@ -25,6 +25,11 @@ x = t[5, :231, :7]
 rel = (x - x[:, 0].min()) / 100.0
 print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end:", np.round(np.median(rel, axis=0), 2))
 print("            stamps (max us):", np.round(rel.max(axis=0), 2))
-x = t[6, 0, :6]
-print("k_bbox_events stamps (us): start, A done, B done, first chunk loaded, events done, end:", np.round((x - x[0]) / 100.0, 2))
+x = t[7, :231, :4]
+rel = (x - t[5, :231, 0:1]) / 100.0
+print("k_leaf_tile A1 (median us since kernel start): first barrier, records landed + masks, barrier, parent search done:", np.round(np.median(rel, axis=0), 2))
+x8 = t[8, 0, :8]
+x = t[6, 0, :7]
+print("k_boxes_events replay rounds (us since start, after each block-wide minimum):", np.round((x8 - x[0]) / 100.0, 2))
+print("k_boxes_events, workgroup 0, stamps (us): start, first point found, chunk 0 replayed, chunk boxes all there, sweep done, events done, end:", np.round((x - x[0]) / 100.0, 2))
 ctx.close()
