@@ -32,6 +32,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <pcl/cloud_codec_v2/point_cloud_codec_v2.h>
@@ -79,6 +80,9 @@ const OptionDef kOptions[] = {
     {"debug_level", 0, "0", false, false},
     // not in the reference: load the input, print point counts and a checksum per file, and stop (no GPU needed)
     {"list_only", 0, "0", true, true},
+    // not in the reference: GPUs that share the frames of a group, "0,1,2,..." (frame f on the f mod N-th of them through
+    // pcc_pipeline_create_multi; bitstreams and frame ids as in the serial loop).  Empty: the reference's loop on PCC_DEVICE.
+    {"devices", 0, "", false, false},
 };
 
 struct Options {
@@ -414,10 +418,29 @@ struct App {
   Options opt;
   std::unique_ptr<Codec> encoder, decoder;
   pcc_ctx* quality_ctx = nullptr;
+  pcc_multi_pipeline* multi = nullptr;  // --devices: the GPUs that share the frames of a group
   int output_index = -1;
   std::ofstream predictive_csv;
 
-  ~App() { if (quality_ctx) pcc_destroy(quality_ctx); }
+  ~App() {
+    if (quality_ctx) pcc_destroy(quality_ctx);
+    if (multi) pcc_multi_pipeline_destroy(multi);
+  }
+
+  bool open_devices() {  // --devices 0,1,2,...
+    const std::string list = opt.str("devices");
+    if (list.empty() || multi) return true;
+    std::vector<int> devs;
+    std::stringstream ls(list);
+    std::string item;
+    while (std::getline(ls, item, ','))
+      if (!item.empty()) devs.push_back(atoi(item.c_str()));
+    if (devs.empty()) return true;
+    const int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+    multi = pcc_pipeline_create_multi(devs.data(), (int)devs.size(), std::max(2, std::min(16, cpus / (int)devs.size())));
+    if (!multi) std::cerr << "cannot open the GPUs of --devices " << list << ": " << pcc_multi_pipeline_last_error(nullptr) << "\n";
+    return multi != nullptr;
+  }
 
   void complete_initialization() {  // eval.hpp:341-428 (V2 branch)
     const int octree_bits = opt.integer("octree_bits"), enh_bits = opt.integer("enh_bits"), color_bits = opt.integer("color_bits");
@@ -440,7 +463,7 @@ struct App {
 
   // do_quality_computation (eval.hpp:529-541): computeQualityMetric on the GPU
   void do_quality_computation(const CloudPtr& reference, const CloudPtr& cloud, QualityMetric& q, double res) {
-    if (!quality_ctx) quality_ctx = pcc_create(0);
+    if (!quality_ctx) quality_ctx = pcc_create(pcl::io::pcc_shim_device());
     pcc_quality m;
     const int rc = quality_ctx ? pcc_quality_metrics(quality_ctx, reinterpret_cast<const pcc_point_xyzrgb*>(reference->points.data()), reference->points.size(),
                                                      reinterpret_cast<const pcc_point_xyzrgb*>(cloud->points.data()), cloud->points.size(), res, &m)
@@ -469,11 +492,40 @@ struct App {
     const double f = opt.real("bb_expand_factor");
     if (f > 0.0) bb = Codec::normalize_pointclouds(working_group, boxes, f, dyn_range, offset, (unsigned)opt.integer("debug_level"));
     const double res = opt.integer("octree_bits") > 0 ? std::pow(2.0, -1.0 * opt.integer("octree_bits")) : opt.real("octree_resolution");
+    // Several GPUs: the whole group is encoded up front, frame f on GPU f mod N (the frames are independent I-frames);
+    // the loop below then takes each frame's bitstream instead of calling the encoder.  Delta coding needs the
+    // encoder object's simplified cloud of every frame, so it keeps the reference's loop.
+    std::vector<pcc_bitstream> pre;
+    double pre_ms_per_frame = 0.0;
+    if (multi && !opt.flag("do_delta_coding")) {
+      std::vector<const void*> ptrs;
+      std::vector<size_t> counts;
+      for (CloudPtr& c : working_group) { ptrs.push_back(c->points.data()); counts.push_back(c->points.size()); }
+      pre.assign(working_group.size(), pcc_bitstream());
+      pcc_params prm = encoder->native_params();
+      prm.frame_id = encoder->next_frame_id();
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = pcc_multi_pipeline_encode_host(multi, ptrs.data(), counts.data(), ptrs.size(), sizeof(PointT), 16, &prm, pre.data());
+      pre_ms_per_frame = ms_since(t0) / (double)std::max<size_t>(1, ptrs.size());
+      if (rc != PCC_OK) {
+        std::cerr << "multi-GPU encode failed: " << pcc_multi_pipeline_last_error(multi) << "\n";
+        return false;
+      }
+      size_t coded = 0;
+      for (const pcc_bitstream& b : pre) coded += b.len ? 1 : 0;
+      encoder->advance_frame_id((uint32_t)coded);
+    }
     for (size_t i = 0; i < working_group.size(); ++i) {
       CloudPtr pc = working_group[i];
       QualityMetric q;
       std::stringstream ss;
-      {  // do_encoding (eval.hpp:446-474)
+      if (!pre.empty()) {
+        ss.write(reinterpret_cast<const char*>(pre[i].data), (std::streamsize)pre[i].len);
+        q.encoding_time_ms = pre_ms_per_frame;
+        q.byte_count_octree_layer = pre[i].perf[0]; q.byte_count_centroid_layer = pre[i].perf[1]; q.byte_count_color_layer = pre[i].perf[2];
+        q.compressed_size = pre[i].len;
+        std::cout << " octreeCoding " << q.compressed_size << " bytes  base layer  " << std::endl;
+      } else {  // do_encoding (eval.hpp:446-474)
         const auto t0 = std::chrono::steady_clock::now();
         encoder->encodePointCloud(pc, ss);
         q.encoding_time_ms = ms_since(t0);
@@ -572,6 +624,7 @@ struct App {
     }
 
     complete_initialization();
+    if (!open_devices()) return 1;
     std::ostringstream settings;  // eval.hpp:741
     settings << "octree_bits=" << opt.integer("octree_bits") << " color_bits=" << opt.integer("color_bits") << " enh._bits=" << opt.integer("enh_bits")
              << "_colortype=" << opt.integer("color_coding_type") << " centroid=" << opt.integer("keep_centroid");

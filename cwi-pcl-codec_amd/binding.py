@@ -38,6 +38,8 @@ EXPORTS = [
     "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_encode_host", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
+    "pcc_pipeline_create_multi", "pcc_multi_pipeline_destroy", "pcc_multi_pipeline_size", "pcc_multi_pipeline_member",
+    "pcc_multi_pipeline_encode_host", "pcc_multi_pipeline_encode", "pcc_multi_pipeline_last_error",
     "pcc_quality_metrics", "pcc_remove_outliers", "pcc_device_range_encode",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
@@ -168,6 +170,17 @@ def load_library():
     lib.pcc_pipeline_contexts.argtypes = [vp]
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
+    lib.pcc_pipeline_create_multi.restype = vp
+    lib.pcc_pipeline_create_multi.argtypes = [C.POINTER(i32), i32, i32]
+    lib.pcc_multi_pipeline_destroy.argtypes = [vp]
+    lib.pcc_multi_pipeline_destroy.restype = None
+    lib.pcc_multi_pipeline_size.argtypes = [vp]
+    lib.pcc_multi_pipeline_member.restype = vp
+    lib.pcc_multi_pipeline_member.argtypes = [vp, i32]
+    lib.pcc_multi_pipeline_last_error.restype = C.c_char_p
+    lib.pcc_multi_pipeline_last_error.argtypes = [vp]
+    for fn in (lib.pcc_multi_pipeline_encode_host, lib.pcc_multi_pipeline_encode):
+        fn.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_pipeline_encode_host.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_pipeline_encode.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, sz, C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_pipeline_reserve.argtypes = [vp, sz, sz, sz]
@@ -556,6 +569,40 @@ class Pipeline:
         self.lib.pcc_pipeline_cpu_times(self.h, cpu)
         out.update(launch_cpu_us=cpu[0], finish_cpu_us=cpu[1], entropy_cpu_us=cpu[2])
         return out
+
+
+class MultiPipeline:
+    """pcc_multi_pipeline: one pipeline per entry of `devices`, frame f on devices[f % len(devices)]."""
+
+    def __init__(self, devices, workers_per_device=8):
+        self.lib = load_library()
+        arr = (C.c_int32 * len(devices))(*devices)
+        self.h = self.lib.pcc_pipeline_create_multi(arr, len(devices), workers_per_device)
+        if not self.h:
+            raise RuntimeError("pcc_pipeline_create_multi(%r) failed: a device is missing -- there is no CPU fallback" % (list(devices),))
+        self.devices = list(devices)
+
+    def close(self):
+        if self.h:
+            self.lib.pcc_multi_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode_host(self, host_frames, params, stride=32, rgb_offset=16, copy=True):
+        frames = [np.ascontiguousarray(f) for f in host_frames]
+        k = len(frames)
+        fr = (C.c_void_p * k)(*[f.ctypes.data for f in frames])
+        cn = (C.c_size_t * k)(*[len(f) for f in frames])
+        out = (Bitstream * k)()
+        rc = self.lib.pcc_multi_pipeline_encode_host(self.h, fr, cn, k, stride, rgb_offset, C.byref(params), out)
+        if rc != PCC_OK:
+            raise PccError(rc, self.lib.pcc_multi_pipeline_last_error(self.h).decode())
+        return [((_bytes_at(b.data, b.len) if copy else b.len), [int(x) for x in b.perf]) for b in out]
 
 
 MANUAL_CONFIGURATION = "MANUAL_CONFIGURATION"

@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <float.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "pcc_device.h"
 #include "pcc_kernels.h"
@@ -1783,7 +1785,11 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   // Few tiles (every tile has a CU to itself): 16 waves share a tile's latency-bound steps.  Many tiles: 8 waves with
   // twice the keys per thread need 62 KB of LDS instead of 87 KB, so two tiles share a CU and one loads or waits for
   // its predecessors while the other ranks and writes.
-  const bool many_tiles = s_tiles > kSortSmallGridTiles;
+  static const int forced_shape = [] {  // developer knob: PCC_SORT_SHAPE=narrow|wide
+    const char* e = getenv("PCC_SORT_SHAPE");
+    return !e ? 0 : (!strcmp(e, "narrow") ? 1 : (!strcmp(e, "wide") ? 2 : 0));
+  }();
+  const bool many_tiles = forced_shape ? forced_shape == 1 : s_tiles > kSortSmallGridTiles;
   for (int pass = 0; pass < passes; ++pass) {
     if (many_tiles)
       hipLaunchKernelGGL((k_sort_pass<512, 8>), dim3(s_tiles), dim3(512), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,

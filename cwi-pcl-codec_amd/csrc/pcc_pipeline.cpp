@@ -481,4 +481,91 @@ int pcc_pipeline_kernel_times(pcc_pipeline* p, pcc_kernel_times* sums, int32_t* 
 
 const char* pcc_pipeline_last_error(pcc_pipeline* p) { return p ? p->err.c_str() : "no pipeline (no usable HIP device?)"; }
 
+// ---- several GPUs behind one call: frame f of a sequence goes to devices[f mod n] ----
+// One pcc_pipeline per entry of `devices` (the same GPU may be named twice: two pipelines share it).  Frames are
+// independent I-frames, so there is no exchange between the GPUs; the only thing that ties the frames together,
+// frame_ID_, is written into the finished bitstreams in sequence order, dropped frames not counting (impl.hpp:133 vs
+// 206-212), which makes the result byte-identical to the reference's serial loop on one codec object.
+struct pcc_multi_pipeline {
+  std::vector<pcc_pipeline*> pipes;
+  std::vector<int> devices;
+  std::string err;
+};
+
+pcc_multi_pipeline* pcc_pipeline_create_multi(const int* devices, int n_devices, int n_workers_per_device) {
+  if (!devices || n_devices < 1) return nullptr;
+  pcc_multi_pipeline* m = new pcc_multi_pipeline();
+  for (int d = 0; d < n_devices; ++d) {
+    pcc_pipeline* p = pcc_pipeline_create(devices[d], n_workers_per_device);
+    if (!p) {  // a device that does not exist: nothing is silently left out
+      for (pcc_pipeline* q : m->pipes) pcc_pipeline_destroy(q);
+      delete m;
+      return nullptr;
+    }
+    m->pipes.push_back(p);
+    m->devices.push_back(devices[d]);
+  }
+  return m;
+}
+
+void pcc_multi_pipeline_destroy(pcc_multi_pipeline* m) {
+  if (!m) return;
+  for (pcc_pipeline* p : m->pipes) pcc_pipeline_destroy(p);
+  delete m;
+}
+
+int pcc_multi_pipeline_size(pcc_multi_pipeline* m) { return m ? (int)m->pipes.size() : 0; }
+pcc_pipeline* pcc_multi_pipeline_member(pcc_multi_pipeline* m, int index) {
+  return (m && index >= 0 && index < (int)m->pipes.size()) ? m->pipes[(size_t)index] : nullptr;
+}
+const char* pcc_multi_pipeline_last_error(pcc_multi_pipeline* m) { return m ? m->err.c_str() : "no multi-GPU pipeline (a device is missing)"; }
+
+static int multi_run(pcc_multi_pipeline* m, const void* const* frames, const size_t* n_points, size_t n_frames, size_t stride,
+                     size_t rgb_offset, const pcc_params* params, pcc_bitstream* out, bool host_input) {
+  if (!m || !params || (n_frames && (!frames || !n_points || !out))) return PCC_ERR_ARG;
+  const size_t nd = m->pipes.size();
+  std::vector<std::vector<const void*>> fr(nd);
+  std::vector<std::vector<size_t>> cn(nd);
+  std::vector<std::vector<pcc_bitstream>> res(nd);
+  for (size_t f = 0; f < n_frames; ++f) {
+    fr[f % nd].push_back(frames[f]);
+    cn[f % nd].push_back(n_points[f]);
+  }
+  std::vector<int> rc(nd, PCC_OK);
+  std::vector<std::thread> th;
+  for (size_t d = 0; d < nd; ++d) {
+    res[d].assign(fr[d].size(), pcc_bitstream());
+    th.emplace_back([&, d] {
+      rc[d] = host_input ? pcc_pipeline_encode_host(m->pipes[d], fr[d].data(), cn[d].data(), fr[d].size(), stride, rgb_offset, params, res[d].data())
+                         : pcc_pipeline_encode(m->pipes[d], fr[d].data(), cn[d].data(), fr[d].size(), stride, rgb_offset, params, res[d].data());
+    });
+  }
+  for (std::thread& t : th) t.join();
+  m->err.clear();
+  int first_bad = PCC_OK;
+  for (size_t d = 0; d < nd; ++d)
+    if (rc[d] != PCC_OK && first_bad == PCC_OK) {
+      first_bad = rc[d];
+      m->err = pcc_pipeline_last_error(m->pipes[d]);
+    }
+  uint32_t id = params->frame_id;
+  for (size_t f = 0; f < n_frames; ++f) {
+    out[f] = res[f % nd][f / nd];
+    if (out[f].len >= 52) {  // frame_ID_: u32 behind the two identifiers (28 + 20 bytes)
+      memcpy(const_cast<uint8_t*>(out[f].data) + 48, &id, sizeof(id));
+      ++id;
+    }
+  }
+  return first_bad;
+}
+
+int pcc_multi_pipeline_encode_host(pcc_multi_pipeline* m, const void* const* host_frames, const size_t* n_points, size_t n_frames,
+                                   size_t stride, size_t rgb_offset, const pcc_params* params, pcc_bitstream* out) {
+  return multi_run(m, host_frames, n_points, n_frames, stride, rgb_offset, params, out, true);
+}
+int pcc_multi_pipeline_encode(pcc_multi_pipeline* m, const void* const* dev_frames, const size_t* n_points, size_t n_frames,
+                              size_t stride, size_t rgb_offset, const pcc_params* params, pcc_bitstream* out) {
+  return multi_run(m, dev_frames, n_points, n_frames, stride, rgb_offset, params, out, false);
+}
+
 }  // extern "C"

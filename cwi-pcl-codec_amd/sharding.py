@@ -15,9 +15,25 @@ def frames_for_rank(n_frames, rank, world):
 
 
 def frame_id(frame_index):
-    """Header frame_ID_ of the frame_index-th frame of a group (the encoder is re-created per group,
-    eval.hpp:779, and pre-increments at impl.hpp:133): 1-based sequence index."""
+    """Provisional header frame_ID_ of the frame_index-th frame of a group (the encoder is re-created per group,
+    eval.hpp:779, and pre-increments at impl.hpp:133): 1-based sequence index.  A frame that is dropped (empty or
+    all non-finite, impl.hpp:206-212) does not advance the reference's counter, and a rank cannot know what the
+    other ranks drop: `gather_streams` renumbers the finished bitstreams in sequence order."""
     return frame_index + 1
+
+
+FRAME_ID_OFFSET = 48  # u32 behind the two identifiers of the frame header (28 + 20 bytes, impl.hpp:1472-1486)
+
+
+def renumber(streams, first_id=1):
+    """Frame ids of the reference's serial loop: consecutive over the frames that produced a bitstream."""
+    out, fid = [], first_id
+    for s in streams:
+        if len(s) >= FRAME_ID_OFFSET + 4:
+            s = s[:FRAME_ID_OFFSET] + int(fid).to_bytes(4, "little") + s[FRAME_ID_OFFSET + 4:]
+            fid += 1
+        out.append(s)
+    return out
 
 
 def encode_shard(encode_one, n_frames, rank, world):
@@ -38,4 +54,4 @@ def gather_streams(local, n_frames, dist=None):
     missing = [f for f in range(n_frames) if f not in merged]
     if missing:
         raise RuntimeError("frames not encoded by any rank: %r" % missing)
-    return b"".join(merged[f] for f in range(n_frames))
+    return b"".join(renumber([merged[f] for f in range(n_frames)]))

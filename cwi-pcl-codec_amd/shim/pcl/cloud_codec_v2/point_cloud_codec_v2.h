@@ -136,6 +136,12 @@ class OctreePointCloudCodecV2 {
 
   uint64_t* getPerformanceMetrics() { return perf_; }  // codec.h:193-197
 
+  // Not in the reference: what a caller needs to hand whole groups of frames to pcc_pipeline / pcc_multi_pipeline
+  // (several GPUs) and keep this object's frame counter in step with the frames coded there.
+  const pcc_params& native_params() const { return prm_; }
+  uint32_t next_frame_id() const { return frame_id_ + 1; }
+  void advance_frame_id(uint32_t frames_coded) { frame_id_ += frames_coded; }
+
   // OctreePointCloudCompression::getOutputCloud(): the simplified cloud of the last encode (impl.hpp:1576)
   PointCloudPtr getOutputCloud() {
     PointCloudPtr c(new PointCloud());

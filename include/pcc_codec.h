@@ -244,6 +244,23 @@ int pcc_pipeline_cpu_times(pcc_pipeline *p, double out_us[4]);
 int pcc_pipeline_kernel_times(pcc_pipeline *p, pcc_kernel_times *sums, int32_t *launches, int32_t *frames);
 const char *pcc_pipeline_last_error(pcc_pipeline *p);
 
+/* ---- the same frame loop over several GPUs of one node (frames shard one per GPU, no collective) ----
+ * One pipeline per entry of `devices` (a GPU may be named more than once); frame f goes to devices[f mod n_devices];
+ * the bitstreams come back in sequence order with the frame ids of the reference's serial loop (dropped frames do not
+ * consume one).  pcc_pipeline_create_multi returns NULL if any of the devices is missing.  With device-resident
+ * frames, frame f has to live on devices[f mod n_devices]. */
+typedef struct pcc_multi_pipeline pcc_multi_pipeline;
+pcc_multi_pipeline *pcc_pipeline_create_multi(const int *devices, int n_devices, int n_workers_per_device);
+void pcc_multi_pipeline_destroy(pcc_multi_pipeline *m);
+int pcc_multi_pipeline_size(pcc_multi_pipeline *m);
+pcc_pipeline *pcc_multi_pipeline_member(pcc_multi_pipeline *m, int index); /* e.g. for pcc_pipeline_reserve */
+int pcc_multi_pipeline_encode_host(pcc_multi_pipeline *m, const void *const *host_frames, const size_t *n_points,
+                                   size_t n_frames, size_t stride, size_t rgb_offset, const pcc_params *params,
+                                   pcc_bitstream *out);
+int pcc_multi_pipeline_encode(pcc_multi_pipeline *m, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
+                              size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
+const char *pcc_multi_pipeline_last_error(pcc_multi_pipeline *m);
+
 /* ---- computeQualityMetric (apps/evaluate_compression quality_metrics_impl.hpp:82-239; quality_metrics.h:53-80) ----
  * cloud_a = original, cloud_b = decoded (host pointers).  Nearest neighbours on the GPU (uniform grid of cell size
  * `cell_hint`, e.g. the octree resolution; <= 0: chosen from the clouds), exact like the reference's KdTree;

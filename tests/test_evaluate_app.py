@@ -160,3 +160,27 @@ def test_app_delta_coding_branch(pkg, tmp_path):
     assert int(col[2]) == len(dec)
     got = np.loadtxt(str(tmp_path / "out" / "delta_decoded_pc_1.ply"), skiprows=11)
     assert got.shape == (len(dec), 6)
+
+
+@pytest.mark.gpu
+def test_app_with_a_device_list_gives_the_serial_loops_results(pkg, tmp_path):
+    """--devices 0,0: the group's frames are encoded up front through pcc_pipeline_create_multi (two pipelines, here on the
+    same GPU), frame f on the f mod 2-th; every CSV column but the two timing columns, and the decoded files, equal
+    those of the reference's serial loop (two groups, so the frame ids restart with the second group)."""
+    frames = _raw_frames(pkg, 5, 15_000)
+    d = tmp_path / "in"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        _write_ply(str(d / ("frame_%02d.ply" % i)), f, binary=True)
+    runs = {}
+    for label, extra in (("serial", []), ("multi", ["--devices=0,0"])):
+        w = tmp_path / label
+        w.mkdir()
+        (w / "out").mkdir()
+        p = subprocess.run([APP, "-b", "8", "--jpeg_quality=85", "--group_size=3", "--do_quality_computation=1", "--output_directory=out",
+                            "-i", str(d)] + extra, cwd=str(w), capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        lines = open(w / "intra_frame_quality.csv").read().splitlines()
+        assert len(lines) == 6
+        runs[label] = ([l.split(";")[:14] for l in lines], [open(w / "out" / ("pointcloud_%d.ply" % i), "rb").read() for i in range(5)])
+    assert runs["serial"] == runs["multi"]

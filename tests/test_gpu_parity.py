@@ -451,6 +451,28 @@ def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
     pipe.close()
 
 
+def test_two_pipelines_behind_the_multi_gpu_entry_point(pkg, oracle):
+    """pcc_pipeline_create_multi with the same GPU named twice (a 1-GPU box): frame f goes to pipeline f mod 2, the
+    bitstreams come back in sequence order with the serial loop's frame ids -- a dropped frame in the middle included."""
+    b = pkg.binding
+    sizes = [20_000, 3_000, 25_000, 8_000, 100, 12_000, 30_000]
+    frames = [pkg.synthetic.sphere_shell(n, 0xB00 + i) for i, n in enumerate(sizes)]
+    frames[3]["y"] = np.inf   # dropped
+    kw = dict(octree_bits=8, jpeg_quality=75)
+    want, fid = [], 5
+    for f in frames:
+        r = oracle.encode_intra(f, oracle.make_params(frame_id=fid, **kw), keep=False)
+        want.append(b"" if r is None else r.bitstream)
+        fid += 0 if r is None else 1
+    multi = b.MultiPipeline([0, 0], 2)
+    try:
+        for rep in range(2):
+            got = multi.encode_host(frames, b.make_params(frame_id=5, **kw))
+            assert [g[0] for g in got] == want
+    finally:
+        multi.close()
+
+
 def test_host_frames_through_one_context(pkg, oracle):
     """pcc_hotpath_launch_host with and without an upload lane, pageable and pinned memory, an empty cloud."""
     b = pkg.binding

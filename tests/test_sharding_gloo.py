@@ -14,14 +14,19 @@ import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_FRAMES = 5
+N_FRAMES = 6
+DROPPED = 2   # this frame has no finite point: the reference drops it and does not advance frame_ID_ (impl.hpp:206-212)
 KW = dict(octree_bits=6, color_bits=8, color_coding_type=1, jpeg_quality=80)
 
 
 def _encode_frame(pkg, O, f, fid):
     from test_host_stage import _hot_from_oracle
     pts = pkg.synthetic.sphere_shell(3000, 0xC3 + f)
+    if f == DROPPED:
+        pts["x"] = np.nan
     r = O.encode_intra(pts, O.make_params(frame_id=fid, **KW))
+    if r is None:
+        return b""
     host = pkg.binding.Context(None)
     hr, keep = _hot_from_oracle(pkg, r)
     stream, _ = host.entropy_encode(hr, pkg.binding.make_params(frame_id=fid, **KW))
@@ -69,13 +74,32 @@ def test_two_ranks_equal_sequential(pkg, oracle, tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     sharded = open(out, "rb").read()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    sequential = b"".join(_encode_frame(pkg, oracle, f, f + 1) for f in range(N_FRAMES))
-    assert sharded == sequential
-    # the concatenated GOP decodes frame by frame, ids 1..N in order
+    # the reference's serial loop: the counter only moves for frames that are not dropped
+    parts, fid = [], 1
+    for f in range(N_FRAMES):
+        st = _encode_frame(pkg, oracle, f, fid)
+        parts.append(st)
+        fid += 1 if st else 0
+    assert parts[DROPPED] == b"" and fid == N_FRAMES
+    assert sharded == b"".join(parts)
+    # the concatenated GOP decodes frame by frame, ids 1..N-1 in order
     host = pkg.binding.Context(None)
     pos = 0
-    for f in range(N_FRAMES):
+    for f in range(N_FRAMES - 1):
         pts, info = host.decode_intra(sharded[pos:])
         assert info["params"]["frame_id"] == f + 1 and len(pts) > 0
         pos += info["consumed"]
     assert pos == len(sharded)
+
+
+def test_multi_gpu_entry_point_refuses_missing_devices(pkg):
+    """pcc_pipeline_create_multi: every named device has to exist -- nothing is silently left out, and there is no CPU
+    fallback (on a box without GPUs the call fails for any list)."""
+    import ctypes as C
+    lib = pkg.binding.load_library()
+    bad = (C.c_int32 * 2)(0, 4096)
+    assert not lib.pcc_pipeline_create_multi(bad, 2, 2)
+    assert not lib.pcc_pipeline_create_multi(bad, 0, 2)
+    assert b"device" in lib.pcc_multi_pipeline_last_error(None)
+    with pytest.raises(RuntimeError):
+        pkg.binding.MultiPipeline([0, 4096], 2)
