@@ -278,7 +278,7 @@ def main():
         legs = {}
         for label, src in (("pinned", pinned), ("pageable", host_frames)):
             seq_h = [src[s % n_distinct] for s in range(hf)]
-            pipe.encode_host(seq_h[:max(8, pipe.n_contexts // 2)], params, copy=False)   # warm-up
+            pipe.encode_host(seq_h[:min(hf, 2 * pipe.n_contexts)], params, copy=False)   # warm-up: every context gets its upload buffer
             torch.cuda.synchronize()
             th = time.perf_counter()
             pipe.encode_host(seq_h, params, copy=False)

@@ -435,9 +435,14 @@ class Context:
         dp = DeltaParams()
         dp.codec = params
         c = Cloud()
+        import time
+        t0 = time.perf_counter()
         self._check(self.lib.pcc_decode_delta(self.h, ic.ctypes.data, len(ic), a.ctypes.data if len(a) else None, len(a),
                                               b2.ctypes.data if len(b2) else None, len(b2), C.byref(dp), C.byref(c)))
-        return np.frombuffer(_bytes_at(c.points, 32 * c.n), dtype=POINT_DTYPE).copy()
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3   # the C call alone, without the copy into a numpy array below
+        if not c.n:
+            return np.zeros(0, dtype=POINT_DTYPE)
+        return np.frombuffer((C.c_uint8 * (32 * c.n)).from_address(c.points), dtype=POINT_DTYPE).copy()
 
     def set_option(self, name, value):
         self._check(self.lib.pcc_set_option(self.h, name.encode(), int(value)))

@@ -128,7 +128,8 @@ struct pcc_ctx {
   std::vector<uint64_t> h_ifull;
   std::vector<float> h_mdec;
   Bytes p_stream, i_stream;
-  std::vector<pcc_point_xyzrgb> delta_cloud;
+  PinnedBuf<pcc_point_xyzrgb> delta_cloud;  // predicted (+ decoded intra) points of the last delta call: page-locked, the
+  size_t delta_cloud_n = 0;                 // device-to-host copy of a million points is a DMA, not a staged copy
 
   // host landing buffers
   PinnedBuf<FrameState> h_state;
@@ -379,7 +380,7 @@ void pcc_destroy(pcc_ctx* c) {
             c->usual_wait_ns[1] / 1e3, c->usual_wait_ns[2] / 1e3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->locked_host) { unlock_host_range(c->locked_host); c->locked_host = nullptr; }
-  c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
+  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
@@ -1325,8 +1326,9 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   ga.out_intra = ctx->d_delta_intra.p; ga.out_cloud = ctx->d_delta_out.p;
   launch_delta_gather(ga, ctx->stream);
   PCC_HIP(hipGetLastError());
-  ctx->delta_cloud.resize(out_n);
-  if (out_n) PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.data(), ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(ctx->delta_cloud.ensure(out_n + 1));
+  ctx->delta_cloud_n = out_n;
+  if (out_n) PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.p, ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
   PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
   { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   float ms = 0.f;
@@ -1355,7 +1357,7 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   }
   out->i_data = ctx->i_stream.data(); out->i_len = ctx->i_stream.size();
   out->p_data = ctx->p_stream.data(); out->p_len = ctx->p_stream.size();
-  out->out_cloud = ctx->delta_cloud.data(); out->out_n = out_n;
+  out->out_cloud = ctx->delta_cloud.p; out->out_n = out_n;
   out->macro_block_count = nbp; out->shared_macroblock_count = shared; out->convergence_count = converged;
   out->shared_macroblock_percentage = (float)shared / (float)nbp;                 // impl.hpp:1105-1106
   out->shared_macroblock_convergence_percentage = (float)converged / (float)shared;
@@ -1380,7 +1382,8 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   const pcc_params& cp = dp->codec;
   if (!(cp.octree_resolution > 0.0) || cp.macroblock_size < 1) return fail(ctx, PCC_ERR_ARG, "octree_resolution / macroblock_size");
   PCC_HIP(hipSetDevice(ctx->device));
-  ctx->delta_cloud.clear();
+  ctx->delta_cloud_n = 0;
+  bool delta_copy_pending = false;
   size_t out_n = 0;
   if (n_i && p_len) {
     { const int rc = delta_subcontexts(ctx); if (rc != PCC_OK) return rc; }
@@ -1461,9 +1464,12 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
         ga.out_intra = nullptr; ga.out_cloud = ctx->d_delta_out.p;
         launch_delta_gather(ga, ctx->stream);
         PCC_HIP(hipGetLastError());
-        ctx->delta_cloud.resize(out_n);
-        PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.data(), ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
-        { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+        // room for the intra coded points behind the predicted ones (at most 16384 per byte of a corrupt stream: bounded by decode_frame)
+        PCC_HIP(ctx->delta_cloud.ensure(out_n + 1));
+        ctx->delta_cloud_n = out_n;
+        PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.p, ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
+        // the copy lands while the host decodes the intra part below
+        delta_copy_pending = true;
       }
     } else if (rc != PCC_ERR_EMPTY) {
       return rc;
@@ -1481,10 +1487,21 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
     if (rc != PCC_OK) return fail(ctx, rc, "decode: intra part of the delta frame: header not found, or stream truncated/corrupt");
     out->params = ic.params; out->depth = ic.depth; out->consumed = ic.consumed;
     for (int a = 0; a < 6; ++a) out->bbox[a] = ic.bbox[a];
-    ctx->delta_cloud.insert(ctx->delta_cloud.end(), ctx->dec_points.begin(), ctx->dec_points.end());
+    const size_t n_intra = ctx->dec_points.size();
+    if (ctx->delta_cloud.cap < ctx->delta_cloud_n + n_intra + 1) {  // grow, keeping the predicted points
+      if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; delta_copy_pending = false; }
+      PinnedBuf<pcc_point_xyzrgb> bigger;
+      PCC_HIP(bigger.ensure(ctx->delta_cloud_n + n_intra + 1));
+      if (ctx->delta_cloud_n) memcpy(bigger.p, ctx->delta_cloud.p, ctx->delta_cloud_n * sizeof(pcc_point_xyzrgb));
+      ctx->delta_cloud.release();
+      ctx->delta_cloud = bigger;
+    }
+    if (n_intra) memcpy(ctx->delta_cloud.p + ctx->delta_cloud_n, ctx->dec_points.data(), n_intra * sizeof(pcc_point_xyzrgb));
+    ctx->delta_cloud_n += n_intra;
   }
-  out->points = ctx->delta_cloud.data();
-  out->n = ctx->delta_cloud.size();
+  if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  out->points = ctx->delta_cloud.p;
+  out->n = ctx->delta_cloud_n;
   return PCC_OK;
 }
 

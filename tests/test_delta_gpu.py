@@ -195,6 +195,52 @@ def test_cfg5_moving_sphere_sequence(pkg, oracle, ctx):
         assert got["shared_macroblock_percentage"] > 0.9 and got["convergence_count"] > 300
 
 
+def test_cfg5_at_its_stated_size(pkg, oracle, ctx):
+    """SURVEY.md 8(d) cfg5 as BASELINE.json states it: 30 frames of 200 000 points, sphere shell moving +0.002 in x
+    per frame, 8-bit octree, macroblock 16, run like the reference app's loop with do_delta_coding=1 (eval.hpp:853-890):
+    every frame intra coded (frame ids 1..30), every frame but the first also predicted from the encoder's simplified
+    cloud of the frame before (eval.hpp:862).
+      * every intra bitstream and simplified cloud: bit-exact against the oracle;
+      * every P frame: chunk stream, residual intra stream, predicted cloud and the decoder's output bit-exact against
+        oracle/delta_oracle.py given the transforms the GPU's ICP produced;
+      * ICP (PCL's, outside the reference tree: statistical parity only): shared-block share equal, convergence share
+        and predicted-part size within 2 % of the oracle's own ICP, on every fifth P frame."""
+    cfg = dict(pkg.synthetic.CONFIGS["cfg5"])
+    frames = pkg.synthetic.moving_sphere_group(cfg["n"], cfg["seed"], cfg["frames"])
+    assert len(frames) == 30 and all(len(f) == 200_000 for f in frames)
+    res = 2.0 ** -cfg["octree_bits"]
+    kw = dict(octree_bits=cfg["octree_bits"], color_bits=8, color_coding_type=1, jpeg_quality=85)
+    prm = pkg.binding.make_params(**kw)
+    prm.macroblock_size = cfg["macroblock_size"]
+    prev = None
+    p_bytes = i_bytes = intra_bytes = 0
+    for f, cloud in enumerate(frames):
+        if prev is not None:
+            got = ctx.encode_delta(prev, cloud, prm)
+            want = D.encode_delta(prev, cloud, res, res, icp_fn=_replay(got))
+            assert got["p_stream"] == want["p_stream"] and got["i_stream"] == want["i_stream"], f
+            assert got["out_cloud"].tobytes() == want["out_cloud"].tobytes(), f
+            dec = ctx.decode_delta(prev, got["i_stream"], got["p_stream"], prm)
+            ref = D.decode_delta(prev, want["i_stream"], want["p_stream"], res)
+            assert dec.tobytes() == ref.tobytes(), f
+            assert got["shared_macroblock_percentage"] > 0.95 and got["shared_macroblock_convergence_percentage"] > 0.85
+            p_bytes += len(got["p_stream"]); i_bytes += len(got["i_stream"])
+            if f % 5 == 1:
+                own = D.encode_delta(prev, cloud, res, res, write_out_cloud=False)   # the oracle's ICP
+                assert abs(float(own["shared_percentage"]) - got["shared_macroblock_percentage"]) < 1e-6
+                assert abs(float(own["convergence_percentage"]) - got["shared_macroblock_convergence_percentage"]) < 0.02
+                assert abs(len(own["p_stream"]) - len(got["p_stream"])) <= 0.02 * len(got["p_stream"]) + 40
+        prm.frame_id = f + 1
+        stream, _ = ctx.encode_intra_host(cloud, prm)
+        r = oracle.encode_intra(cloud, oracle.make_params(frame_id=f + 1, **kw))
+        assert stream == r.bitstream, f
+        prev = ctx.output_cloud()
+        assert prev.tobytes() == r.simplified.tobytes(), f
+        intra_bytes += len(stream)
+    # predictive coding pays on this sequence: a P frame is a fraction of an I frame
+    assert (p_bytes + i_bytes) / 29 < 0.4 * intra_bytes / 30
+
+
 @pytest.mark.parametrize("mb,on_original,waves", [(8, False, "4"), (32, False, "1"), (64, True, "1"), (128, True, "4")])
 def test_delta_other_macroblock_sizes_and_big_blocks(pkg, ctx, pair, mb, on_original, waves, monkeypatch):
     """Macroblock sizes other than 16; with 64-voxel blocks on the unsimplified cloud a block holds thousands of points

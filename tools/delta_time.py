@@ -30,16 +30,20 @@ def main():
         wall = (time.perf_counter() - t0) * 1e3
         if best is None or wall < best[0]:
             best = (wall, got["gpu_ms"])
-    t0 = time.perf_counter()
-    dec = ctx.decode_delta(i_cloud, got["i_stream"], got["p_stream"], prm)
-    dwall = (time.perf_counter() - t0) * 1e3
+    dwall = dcall = None
+    for r in range(reps):
+        t0 = time.perf_counter()
+        dec = ctx.decode_delta(i_cloud, got["i_stream"], got["p_stream"], prm)
+        w = (time.perf_counter() - t0) * 1e3
+        if dwall is None or w < dwall:
+            dwall, dcall = w, ctx.last_call_ms
     intra, _ = ctx.encode_intra_host(p_cloud, prm)
     blocks = got["blocks"]
     icp = blocks[blocks["do_icp"] != 0]
     print("points I %d P %d simplified %d; macroblocks %d shared %d predicted %d; ICP iterations mean %.1f max %d" % (
         len(i_cloud), len(p_cloud), got["n_simplified"], got["macro_block_count"], got["shared_macroblock_count"], got["convergence_count"],
         icp["iterations"].mean() if len(icp) else 0, icp["iterations"].max() if len(icp) else 0))
-    print("encode_delta: wall %.2f ms (best of %d), GPU events %.2f ms; decode_delta wall %.2f ms -> %d points" % (best[0], reps, best[1], dwall, len(dec)))
+    print("encode_delta: wall %.2f ms (best of %d), GPU events %.2f ms; decode_delta wall %.2f ms, of which pcc_decode_delta itself %.2f ms -> %d points" % (best[0], reps, best[1], dwall, dcall, len(dec)))
     print("bytes: intra part %d + predicted part %d = %d; the same frame intra coded %d" % (
         len(got["i_stream"]), len(got["p_stream"]), len(got["i_stream"]) + len(got["p_stream"]), len(intra)))
 
