@@ -30,7 +30,7 @@ EXPORTS = [
     "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
-    "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra",
+    "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra", "pcc_decode_intra_gpu", "pcc_get_decode_times",
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
@@ -72,6 +72,7 @@ class HotResult(C.Structure):
         ("image_w", C.c_uint32), ("image_h", C.c_uint32), ("gpu_ms", C.c_float), ("jpeg_coefs", C.c_void_p),
         ("jpeg_tiles", C.c_void_p), ("jpeg_tile_words", C.c_uint32), ("jpeg_n_tiles", C.c_uint32),
         ("occupancy_histogram", C.c_void_p),
+        ("jpeg_lines_dir", C.c_void_p), ("jpeg_lines_data", C.c_void_p), ("jpeg_n_lines", C.c_uint32),
     ]
 
 
@@ -154,6 +155,8 @@ def load_library():
                                             C.POINTER(C.POINTER(Bitstream))]
     lib.pcc_get_output_cloud.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     lib.pcc_decode_intra.argtypes = [vp, vp, sz, C.POINTER(Cloud)]
+    lib.pcc_decode_intra_gpu.argtypes = [vp, vp, sz, C.POINTER(Cloud)]
+    lib.pcc_get_decode_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.pcc_device_free.argtypes = [vp, vp]
     lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
@@ -366,14 +369,22 @@ class Context:
         self._check(self.lib.pcc_get_output_cloud(self.h, C.byref(p), C.byref(n)))
         return np.frombuffer(_bytes_at(p, 32 * n.value), dtype=POINT_DTYPE).copy()
 
-    def decode_intra(self, stream: bytes):
+    def decode_intra(self, stream: bytes, on_gpu=False):
+        """decodePointCloud; on_gpu: the data-parallel half runs on the GPU (pcc_decode_intra_gpu), same cloud."""
         src = np.frombuffer(stream, dtype=np.uint8)
         c = Cloud()
-        self._check(self.lib.pcc_decode_intra(self.h, src.ctypes.data, len(src), C.byref(c)))
+        fn = self.lib.pcc_decode_intra_gpu if on_gpu else self.lib.pcc_decode_intra
+        self._check(fn(self.h, src.ctypes.data, len(src), C.byref(c)))
         pts = np.frombuffer(_bytes_at(c.points, 32 * c.n), dtype=POINT_DTYPE).copy()
         info = dict(bbox=np.array(list(c.bbox)), depth=int(c.depth), consumed=int(c.consumed),
                     params={k: getattr(c.params, k) for k, _ in Params._fields_})
         return pts, info
+
+    def decode_times(self):
+        """ms of the last decode_intra(on_gpu=True): sequential host stages, upload + kernels + download, whole call."""
+        buf = (C.c_double * 3)()
+        self._check(self.lib.pcc_get_decode_times(self.h, buf))
+        return dict(host_sequential_ms=buf[0], gpu_ms=buf[1], total_ms=buf[2])
 
     def quality_metrics(self, cloud_a: np.ndarray, cloud_b: np.ndarray, cell_hint=0.0):
         """computeQualityMetric(original, decoded) (quality_metrics_impl.hpp:82-239) as a dict."""

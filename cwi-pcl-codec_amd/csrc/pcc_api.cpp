@@ -20,6 +20,7 @@
 #include "pcc_host_codec.h"
 #include "pcc_kernels.h"
 #include "pcc_quality.h"
+#include "pcc_decode.h"
 #include "pcc_delta.h"
 #include "pcc_rc_device.h"
 
@@ -102,6 +103,9 @@ struct pcc_ctx {
   DevBuf<uint8_t> d_occ;
   size_t out_off = 0;  // bytes of the records region of the frame in flight = offset of its occupancy bytes
   DevBuf<float> d_simplified;  // 4 floats per leaf
+  DevBuf<uint32_t> d_lines;    // colour coding type 2: directory (4 words per strip) | the strips' bit strings
+  PinnedBuf<uint32_t> h_lines;
+  size_t lines_dir_words = 0;  // of the frame in flight
   DevBuf<int16_t> d_coefs;     // JPEG coefficients of the snake image
   DevBuf<JpegHuffTables> d_huff;
   bool huff_uploaded = false;
@@ -140,6 +144,15 @@ struct pcc_ctx {
   bool copy_image = true;
   std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
   std::vector<pcc_point_xyzrgb> dec_points;  // decodePointCloud()
+  // decodePointCloud with the data-parallel half on the GPU (pcc_decode_intra_gpu)
+  FrameStreams dec_streams;
+  LeafParents dec_parents;
+  BaselineJpeg::JpegCoefs dec_coefs;
+  DevBuf<uint8_t> d_dec;             // one arena: prefixes | first | bits | centroid | colours | coefficients | planes
+  DevBuf<uint8_t> d_dec_points;
+  PinnedBuf<uint8_t> h_dec_stage;    // the same inputs on the host side, page-locked: one upload
+  PinnedBuf<pcc_point_xyzrgb> h_dec_points;
+  double dec_ms[4] = {0, 0, 0, 0};   // last pcc_decode_intra_gpu: sequential host stages, upload + kernels + download, total
   Bytes bitstream;
   double host_us[4] = {0, 0, 0, 0};  // last entropy stage: occupancy coder, JPEG, colour coder, total
 
@@ -380,10 +393,11 @@ void pcc_destroy(pcc_ctx* c) {
             c->usual_wait_ns[1] / 1e3, c->usual_wait_ns[2] / 1e3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->locked_host) { unlock_host_range(c->locked_host); c->locked_host = nullptr; }
+  c->d_dec.release(); c->d_dec_points.release(); c->h_dec_stage.release(); c->h_dec_points.release();
   c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
-  c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release();
+  c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release(); c->d_lines.release(); c->h_lines.release();
   c->d_huff.release();
   c->d_qa.release(); c->d_qb.release(); c->d_qkeys.release(); c->d_qheads.release(); c->d_qnext.release();
   c->d_qidx.release(); c->d_qd2.release(); c->d_qpart.release();
@@ -525,6 +539,17 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   // the snake image itself only leaves the chip if somebody wants to look at it, or the host does the JPEG
   a.image = (a.lp.write_image && (ctx->copy_image || !a.coefs)) ? ctx->d_image.p : nullptr;
   a.jpeg_tiles = (a.coefs && ctx->jpeg_on_gpu >= 2) ? reinterpret_cast<uint32_t*>(ctx->d_occ.p) : nullptr;
+  ctx->lines_dir_words = 0;
+  if (a.lp.do_color && prm->color_coding_type == 2 && ctx->jpeg_on_gpu >= 2 && !simplify_only && !stop_after_leaf_scan) {
+    const size_t max_lines = std::max<size_t>(1, n / 2048);
+    ctx->lines_dir_words = 4 * max_lines;
+    const size_t cap = max_lines * (size_t)kJpegLineWords + (size_t)kJpegLineWords;  // the last strip may be two strips long
+    PCC_HIP(ctx->d_lines.ensure(ctx->lines_dir_words + cap));
+    a.jpeg_lines_dir = ctx->d_lines.p;
+    a.jpeg_lines_data = ctx->d_lines.p + ctx->lines_dir_words;
+    a.jpeg_lines_capacity = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
+    BaselineJpeg::quantiser(prm->jpeg_quality, a.jq.half, a.jq.magic);
+  }
   ctx->out_off = tiles_region(n);
   a.huff = ctx->d_huff.p;
   if (box) a.box = *box;
@@ -703,7 +728,11 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   if (tiles_too) PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, off + B, hipMemcpyDeviceToHost, ctx->stream));
   else PCC_HIP(hipMemcpyAsync(ctx->h_occ.p + off, ctx->d_occ.p + off, B, hipMemcpyDeviceToHost, ctx->stream));
   const uint32_t* h_tiles = reinterpret_cast<const uint32_t*>(ctx->h_occ.p);
-  const bool want_bgr = color && (prm.color_coding_type != 1 || ctx->copy_image);
+  const bool lines_on_gpu = ctx->lines_dir_words != 0 && color && prm.color_coding_type == 2;
+  // the per-voxel colours themselves only leave the chip if the host codes them (types 0, 3; type 2 without the GPU
+  // stage) or somebody wants to look at them
+  const bool want_bgr = color && (((prm.color_coding_type == 1 || lines_on_gpu) && ctx->copy_image) ||
+                                  (prm.color_coding_type != 1 && !lines_on_gpu));
   if (want_bgr) {
     PCC_HIP(ctx->h_bgr.ensure(3 * L + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_bgr.p, ctx->d_bgr.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
@@ -726,7 +755,23 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     PCC_HIP(ctx->h_centroid.ensure(3 * L + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_centroid.p, ctx->d_centroid.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
   }
+  const size_t n_lines = L / 2048 ? L / 2048 : 1;
+  if (lines_on_gpu) {  // directory and bit strings are one piece of HBM: one copy
+    const size_t words = ctx->lines_dir_words + st.jpeg_line_words;
+    PCC_HIP(ctx->h_lines.ensure(words + 16));
+    PCC_HIP(hipMemcpyAsync(ctx->h_lines.p, ctx->d_lines.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
   { const int wrc = wait_stream(ctx, 1); if (wrc != PCC_OK) return wrc; }
+  bool lines_ok = lines_on_gpu;
+  if (lines_on_gpu) {
+    for (size_t i = 0; i < n_lines; ++i)
+      if (ctx->h_lines.p[4 * i + 3] != 0) lines_ok = false;
+    if (!lines_ok) {  // cannot happen (the region holds the worst case); the host codes the strips from the colours then
+      PCC_HIP(ctx->h_bgr.ensure(3 * L + 16));
+      PCC_HIP(hipMemcpyAsync(ctx->h_bgr.p, ctx->d_bgr.p, 3 * L, hipMemcpyDeviceToHost, ctx->stream));
+      { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    }
+  }
 
   for (int a = 0; a < 3; ++a) { out->bbox[a] = st.mn[a]; out->bbox[3 + a] = st.mx[a]; }
   out->depth = (uint32_t)st.depth;
@@ -735,7 +780,10 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->n_leaves = L;
   out->n_branches = B;
   out->occupancy = ctx->h_occ.p + off;
-  out->bgr = want_bgr ? ctx->h_bgr.p : nullptr;
+  out->bgr = (want_bgr || (lines_on_gpu && !lines_ok)) ? ctx->h_bgr.p : nullptr;
+  out->jpeg_lines_dir = lines_ok ? ctx->h_lines.p : nullptr;
+  out->jpeg_lines_data = lines_ok ? ctx->h_lines.p + ctx->lines_dir_words : nullptr;
+  out->jpeg_n_lines = lines_ok ? (uint32_t)n_lines : 0u;
   out->centroid = prm.do_voxel_centroid ? ctx->h_centroid.p : nullptr;
   out->image = want_image ? ctx->h_image.p : nullptr;
   bool tiles_ok = tiles;
@@ -994,6 +1042,119 @@ int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud*
   out->points = ctx->dec_points.data();
   out->n = ctx->dec_points.size();
   if (rc != PCC_OK) return fail(ctx, rc, "decode: frame header not found, or stream truncated/corrupt");
+  return PCC_OK;
+}
+
+// decodePointCloud (impl.hpp:224-310) with everything behind the sequential stages on the GPU.  Falls back to the
+// host decoder for what the kernels do not cover (trees deeper than 21 levels, inconsistent vector lengths of a
+// corrupt stream): same results either way.
+int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud* out) {
+  if (!ctx || !out || (!stream && len)) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  auto ms_since = [&](const timespec& a) {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)(t.tv_sec - a.tv_sec) * 1e3 + (double)(t.tv_nsec - a.tv_nsec) * 1e-6;
+  };
+  FrameStreams& fs = ctx->dec_streams;
+  LeafParents& lp = ctx->dec_parents;
+  int rc;
+  bool host_only = false;
+  try {
+    rc = decode_frame_streams(stream, len, *out, fs, false);
+    if (rc != PCC_OK) return fail(ctx, rc, "decode: frame header not found, or stream truncated/corrupt");
+    const size_t L = (size_t)fs.count;
+    int img_w = 0, img_h = 0;
+    const bool jpeg = fs.with_color && fs.cct == 1;
+    if (out->depth > (uint32_t)kMaxDepth || L >= (1ull << 31) || L == 0) host_only = true;
+    if (!host_only && out->params.do_voxel_centroid && fs.cen.size() < 3 * L) host_only = true;
+    if (!host_only && fs.with_color && !jpeg && fs.col.size() < 3 * L) host_only = true;
+    if (!host_only && jpeg) {
+      if (!BaselineJpeg::decode_coefs(fs.payload.data(), fs.payload.size(), img_w, img_h, ctx->dec_coefs) || img_w % 8 != 0 ||
+          (size_t)img_w * (size_t)img_h < L)
+        host_only = true;
+    }
+    if (!host_only) {
+      rc = walk_leaf_parents(fs.occ, out->depth, fs.count, lp);
+      if (rc != PCC_OK) return fail(ctx, rc, "decode: occupancy stream does not describe the announced number of voxels");
+    }
+    if (host_only) {
+      rc = decode_frame(stream, len, ctx->dec_points, *out);
+      out->points = ctx->dec_points.data();
+      out->n = ctx->dec_points.size();
+      if (rc != PCC_OK) return fail(ctx, rc, "decode: frame header not found, or stream truncated/corrupt");
+      return PCC_OK;
+    }
+    ctx->dec_ms[0] = ms_since(t0);
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    PCC_HIP(hipSetDevice(ctx->device));
+    // one staging buffer, one upload
+    const size_t np = lp.prefix.size();
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_prefix = 0, o_first = up16(o_prefix + 8 * np), o_bits = up16(o_first + 4 * np);
+    const size_t o_cen = up16(o_bits + np), n_cen = out->params.do_voxel_centroid ? 3 * L : 0;
+    const size_t o_col = up16(o_cen + n_cen), n_col = (fs.with_color && !jpeg) ? 3 * L : 0;
+    const size_t o_coef = up16(o_col + n_col), n_coef = jpeg ? ctx->dec_coefs.blocks.size() * sizeof(int16_t) : 0;
+    const size_t staged = up16(o_coef + n_coef);
+    const size_t mx = jpeg ? (size_t)ctx->dec_coefs.mcus_x : 0, my = jpeg ? (size_t)ctx->dec_coefs.mcus_y : 0;
+    const size_t o_py = staged, o_pcb = up16(o_py + 256 * mx * my), o_pcr = up16(o_pcb + 64 * mx * my), total = up16(o_pcr + 64 * mx * my);
+    PCC_HIP(ctx->h_dec_stage.ensure(staged + 16));
+    PCC_HIP(ctx->d_dec.ensure(total + 16));
+    PCC_HIP(ctx->d_dec_points.ensure(32 * L + 32));
+    PCC_HIP(ctx->h_dec_points.ensure(L + 1));
+    uint8_t* h = ctx->h_dec_stage.p;
+    memcpy(h + o_prefix, lp.prefix.data(), 8 * np);
+    memcpy(h + o_first, lp.first.data(), 4 * np);
+    memcpy(h + o_bits, lp.bits.data(), np);
+    if (n_cen) memcpy(h + o_cen, fs.cen.data(), n_cen);
+    if (n_col) memcpy(h + o_col, fs.col.data(), n_col);
+    if (n_coef) memcpy(h + o_coef, ctx->dec_coefs.blocks.data(), n_coef);
+    PCC_HIP(hipMemcpyAsync(ctx->d_dec.p, h, staged, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d = ctx->d_dec.p;
+    DecodeArgs da{};
+    if (jpeg) {
+      IdctArgs ia{};
+      ia.blocks = reinterpret_cast<const int16_t*>(d + o_coef);
+      memcpy(ia.q, ctx->dec_coefs.q, sizeof(ia.q));
+      ia.mcus_x = (uint32_t)mx; ia.mcus_y = (uint32_t)my;
+      ia.plane_y = d + o_py; ia.plane_cb = d + o_pcb; ia.plane_cr = d + o_pcr;
+      launch_decode_idct(ia, ctx->stream);
+      da.plane_y = ia.plane_y; da.plane_cb = ia.plane_cb; da.plane_cr = ia.plane_cr;
+      da.img_w = (uint32_t)img_w; da.img_h = (uint32_t)img_h;
+      da.y_stride = (uint32_t)(16 * mx); da.c_stride = (uint32_t)(8 * mx);
+    }
+    da.prefix = reinterpret_cast<const uint64_t*>(d + o_prefix);
+    da.first = reinterpret_cast<const uint32_t*>(d + o_first);
+    da.bits = d + o_bits;
+    da.n_parents = (uint32_t)np;
+    da.n_leaves = (uint32_t)L;
+    da.res = out->params.octree_resolution;
+    for (int a = 0; a < 3; ++a) da.mn[a] = out->bbox[a];
+    da.centroid = n_cen ? d + o_cen : nullptr;
+    da.colours = n_col ? d + o_col : nullptr;
+    da.colour_shift = (fs.cct == 0) ? (uint32_t)(8 - out->params.color_bit_resolution) & 7u : 0u;
+    da.with_colour = fs.with_color ? 1 : 0;
+    da.points = ctx->d_dec_points.p;
+    launch_decode_points(da, ctx->stream);
+    PCC_HIP(hipGetLastError());
+    PCC_HIP(hipMemcpyAsync(ctx->h_dec_points.p, ctx->d_dec_points.p, 32 * L, hipMemcpyDeviceToHost, ctx->stream));
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    ctx->dec_ms[1] = ms_since(t1);
+    ctx->dec_ms[2] = ms_since(t0);
+    out->points = ctx->h_dec_points.p;
+    out->n = L;
+    return PCC_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, PCC_ERR_STREAM, "decode: the stream asks for more memory than there is");
+  }
+}
+
+int pcc_get_decode_times(pcc_ctx* ctx, double out_ms[3]) {
+  if (!ctx || !out_ms) return PCC_ERR_ARG;
+  for (int i = 0; i < 3; ++i) out_ms[i] = ctx->dec_ms[i];
   return PCC_OK;
 }
 
@@ -1384,6 +1545,15 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   PCC_HIP(hipSetDevice(ctx->device));
   ctx->delta_cloud_n = 0;
   bool delta_copy_pending = false;
+  static const bool trace = getenv("PCC_TRACE_DELTA") != nullptr;  // developer knob: where the call's time goes
+  timespec tr0;
+  clock_gettime(CLOCK_MONOTONIC, &tr0);
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[pcc_decode_delta] %-28s %8.3f ms\n", what, (double)(t.tv_sec - tr0.tv_sec) * 1e3 + (double)(t.tv_nsec - tr0.tv_nsec) * 1e-6);
+  };
   size_t out_n = 0;
   if (n_i && p_len) {
     { const int rc = delta_subcontexts(ctx); if (rc != PCC_OK) return rc; }
@@ -1391,10 +1561,12 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
     PCC_HIP(ctx->d_delta_i.ensure(32 * n_i));
     PCC_HIP(hipMemcpyAsync(ctx->d_delta_i.p, i_cloud, 32 * n_i, hipMemcpyHostToDevice, ctx->stream));
     { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+    mark("I cloud uploaded");
     int rc = launch_block_tree(s_it, ctx->d_delta_i.p, n_i, 32, 16, cp.octree_resolution * (double)cp.macroblock_size);
     if (rc != PCC_OK) return fail(ctx, rc, "I macroblock tree: " + s_it->err);
     DeltaArgs da{};
     rc = block_tree_of(ctx, s_it, ctx->d_delta_i.p, 32, 16, da.i_tree);
+    mark("I macroblock tree");
     if (rc == PCC_OK) {
       const uint32_t nbi = da.i_tree.n_blocks;
       PCC_HIP(ctx->d_ifull.ensure(nbi));
@@ -1407,6 +1579,7 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
       PCC_HIP(hipMemcpyAsync(ctx->h_ifull.data(), ctx->d_ifull.p, (size_t)nbi * 8, hipMemcpyDeviceToHost, ctx->stream));
       PCC_HIP(hipMemcpyAsync(ctx->h_istart.data(), da.i_tree.leaf_start, ((size_t)nbi + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
       { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+      mark("block keys on the host");
       // the chunks (impl.hpp:1135-1200)
       ctx->h_blocks.clear();
       ctx->h_mdec.clear();
@@ -1439,6 +1612,7 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
         out_n += r.n_i;
       }
       const uint32_t nch = (uint32_t)ctx->h_blocks.size();
+      mark("chunks parsed");
       if (nch) {
         ctx->h_dst_intra.assign(nch, 0xffffffffu);
         ctx->h_pstart.assign((size_t)nch + 1, 0u);
@@ -1470,6 +1644,7 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
         PCC_HIP(hipMemcpyAsync(ctx->delta_cloud.p, ctx->d_delta_out.p, 32 * out_n, hipMemcpyDeviceToHost, ctx->stream));
         // the copy lands while the host decodes the intra part below
         delta_copy_pending = true;
+        mark("gather enqueued");
       }
     } else if (rc != PCC_ERR_EMPTY) {
       return rc;
@@ -1487,6 +1662,7 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
     if (rc != PCC_OK) return fail(ctx, rc, "decode: intra part of the delta frame: header not found, or stream truncated/corrupt");
     out->params = ic.params; out->depth = ic.depth; out->consumed = ic.consumed;
     for (int a = 0; a < 6; ++a) out->bbox[a] = ic.bbox[a];
+    mark("intra part decoded");
     const size_t n_intra = ctx->dec_points.size();
     if (ctx->delta_cloud.cap < ctx->delta_cloud_n + n_intra + 1) {  // grow, keeping the predicted points
       if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; delta_copy_pending = false; }
@@ -1500,6 +1676,8 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
     ctx->delta_cloud_n += n_intra;
   }
   if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; delta_copy_pending = false; }
+  mark("done");
   out->points = ctx->delta_cloud.p;
   out->n = ctx->delta_cloud_n;
   return PCC_OK;

@@ -253,13 +253,30 @@ size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, 
   for (int i = 0; i < 4; ++i) code = (code << 8) | in[pos++];
   const uint32_t total = freq[256];
   if (total == 0) return 0;
+  // PCL finds the symbol of a cumulative count by an eight-step binary search; each step is an unpredictable branch,
+  // most of the decoder's time.  The encoder keeps the total below 2^16 (it halves the table otherwise), so a table
+  // count -> symbol of at most 64 K entries answers in one load; any other table (foreign or corrupt stream) takes the
+  // search.  The table must be non-decreasing for the two to agree: checked.
+  bool monotone = true;
+  for (int k = 0; k < 256; ++k) monotone &= freq[k] <= freq[k + 1];
+  std::vector<uint8_t> lut;
+  if (monotone && freq[0] == 0 && total <= 65536u && n >= 4096) {
+    lut.resize(total);
+    for (unsigned sy = 0; sy < 256; ++sy)
+      if (freq[sy + 1] > freq[sy]) memset(lut.data() + freq[sy], (int)sy, freq[sy + 1] - freq[sy]);
+  }
+  const uint8_t* const table = lut.empty() ? nullptr : lut.data();
   for (size_t i = 0; i < n; ++i) {
     range /= total;
     if (range == 0) return 0;  // corrupt table: PCL would divide by zero here
     const uint32_t count = (code - low) / range;
     unsigned sym = 0;
-    for (unsigned step = 128; step; step >>= 1)
-      if (freq[sym + step] <= count) sym += step;
+    if (table && count < total) {
+      sym = table[count];  // the largest symbol whose cumulative count does not exceed `count`, as the search finds it
+    } else {
+      for (unsigned step = 128; step; step >>= 1)
+        if (freq[sym + step] <= count) sym += step;
+    }
     out[i] = (uint8_t)sym;
     low += freq[sym] * range;
     range *= freq[sym + 1] - freq[sym];
@@ -633,6 +650,21 @@ bool BaselineJpeg::encode_tiles(const uint32_t* tiles, uint32_t tile_words, uint
   return true;
 }
 
+void BaselineJpeg::wrap_bits(const uint32_t* words, uint32_t n_bits, int w, int h, int quality, Bytes& out) {
+  const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
+  put_headers(out, w, h, ql, qc);
+  BitSink bs(out);
+  bs.start();
+  uint32_t p = 0;
+  while (p < n_bits) {  // at most 24 bits at a time (BitSink::put)
+    const uint32_t off = p & 31u, take = std::min(std::min(n_bits - p, 32u - off), 24u);
+    bs.put(words[p >> 5] >> (32u - off - take), (int)take);
+    p += take;
+  }
+  bs.flush();
+  be16(out, 0xFFD9);
+}
+
 void BaselineJpeg::encode_coefs(const int16_t* coefs, int w, int h, int quality, Bytes& out) {
   const Quant ql(kLumaQ, quality), qc(kChromaQ, quality);
   static const HuffEnc dcl(kDcLuma), acl(kAcLuma), dcc(kDcChroma), acc(kAcChroma);
@@ -846,6 +878,13 @@ void idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t* dst, int 
 }  // namespace
 
 bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h) {
+  return decode_impl(jpg, len, &rgb, w, h, nullptr);
+}
+bool BaselineJpeg::decode_coefs(const uint8_t* jpg, size_t len, int& w, int& h, JpegCoefs& out) {
+  return decode_impl(jpg, len, nullptr, w, h, &out);
+}
+
+bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, int& w, int& h, JpegCoefs* coefs_out) {
   uint16_t qt[4][64] = {};
   HuffDec hd[2][4];
   int restart = 0;
@@ -912,13 +951,23 @@ bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w
   const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
   const int cw = (w + 1) / 2, chh = (h + 1) / 2;
   const int yw = mcus_x * 16, cpw = mcus_x * 8;
-  std::vector<uint8_t> Y((size_t)yw * mcus_y * 16), C0((size_t)cpw * mcus_y * 8), C1((size_t)cpw * mcus_y * 8);
+  std::vector<uint8_t> Y, C0, C1;
+  if (coefs_out) {  // entropy decoding only: the quantised coefficients, six blocks per MCU (Y00 Y01 Y10 Y11 Cb Cr), natural order
+    coefs_out->blocks.assign((size_t)mcus_x * mcus_y * 6 * 64, 0);
+    for (int k = 0; k < 64; ++k) { coefs_out->q[0][k] = qt[tq[0]][k]; coefs_out->q[1][k] = qt[tq[1]][k]; coefs_out->q[2][k] = qt[tq[2]][k]; }
+    coefs_out->mcus_x = mcus_x; coefs_out->mcus_y = mcus_y;
+  } else {
+    Y.resize((size_t)yw * mcus_y * 16); C0.resize((size_t)cpw * mcus_y * 8); C1.resize((size_t)cpw * mcus_y * 8);
+  }
   uint8_t* C[2] = {C0.data(), C1.data()};
   BitSource br{jpg, len, pos};
   int last_dc[3] = {0, 0, 0}, count = 0, next_rst = 0;
-  int16_t blk[64];
+  int16_t blk_local[64];
+  int16_t* blk = blk_local;
+  size_t blocks_done = 0;
   auto one_block = [&](int c, uint8_t* dst, int stride) {
-    memset(blk, 0, sizeof(blk));
+    if (coefs_out) blk = coefs_out->blocks.data() + 64 * blocks_done++;
+    memset(blk, 0, 64 * sizeof(int16_t));
     int sz = br.sym(hd[0][tdc[c]]);
     if (sz > 16) sz = 0;  // corrupt table: libjpeg treats a bad code as zero as well
     last_dc[c] = (int16_t)(last_dc[c] + (sz ? extend_sign(br.bits(sz), sz) : 0));  // stays in range on corrupt data too
@@ -935,7 +984,7 @@ bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w
         break;
       }
     }
-    idct_block(blk, qt[tq[c]], dst, stride);
+    if (!coefs_out) idct_block(blk, qt[tq[c]], dst, stride);
   };
   for (int my = 0; my < mcus_y; ++my)
     for (int mx = 0; mx < mcus_x; ++mx) {
@@ -947,11 +996,13 @@ bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w
         last_dc[0] = last_dc[1] = last_dc[2] = 0;
       }
       for (int yi = 0; yi < 2; ++yi)
-        for (int xi = 0; xi < 2; ++xi) one_block(0, Y.data() + (size_t)(16 * my + 8 * yi) * yw + 16 * mx + 8 * xi, yw);
-      one_block(1, C[0] + (size_t)8 * my * cpw + 8 * mx, cpw);
-      one_block(2, C[1] + (size_t)8 * my * cpw + 8 * mx, cpw);
+        for (int xi = 0; xi < 2; ++xi) one_block(0, coefs_out ? nullptr : Y.data() + (size_t)(16 * my + 8 * yi) * yw + 16 * mx + 8 * xi, yw);
+      one_block(1, coefs_out ? nullptr : C[0] + (size_t)8 * my * cpw + 8 * mx, cpw);
+      one_block(2, coefs_out ? nullptr : C[1] + (size_t)8 * my * cpw + 8 * mx, cpw);
       ++count;
     }
+  if (coefs_out) return true;
+  Bytes& rgb = *rgb_out;
 
   // chroma upsampling (jdsample.c): triangle filter if downsampled_width > 2, else replication
   const int uw = cpw * 2;
@@ -1067,10 +1118,15 @@ void colour_payload(const pcc_hot_result& hot, const pcc_params& prm, Bytes& pay
     const uint32_t count = lines ? (uint32_t)lines : 1u;
     put_le<uint32_t>(payload, count);
     Bytes one;
+    const bool from_gpu = hot.jpeg_lines_dir && hot.jpeg_lines_data && hot.jpeg_n_lines == count;
     for (uint32_t i = 0; i < count; ++i) {
       const size_t start = (size_t)2048 * i;
       const size_t width = lines == 0 ? L : (i + 1 != count ? 2048 : L - start);
       one.clear();
+      if (from_gpu) {  // entropy-coded on the GPU: headers, 0xFF stuffing and the end marker are added here
+        const uint32_t* d = hot.jpeg_lines_dir + 4 * (size_t)i;
+        BaselineJpeg::wrap_bits(hot.jpeg_lines_data + d[0], d[1], (int)width, 1, prm.jpeg_quality, one);
+      } else
       BaselineJpeg::encode_rgb(hot.bgr + 3 * start, (int)width, 1, prm.jpeg_quality, one);
       put_le<uint32_t>(payload, (uint32_t)one.size());
       payload.insert(payload.end(), one.begin(), one.end());
@@ -1196,9 +1252,8 @@ struct Reader {
 };
 }  // namespace
 
-int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info) {
+int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too) {
   memset(&info, 0, sizeof(info));
-  points.clear();
   Reader r{stream, len, 0};
   if (!r.sync(kV2Id) || !r.sync(kV1Id)) return PCC_ERR_STREAM;
   pcc_params& p = info.params;
@@ -1246,11 +1301,13 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
 
   uint64_t occ_n = 0;
   if (!r.get(occ_n) || occ_n > len * 64 + 64) return PCC_ERR_STREAM;
-  Bytes occ((size_t)occ_n);
+  Bytes& occ = fs.occ;
+  occ.resize((size_t)occ_n);
   size_t used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, occ.data(), occ.size());
   if (!used) return PCC_ERR_STREAM;
   r.pos += used;
-  Bytes cen;
+  Bytes& cen = fs.cen;
+  cen.clear();
   if (p.do_voxel_centroid) {
     uint32_t n = 0;
     if (!r.get(n) || n > len * 64 + 64) return PCC_ERR_STREAM;
@@ -1259,15 +1316,20 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
     if (!used) return PCC_ERR_STREAM;
     r.pos += used;
   }
-  Bytes col;
+  Bytes& col = fs.col;
+  col.clear();
+  fs.payload.clear();
   if (with_color) {
     uint64_t n = 0;
     if (!r.get(n) || n > len * 64 + 64) return PCC_ERR_STREAM;
-    Bytes payload((size_t)n);
+    Bytes& payload = fs.payload;
+    payload.resize((size_t)n);
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, payload.data(), payload.size());
     if (!used) return PCC_ERR_STREAM;
     r.pos += used;
-    if (cct == 1) {  // decodeJPEGSnake (jpegcc.h:228-242)
+    if (!colours_too && cct == 1) {
+      // the caller takes the JPEG from fs.payload (the GPU decoder: inverse DCT, upsampling and un-snaking on the device)
+    } else if (cct == 1) {  // decodeJPEGSnake (jpegcc.h:228-242)
       Bytes img;
       int w = 0, h = 0;
       if (BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h) && w % 8 == 0) {
@@ -1295,7 +1357,58 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
     }
   }
   info.consumed = r.pos;
+  fs.count = count;
+  fs.with_color = with_color != 0;
+  fs.cct = cct;
+  return PCC_OK;
+}
 
+// The leaf parents of the depth-first occupancy stream: a node of level D-1 has its voxels as children, so everything
+// a voxel needs is its parent's key, its parent's byte and how many voxels came before.  The walk is the sequential
+// part of deserializeTree (the level of a byte depends on every byte before it); it visits branch nodes only.
+int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents& lp) {
+  lp.prefix.clear(); lp.bits.clear(); lp.first.clear();
+  if (D == 0 || D > 21 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
+  uint8_t rem[24];
+  int sp = 0;
+  size_t op = 0;
+  uint64_t prefix = 0, leaves = 0;
+  rem[0] = occ[op++];
+  while (sp >= 0) {
+    if ((unsigned)sp == D - 1) {
+      lp.prefix.push_back(prefix);
+      lp.bits.push_back(rem[sp]);
+      lp.first.push_back((uint32_t)leaves);
+      leaves += (uint64_t)__builtin_popcount(rem[sp]);
+      if (leaves > count) return PCC_ERR_STREAM;
+      --sp; prefix >>= 3;
+      continue;
+    }
+    if (!rem[sp]) { --sp; prefix >>= 3; continue; }
+    const int c = __builtin_ctz(rem[sp]);
+    rem[sp] = (uint8_t)(rem[sp] & (rem[sp] - 1));
+    if (op >= occ.size()) return PCC_ERR_STREAM;
+    prefix = (prefix << 3) | (uint64_t)c;
+    rem[++sp] = occ[op++];
+  }
+  return leaves == count ? PCC_OK : PCC_ERR_STREAM;
+}
+
+
+int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info) {
+  points.clear();
+  FrameStreams fs;
+  {
+    const int rc = decode_frame_streams(stream, len, info, fs, true);
+    if (rc != PCC_OK) return rc;
+  }
+  const pcc_params& p = info.params;
+  const uint64_t count = fs.count;
+  const bool with_color = fs.with_color;
+  const uint32_t cct = fs.cct;
+  const double res = p.octree_resolution;
+  const Bytes &occ = fs.occ, &cen = fs.cen, &col = fs.col;
+  const uint64_t occ_n = occ.size();
   // deserializeTree: pre-order walk with an explicit stack (Appendix B), leaves in Morton order
   if (count > 8 * occ_n) return PCC_ERR_STREAM;  // a tree of occ_n branch nodes has at most eight leaves per node: corrupt header
   points.resize((size_t)count);

@@ -55,11 +55,25 @@ class BaselineJpeg {
   // Same file from the per-MCU-row bit strings of the GPU Huffman stage (layout: pcc_hot_result.jpeg_tiles).
   // Returns false if a row did not fit its record (then the caller Huffman-codes the coefficients instead).
   static bool encode_tiles(const uint32_t* tiles, uint32_t tile_words, uint32_t n_tiles, int w, int h, int quality, Bytes& out);
+  // A complete JPEG file around an entropy-coded bit string that the GPU produced for a whole image (colour coding type
+  // 2: one strip): headers, the bits with 0xFF stuffing, padding, end marker.
+  static void wrap_bits(const uint32_t* words, uint32_t n_bits, int w, int h, int quality, Bytes& out);
   // The Huffman tables of jpeg_set_defaults as (length << 16 | code): dc[component][size], ac[component][run << 4 | size]
   static void huffman_tables(uint32_t dc[2][12], uint32_t ac[2][256]);
   // The quantiser the GPU front end needs for `quality` (natural order; see pcc_kernels.h JpegQuant)
   static void quantiser(int quality, uint16_t half[2][64], uint32_t magic[2][64]);
   static bool decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h);
+  // Entropy decoding only (the sequential part of a JPEG decoder): quantised coefficients, six blocks of 64 per MCU
+  // (Y00 Y01 Y10 Y11 Cb Cr) in natural order, and the quantisation tables of the three components.
+  struct JpegCoefs {
+    std::vector<int16_t> blocks;
+    uint16_t q[3][64];
+    int mcus_x = 0, mcus_y = 0;
+  };
+  static bool decode_coefs(const uint8_t* jpg, size_t len, int& w, int& h, JpegCoefs& out);
+
+ private:
+  static bool decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, int& w, int& h, JpegCoefs* coefs_out);
 };
 
 // SnakeGridMapping (snake.h): position of linear element i in a w x h image (w multiple of 8)
@@ -76,5 +90,22 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
 
 // decodePointCloud (impl.hpp:224-310); returns PCC_OK or PCC_ERR_STREAM
 int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info);
+
+// The two sequential halves of decode_frame, for the decoder that does the rest on the GPU (pcc_decode_intra_gpu):
+// header + the three range-coded vectors (+ the per-voxel colour bytes unless `colours_too` is false and the colours are
+// one snake-mapped JPEG, which then stays in `payload`), and the walk over the occupancy stream.
+struct FrameStreams {
+  uint64_t count = 0;  // voxels announced by the header
+  bool with_color = false;
+  uint32_t cct = 0;
+  Bytes occ, cen, col, payload;
+};
+int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too);
+struct LeafParents {             // per node of level D-1, in stream order:
+  std::vector<uint64_t> prefix;  //   its key, 3 bits per level, x-major triples
+  std::vector<uint8_t> bits;     //   its occupancy byte = which of its eight voxels exist
+  std::vector<uint32_t> first;   //   how many voxels the nodes before it hold
+};
+int walk_leaf_parents(const Bytes& occ, unsigned depth, uint64_t count, LeafParents& lp);
 
 }  // namespace pcc

@@ -47,6 +47,8 @@ struct JpegQuant {
 constexpr int kJpegTileWords = 512;
 constexpr int kJpegTileHeader = 16;
 constexpr int kJpegTileBits = (kJpegTileWords - kJpegTileHeader) * 32;
+// "lines" mode: a strip has at most 256 MCUs = 1536 blocks of at most 219 bits
+constexpr int kJpegLineWords = (1536 * 219 + 31) / 32 + 15;
 // Huffman tables as (length << 16 | code): DC [component][size 0..11], AC [component][run << 4 | size]
 struct JpegHuffTables {
   uint32_t dc[2][12];
@@ -87,6 +89,10 @@ struct HotPathArgs {
   JpegQuant jq;
   uint32_t* jpeg_tiles;          // per-MCU-row Huffman records (null: Huffman coding on the host)
   const JpegHuffTables* huff;    // device copy of the standard tables
+  // colour coding type 2 on the GPU: directory {word offset, bits, width, overflow} per strip and the strips' bit strings
+  uint32_t* jpeg_lines_dir;
+  uint32_t* jpeg_lines_data;
+  uint32_t jpeg_lines_capacity;  // words
   std::vector<const char*>* span_names;  // profiling: kernel name of every span slot, in launch order (host side)
   unsigned long long* spans;     // profiling: kMaxSpans x 2 x kSpanShards words {workgroup starts | ~(wave ends)} in launch order, preset to ~0 (null: off)
 };

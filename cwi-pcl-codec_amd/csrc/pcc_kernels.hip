@@ -428,6 +428,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
   //         to the first one that was not there yet.
   if (threadIdx.x == 0) s_nfin = 0;
   st->occ_hist[threadIdx.x] = 0u;  // kBlock = 256 threads: one counter each (filled by k_occ_histogram at the end of the frame)
+  if (threadIdx.x == 0) st->jpeg_line_words = 0u;
   int first = 0x7fffffff, cand = 0x7fffffff;
   unsigned nfin = 0;
   float g[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -976,6 +977,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_pass(const uint64_t* buf_a, co
       }
     }
   }
+  PCC_KT(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1705,6 +1707,204 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
 }
 
 // ------------------------------------------------------------------------------------------
+// Colour coding type 2, "lines" (jpegcc.h:244-317): the per-voxel colours are cut into strips of 2048 voxels (the last
+// strip takes the remainder, 2048..4095; fewer than 2048 voxels make one strip) and every strip is a JPEG image of
+// its own, w x 1 pixels.  One workgroup per strip does what libjpeg does with such an image (jpeg_io.hpp:259-314):
+// the single row is repeated down the 16 rows of its MCU row (jcprepct.c), so every 8x8 block has eight equal rows and
+// only the first row of its DCT is non-zero: one 1-D FDCT per block, coefficient (0,c) = 2 * row_pass[c]; the second
+// luma block row of the MCU lies below the image and consists of dummy blocks (DC of the block before, no AC,
+// jccoefct.c).  Huffman coding (jchuff.c) per block by one thread; the DC chain never leaves the strip.
+// Output: the strip's bit string (MSB first in each u32) appended to `data` at a position taken from a cursor, and a
+// directory entry {word offset, bits, width, 0}; the host adds the headers and the 0xFF stuffing.
+// A block costs at most 22 + 7 * 26 + 11 + 4 = 219 bits, 1536 blocks at most: the LDS string cannot overflow.
+// ------------------------------------------------------------------------------------------
+constexpr int kLineThreads = 1024;
+constexpr int kLineMaxBlocks = 6 * 256;
+
+struct LineBlockCoder {  // the symbols of one block, either counted or written into the LDS bit string
+  uint32_t* bits;  // null: count only
+  uint32_t pos;
+  __device__ __forceinline__ void put(uint32_t code, uint32_t len) {
+    if (bits && len) {
+      const uint32_t off = pos & 31u;
+      if (off + len <= 32u) {
+        atomicOr(&bits[pos >> 5], code << (32u - off - len));
+      } else {
+        const uint32_t second = off + len - 32u;
+        atomicOr(&bits[pos >> 5], code >> second);
+        atomicOr(&bits[(pos >> 5) + 1u], code << (32u - second));
+      }
+    }
+    pos += len;
+  }
+};
+
+// jchuff.c encode_one_block for a block whose only non-zero coefficients are q[0] (DC) and q[1..7] = the rest of the
+// first row; zigzag positions of (0,1)..(0,7): 1, 5, 6, 14, 15, 27, 28
+__device__ __forceinline__ void code_line_block(LineBlockCoder& c, int dc_diff, const int* q, bool dummy, const uint32_t* s_hdc,
+                                                const uint32_t* s_hac, int comp) {
+  {
+    const uint32_t a = (uint32_t)(dc_diff < 0 ? -dc_diff : dc_diff);
+    const uint32_t nb = a ? 32u - (uint32_t)__clz((int)a) : 0u;
+    const uint32_t e = s_hdc[comp * 12 + nb];
+    c.put(e & 0xffffu, e >> 16);
+    if (nb) c.put((uint32_t)(dc_diff < 0 ? dc_diff - 1 : dc_diff) & ((1u << nb) - 1u), nb);
+  }
+  if (!dummy) {
+    constexpr int kZz[8] = {0, 1, 5, 6, 14, 15, 27, 28};
+    int prev = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const int v = q[k];
+      if (v == 0) continue;
+      int run = kZz[k] - prev - 1;
+      prev = kZz[k];
+      if (run >= 16) {
+        const uint32_t z = s_hac[comp * 256 + 0xF0];
+        c.put(z & 0xffffu, z >> 16);
+        run -= 16;
+      }
+      const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+      const uint32_t nb = 32u - (uint32_t)__clz((int)a);
+      const uint32_t e = s_hac[comp * 256 + ((uint32_t)run << 4 | nb)];
+      c.put(e & 0xffffu, e >> 16);
+      c.put((uint32_t)(v < 0 ? v - 1 : v) & ((1u << nb) - 1u), nb);
+    }
+  }
+  const uint32_t eob = s_hac[comp * 256];  // the last coefficient of a block is never reached: always an end-of-block
+  c.put(eob & 0xffffu, eob >> 16);
+}
+
+__global__ __launch_bounds__(kLineThreads) void k_jpeg_lines(FrameState* __restrict__ st, const uint8_t* __restrict__ bgr, JpegQuant jq,
+                                                             const JpegHuffTables* __restrict__ huff, uint32_t* __restrict__ dir,
+                                                             uint32_t* __restrict__ data, uint32_t capacity_words, unsigned long long* span) {
+  const KSpan kspan(span);
+  if (st->error != kErrNone || st->n_epochs == 0) return;
+  const uint32_t L = st->n_leaves;
+  const uint32_t lines = L / 2048u, count = lines ? lines : 1u;
+  const uint32_t line = blockIdx.x;
+  if (line >= count || L == 0) return;
+  const uint32_t start = 2048u * line;
+  const uint32_t width = lines == 0 ? L : (line + 1u != count ? 2048u : L - start);
+  const uint32_t mcus = (width + 15u) / 16u, nblk = 6u * mcus;
+
+  __shared__ __attribute__((aligned(16))) uint8_t s_px[3 * 4096 + 16];
+  __shared__ int s_dc[kLineMaxBlocks];
+  __shared__ uint32_t s_bits[kJpegLineWords];
+  __shared__ uint32_t s_hdc[2 * 12], s_hac[2 * 256];
+  __shared__ uint32_t s_scan[kLineThreads / 64];
+  __shared__ uint32_t s_where;
+
+  for (uint32_t k = threadIdx.x; k < (uint32_t)kJpegLineWords; k += kLineThreads) s_bits[k] = 0u;
+  for (uint32_t k = threadIdx.x; k < 24u; k += kLineThreads) s_hdc[k] = (&huff->dc[0][0])[k];
+  for (uint32_t k = threadIdx.x; k < 512u; k += kLineThreads) s_hac[k] = (&huff->ac[0][0])[k];
+  {
+    const uint32_t nbytes = 3u * width, ndw = nbytes >> 2;  // 3 * start is a multiple of 4
+    const uint8_t* src = bgr + 3 * (size_t)start;
+    for (uint32_t k = threadIdx.x; k < ndw; k += kLineThreads) reinterpret_cast<uint32_t*>(s_px)[k] = reinterpret_cast<const uint32_t*>(src)[k];
+    for (uint32_t k = 4u * ndw + threadIdx.x; k < nbytes; k += kLineThreads) s_px[k] = src[k];
+  }
+  __syncthreads();
+
+  // thread t owns blocks 2t and 2t+1 (MCU order: Y00 Y01 Y10 Y11 Cb Cr), so that the scan below runs over threads
+  int q[2][8];
+  bool live[2], dummy[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t b = 2u * threadIdx.x + (uint32_t)h;
+    live[h] = b < nblk;
+    const uint32_t mcu = b / 6u, slot = b % 6u;
+    dummy[h] = slot == 2u || slot == 3u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[h][k] = 0;
+    if (!live[h] || dummy[h]) continue;
+    int d[8];
+    if (slot < 2u) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t x = min(16u * mcu + 8u * slot + (uint32_t)c, width - 1u);  // right edge: the last pixel repeated (jcprepct.c)
+        const int R = s_px[3 * x], G = s_px[3 * x + 1], B = s_px[3 * x + 2];
+        d[c] = ((19595 * R + 38470 * G + 7471 * B + 32768) >> 16) - 128;
+      }
+    } else {
+      const bool is_cr = slot == 5u;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int sum = (c & 1) ? 2 : 1;  // jcsample.c h2v2_downsample bias 1,2,1,2; both rows of the 2x2 box are the same row
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t x = min(16u * mcu + 2u * (uint32_t)c + (uint32_t)k, width - 1u);
+          const int R = s_px[3 * x], G = s_px[3 * x + 1], B = s_px[3 * x + 2];
+          const int v = is_cr ? ((32768 * R - 27439 * G - 5329 * B + (128 << 16) + 32767) >> 16)
+                              : ((-11059 * R - 21709 * G + 32768 * B + (128 << 16) + 32767) >> 16);
+          sum += 2 * v;
+        }
+        d[c] = (sum >> 2) - 128;
+      }
+    }
+    jpeg_fdct_1d<true>(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+    const int comp = slot < 4u ? 0 : 1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {  // column pass over eight equal values: (0,c) = 2 * d[c]; then quantisation as in k_leaf_tile
+      const int v = 2 * d[c];
+      const uint32_t a = (uint32_t)(v < 0 ? -v : v) + jq.half[comp][c];
+      const int qv = (int)(((uint64_t)a * jq.magic[comp][c]) >> 32);
+      q[h][c] = v < 0 ? -qv : qv;
+    }
+    s_dc[b] = q[h][0];
+  }
+  // A strip whose width leaves its last MCU at most eight pixels has an odd number of luma blocks: the MCU's second
+  // luma block lies beyond the component and is a dummy block too (jccoefct.c: DC of the block before, no AC) -- not
+  // the transform of the repeated edge pixel.  Blocks 6m and 6m+1 belong to the same thread.
+  if (live[1] && (2u * threadIdx.x + 1u) % 6u == 1u && 2u * ((2u * threadIdx.x + 1u) / 6u) + 1u >= (width + 7u) / 8u) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) q[1][k] = 0;
+    q[1][0] = q[0][0];
+    dummy[1] = true;
+    s_dc[2u * threadIdx.x + 1u] = q[0][0];
+  }
+  __syncthreads();
+  // DC differences along the chains Y00 Y01 Y10 Y11 | Cb | Cr (a dummy block repeats the DC of the block before it)
+  int diff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t b = 2u * threadIdx.x + (uint32_t)h;
+    diff[h] = 0;
+    if (!live[h]) continue;
+    const uint32_t mcu = b / 6u, slot = b % 6u;
+    if (slot == 0u) diff[h] = q[h][0] - (mcu ? s_dc[6u * (mcu - 1u) + 1u] : 0);
+    else if (slot == 1u) diff[h] = q[h][0] - s_dc[b - 1u];
+    else if (slot >= 4u) diff[h] = q[h][0] - (mcu ? s_dc[b - 6u] : 0);
+  }
+  uint32_t len[2] = {0u, 0u};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (!live[h]) continue;
+    LineBlockCoder c{nullptr, 0u};
+    code_line_block(c, diff[h], q[h], dummy[h], s_hdc, s_hac, (2u * threadIdx.x + (uint32_t)h) % 6u < 4u ? 0 : 1);
+    len[h] = c.pos;
+  }
+  uint32_t total;
+  const uint32_t at = block_excl_scan<kLineThreads / 64, uint32_t>(len[0] + len[1], s_scan, total);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (!live[h]) continue;
+    LineBlockCoder c{s_bits, at + (h ? len[0] : 0u)};
+    code_line_block(c, diff[h], q[h], dummy[h], s_hdc, s_hac, (2u * threadIdx.x + (uint32_t)h) % 6u < 4u ? 0 : 1);
+  }
+  const uint32_t nwords = (total + 31u) / 32u;
+  if (threadIdx.x == 0) s_where = atomicAdd(&st->jpeg_line_words, nwords);
+  __syncthreads();
+  const uint32_t where = s_where;
+  const bool fits = where + nwords <= capacity_words;  // always, the region holds the worst case of every strip
+  if (threadIdx.x == 0) {
+    dir[4u * line] = where; dir[4u * line + 1u] = fits ? total : 0u; dir[4u * line + 2u] = width; dir[4u * line + 3u] = fits ? 0u : 1u;
+  }
+  if (fits)
+    for (uint32_t k = threadIdx.x; k < nwords; k += kLineThreads) data[where + k] = s_bits[k];
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launch sequence
 // ------------------------------------------------------------------------------------------
 #define PCC_STAMP(name)                                      \
@@ -1808,6 +2008,12 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
                      reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff, span("k_leaf_tile"));
   PCC_STAMP("k_leaf_tile");
+  if (a.jpeg_lines_dir) {
+    const uint32_t max_lines = std::max(1u, n / 2048u);
+    hipLaunchKernelGGL(k_jpeg_lines, dim3(max_lines), dim3(kLineThreads), 0, stream, a.state, a.bgr, a.jq, a.huff, a.jpeg_lines_dir, a.jpeg_lines_data,
+                       a.jpeg_lines_capacity, span("k_jpeg_lines"));
+    PCC_STAMP("k_jpeg_lines");
+  }
   if (!a.lp.simplify_only) {
     // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64
     const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));

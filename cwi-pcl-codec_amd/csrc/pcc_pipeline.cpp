@@ -62,6 +62,7 @@ struct Ready {  // a context whose GPU stage is done
 struct pcc_pipeline {
   int device = 0;
   int n_entropy = 0, n_gpu = 0;
+  int n_gpu_device = 0;  // of the n_gpu GPU-stage threads, how many take part when the frames already sit in HBM
   pcc_upload_lane* lane = nullptr;  // host-to-device copies of host-input jobs, one after the other
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
   int batch_now = PCC_MAX_FRAMES_AT_ONCE;  // ... for the job at hand: short jobs spread their frames over the threads instead
@@ -129,9 +130,13 @@ struct pcc_pipeline {
     if (--busy == 0) cv_done.notify_all();
   }
 
-  void gpu_thread() {
+  void gpu_thread(int index) {
     uint64_t seen = 0;
     while (next_job(seen)) {
+      // A frame that comes from host memory spends most of its time waiting for its turn on the PCIe link (and, if
+      // its memory is pageable, in the page-locking call): more threads keep the link busy.  With the frames in HBM
+      // the extra frames in flight only get in each other's way on the GPU.
+      if (!job.host_input && index >= n_gpu_device) { job_done(); continue; }
       double tl = 0, tf = 0, cl = 0, cf = 0;
       for (;;) {
         Ready r;
@@ -300,10 +305,15 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   pcc_pipeline* p = new pcc_pipeline();
   p->device = device;
   p->n_entropy = n_workers;
-  p->n_gpu = n_workers < 6 ? n_workers : 6;  // frames in flight on the GPU: a handful saturates it
+  p->n_gpu_device = n_workers < 6 ? n_workers : 6;  // frames in flight on the GPU: a handful saturates it
   if (const char* e = getenv("PCC_PIPELINE_GPU_THREADS")) {
     const int v = atoi(e);
-    if (v >= 1 && v <= 64) p->n_gpu = v;
+    if (v >= 1 && v <= 64) p->n_gpu_device = v;
+  }
+  p->n_gpu = std::max(p->n_gpu_device, std::min(n_workers, 10));
+  if (const char* e = getenv("PCC_PIPELINE_UPLOAD_THREADS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) p->n_gpu = std::max(p->n_gpu_device, v);
   }
   if (const char* e = getenv("PCC_PIPELINE_BATCH")) {
     const int v = atoi(e);
@@ -321,7 +331,7 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     p->ctxs.push_back(c);
   }
   p->lane = pcc_upload_lane_create(device);
-  for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p] { p->gpu_thread(); });
+  for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p] { p->entropy_thread(); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
   // threads of one core run at about half speed each.  PCC_PIPELINE_PIN=cores gives every entropy thread a physical

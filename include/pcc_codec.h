@@ -91,6 +91,12 @@ typedef struct pcc_hot_result {
   /* 256 counts: how often each byte value occurs in `occupancy` (counted on the GPU; saves the range coder its
    * histogram pass).  NULL: the host counts. */
   const uint32_t *occupancy_histogram;
+  /* Colour coding type 2 ("lines", jpegcc.h:244-317) coded on the GPU: per strip {word offset into jpeg_lines_data, bits,
+   * width in pixels, 1 = did not fit}, and the strips' entropy-coded bit strings (MSB first inside each u32, no 0xFF
+   * stuffing, no headers: the host adds those).  NULL: the host codes the strips from `bgr`. */
+  const uint32_t *jpeg_lines_dir;
+  const uint32_t *jpeg_lines_data;
+  uint32_t jpeg_n_lines;
 } pcc_hot_result;
 
 typedef struct pcc_bitstream {
@@ -179,6 +185,14 @@ int pcc_get_output_cloud(pcc_ctx *ctx, const pcc_point_xyzrgb **points, size_t *
 
 /* ---- decodePointCloud (codec.h:177-178, impl.hpp:224-310) ---- */
 int pcc_decode_intra(pcc_ctx *ctx, const uint8_t *stream, size_t len, pcc_cloud *out);
+
+/* The same with the data-parallel half on the GPU: the host runs what is sequential by construction (the three range
+ * decoders, the JPEG's Huffman decoding, the walk over the depth-first occupancy stream that finds every byte's
+ * level), the GPU the rest (voxel keys -> centres or centroids, inverse DCT, chroma upsampling, colour conversion and
+ * un-snaking of the colour image).  Same cloud, bit for bit; out->points is page-locked library memory. */
+int pcc_decode_intra_gpu(pcc_ctx *ctx, const uint8_t *stream, size_t len, pcc_cloud *out);
+/* milliseconds of the last pcc_decode_intra_gpu: sequential host stages | upload + kernels + download | whole call */
+int pcc_get_decode_times(pcc_ctx *ctx, double out_ms[3]);
 
 /* ---- helpers around the path ---- */
 /* device memory for callers that keep clouds resident (bench, multi-frame pipelines) */

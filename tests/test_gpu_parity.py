@@ -386,6 +386,33 @@ def test_jpeg_stage_on_gpu_equals_host_jpeg(pkg, oracle, L):
             assert stream == want.bitstream, (L, q, on_gpu)
 
 
+@pytest.mark.parametrize("L", [1, 17, 24, 2047, 2048, 2049, 2056, 4095, 4096, 4097, 6143, 6144, 10_000, 33_000])
+def test_jpeg_lines_on_gpu_equal_host_jpeg(pkg, oracle, L):
+    """Colour coding type 2 (jpegcc.h:244-317): strips of 2048 voxels, the last one 2048..4095 wide, each a w x 1 JPEG.
+    Coded on the GPU (k_jpeg_lines: one 1-D FDCT per block, dummy luma blocks, Huffman coding) or on the host from the
+    per-voxel colours: the same bytes as the oracle's, for busy and for flat colours."""
+    b = pkg.binding
+    rng = np.random.default_rng(L)
+    side = int(np.ceil(np.sqrt(L)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:L]
+    xyz = np.concatenate([(2 * ij + 0.5) / 256.0 + 0.1, np.full((L, 1), 0.5)], 1)  # two voxels apart: L leaves wherever the box starts
+    for busy in (True, False):
+        rgb = rng.integers(0, 256, (L, 3)) if busy else np.stack([ij[:, 0] % 256, ij[:, 1] % 256, (ij[:, 0] + ij[:, 1]) % 256], 1)
+        pts = cloud(pkg, xyz, rgb=rgb)
+        for q in (30, 85, 100):
+            kw = dict(octree_resolution=1 / 256.0, point_resolution=1 / 256.0, color_coding_type=2, jpeg_quality=q)
+            want = oracle.encode_intra(pts, oracle.make_params(**kw))
+            assert want.n_leaves == L
+            for mode in (2, 0):
+                c = b.Context(0)
+                c.set_option("jpeg_on_gpu", mode)
+                c.set_option("copy_image", 0)
+                hot, stream, perf, _ = run_gpu(c, pts, b.make_params(**kw))
+                assert bool(hot.raw.jpeg_lines_dir) == (mode == 2) and bool(hot.raw.bgr) == (mode == 0)
+                assert stream == want.bitstream and perf == want.perf, (L, busy, q, mode)
+                c.close()
+
+
 def test_jpeg_huffman_rows_that_do_not_fit_fall_back_to_coefficients(pkg, oracle):
     """White-noise colours at quality 100: an MCU row needs more bits than its record holds, the frame is then
     Huffman-coded on the host from the coefficients -- same bytes."""
@@ -500,6 +527,51 @@ def test_host_frames_through_one_context(pkg, oracle):
         lib.pcc_upload_lane_destroy(lane)
 
 
+# ---------------- the decoder with its data-parallel half on the GPU ----------------
+
+@pytest.mark.parametrize("kw", [
+    dict(octree_bits=9, color_coding_type=1, jpeg_quality=85),
+    dict(octree_bits=9, color_coding_type=1, jpeg_quality=30, keep_centroid=1),
+    dict(octree_bits=8, color_coding_type=0, color_bits=6, keep_centroid=1),
+    dict(octree_bits=8, color_coding_type=2, jpeg_quality=75),
+    dict(octree_bits=8, color_coding_type=3),
+    dict(octree_bits=10, color_bits=0),
+    dict(octree_resolution=0.0037, point_resolution=0.0037, color_coding_type=1, jpeg_quality=95),
+])
+def test_gpu_decode_equals_the_oracles_decoder(pkg, oracle, ctx, kw):
+    """pcc_decode_intra_gpu: range decoders, JPEG Huffman decoding and the level walk over the occupancy stream on the
+    host, voxel keys -> points, inverse DCT, fancy chroma upsampling, colour conversion and un-snaking on the GPU.
+    Bit-exact against oracle.decode_intra and against the product's host decoder, sizes from one voxel to 200 k."""
+    rng = np.random.default_rng(len(str(kw)))
+    for n in (1, 9, 300, 5_000, 70_000, 200_000):
+        if "octree_resolution" in kw:
+            pts = cloud(pkg, rng.normal(size=(n, 3)) * 0.4 + 2.0, seed=n)
+        else:
+            pts = pkg.synthetic.sphere_shell(n, 0xDEC0 + n) if n > 9 else cloud(pkg, rng.uniform(0.2, 0.8, (n, 3)), seed=n)
+        stream = oracle.encode_intra(pts, oracle.make_params(frame_id=3, **kw)).bitstream
+        ref = oracle.decode_intra(stream).points
+        got, info = ctx.decode_intra(stream + b"trailing bytes of the next frame", on_gpu=True)
+        host, _ = ctx.decode_intra(stream)
+        assert info["consumed"] == len(stream)
+        assert got.tobytes() == ref.tobytes() and host.tobytes() == ref.tobytes(), (kw, n)
+    with pytest.raises(pkg.binding.PccError):
+        ctx.decode_intra(stream[:len(stream) // 2], on_gpu=True)
+    with pytest.raises(pkg.binding.PccError):
+        ctx.decode_intra(b"no frame here", on_gpu=True)
+
+
+def test_gpu_decode_of_the_headline_frame(pkg, oracle, ctx):
+    """cfg2 (1 M points, 10-bit octree, JPEG snake): decoded cloud identical to the oracle's; the times of the two halves
+    are reported by pcc_get_decode_times."""
+    pts = pkg.synthetic.make_frame("cfg2")
+    stream = oracle.encode_intra(pts, oracle.make_params(octree_bits=10, jpeg_quality=85, frame_id=1)).bitstream
+    ref = oracle.decode_intra(stream).points
+    got, _ = ctx.decode_intra(stream, on_gpu=True)
+    assert got.tobytes() == ref.tobytes()
+    t = ctx.decode_times()
+    assert t["total_ms"] >= t["host_sequential_ms"] > 0 and t["gpu_ms"] > 0
+
+
 # ---------------- randomised sweep ----------------
 
 def _random_case(pkg, seed):
@@ -560,3 +632,7 @@ def test_random_sweep(pkg, oracle, ctx, seed):
     if want.depth > 21:
         pytest.skip("deeper than the 63-bit Morton limit (documented)")
     assert_matches_oracle(pkg, oracle, ctx, pts, **kw)
+    # ... and back: the decoder with its data-parallel half on the GPU gives the oracle's cloud
+    ref = oracle.decode_intra(want.bitstream).points
+    got, info = ctx.decode_intra(want.bitstream, on_gpu=True)
+    assert info["consumed"] == len(want.bitstream) and got.tobytes() == ref.tobytes()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_struct_layouts_match_header(pkg, oracle):
     b = pkg.binding
     assert C.sizeof(b.Params) == 56 and b.POINT_DTYPE.itemsize == 32
-    assert C.sizeof(b.HotResult) == 8 * 6 + 4 + 4 + 8 * 3 + 8 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 4 + 4 + 8
+    assert C.sizeof(b.HotResult) == 8 * 6 + 4 + 4 + 8 * 3 + 8 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4   # ... + jpeg_lines_dir, jpeg_lines_data, jpeg_n_lines (+ padding)
     assert C.sizeof(b.Bitstream) == 8 + 8 + 24
 
 

@@ -187,3 +187,28 @@ def test_normalize_matches_numpy(oracle, pkg):
     for ax in "xyz":
         assert np.array_equal(a[ax], b[ax])
         assert abs(a[ax].min() - 0.2 / 1.4) < 1e-6 and abs(a[ax].max() - 1.2 / 1.4) < 1e-6
+
+
+def test_pin_recipe_stays_runnable(oracle):
+    """oracle/pin_with_pcl.sh + pin_check.py + ref_codec_driver.cpp are the recipe that pins the PCL-inherited parts of
+    the oracle the day a PCL installation exists (none here: DESIGN.md (c)).  What can be checked without PCL: the
+    checker imports, its clouds encode with the oracle, the driver exports what the checker binds, and the build line
+    names the reference's own sources where they lie (nothing copied)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin_check", os.path.join(root, "oracle", "pin_check.py"))
+    pc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pc)
+    cases = pc.extra_cases()
+    assert len(cases) == 4
+    name, pts, kw = cases[0]
+    r = oracle.encode_intra(pts, oracle.make_params(**kw))
+    assert r.n_leaves > 10_000 and r.n_branches > 2 ** 16 // 8
+    drv = open(os.path.join(root, "oracle", "ref_codec_driver.cpp")).read()
+    for sym in ("ref_encode", "ref_stream", "ref_cloud_size", "ref_cloud", "ref_decode"):
+        assert sym + "(" in drv
+    assert "#include <pcl/cloud_codec_v2/impl/point_cloud_codec_v2_impl.hpp>" in drv
+    sh = open(os.path.join(root, "oracle", "pin_with_pcl.sh")).read()
+    assert '"$REF/jpeg_io/src/jpeg_io.cpp"' in sh and "ref_codec_driver.cpp" in sh
+    assert not any(line.strip().startswith(("cmake", "make ")) for line in sh.splitlines())   # a plain compiler line, not the reference's build system

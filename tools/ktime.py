@@ -6,27 +6,35 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as G
 pkg = G.load_package(); b, syn = pkg.binding, pkg.synthetic
-cfg = syn.CONFIGS["cfg2"]
-p = b.make_params(octree_bits=cfg["octree_bits"])
-ctx = b.Context(0); pts = syn.make_frame("cfg2"); dev = ctx.upload(pts)
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+cfg = syn.CONFIGS[wl]
+p = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
+                  jpeg_quality=cfg["jpeg_quality"])
+ctx = b.Context(0); pts = syn.make_frame(wl); dev = ctx.upload(pts)
+ntiles = min(1024, (len(pts) + 4095) // 4096)   # stamps exist for the first 1024 workgroups of a launch
 for _ in range(5):
     ctx.hotpath_launch(dev, len(pts), p); hot = ctx.hotpath_finish(copy=False)
 buf = np.zeros(9 * 1024 * 8, dtype=np.uint64)
 lib = b.load_library()
 print("rc", lib.pcc_debug_read_ktime(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.size)))
 t = buf.reshape(9, 1024, 8).astype(np.int64)
-for ps in range(4):
-    x = t[ps, :245, :8]
+for ps in range(hot.depth * 3 // 9 + 1 if wl != "cfg2" else 4):
+    x = t[ps, :ntiles, :8]
     t0 = x[:, 0].min()
     rel = (x - t0) / 100.0
     print("pass %d: stamps (median us): start %.2f tile %.2f published %.2f closers-done %.2f ranked %.2f mates-read %.2f prev-group-ready %.2f lookback-done %.2f" % ((ps,) + tuple(np.median(rel, axis=0))))
     print("        stamps (max us):", np.round(rel.max(axis=0), 2))
-x = t[5, :231, :7]
+    d = x.astype(np.float64) / 100.0
+    print("        per workgroup (median us): ticket+totals %.2f  keys+histogram %.2f  ranking %.2f  look-back %.2f  reorder+write %.2f  whole %.2f" % (
+        np.median(d[:, 1] - d[:, 0]), np.median(d[:, 2] - d[:, 1]), np.median(d[:, 4] - d[:, 3]), np.median(d[:, 7] - d[:, 4]),
+        np.median(d[:, 5] - d[:, 7]), np.median(d[:, 5] - d[:, 0])))
+nlt = min(1024, hot.n_leaves // 4096 + 1)
+x = t[5, :nlt, :7]
 rel = (x - x[:, 0].min()) / 100.0
 print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end:", np.round(np.median(rel, axis=0), 2))
 print("            stamps (max us):", np.round(rel.max(axis=0), 2))
-x = t[7, :231, :4]
-rel = (x - t[5, :231, 0:1]) / 100.0
+x = t[7, :nlt, :4]
+rel = (x - t[5, :nlt, 0:1]) / 100.0
 print("k_leaf_tile A1 (median us since kernel start): first barrier, records landed + masks, barrier, parent search done:", np.round(np.median(rel, axis=0), 2))
 x8 = t[8, 0, :8]
 x = t[6, 0, :7]
