@@ -34,13 +34,15 @@ EXPORTS = [
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
-    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_workers", "pcc_pipeline_contexts",
+    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_workers", "pcc_pipeline_contexts",
     "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_encode_host", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
     "pcc_pipeline_create_multi", "pcc_multi_pipeline_destroy", "pcc_multi_pipeline_size", "pcc_multi_pipeline_member",
     "pcc_multi_pipeline_encode_host", "pcc_multi_pipeline_encode", "pcc_multi_pipeline_last_error",
     "pcc_quality_metrics", "pcc_remove_outliers", "pcc_device_range_encode",
+    "pcc_entropy_batch_create", "pcc_entropy_batch_destroy", "pcc_entropy_batch_size", "pcc_entropy_batch_capacity",
+    "pcc_entropy_batch_add", "pcc_entropy_batch_flush", "pcc_entropy_batch_last_error",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
     "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_normalize_group_boxes", "pcc_restore_scaling",
@@ -173,6 +175,19 @@ def load_library():
     lib.pcc_pipeline_contexts.argtypes = [vp]
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
+    lib.pcc_entropy_batch_create.restype = vp
+    lib.pcc_entropy_batch_create.argtypes = [i32, sz]
+    lib.pcc_entropy_batch_destroy.argtypes = [vp]
+    lib.pcc_entropy_batch_destroy.restype = None
+    lib.pcc_entropy_batch_size.restype = sz
+    lib.pcc_entropy_batch_size.argtypes = [vp]
+    lib.pcc_entropy_batch_capacity.restype = sz
+    lib.pcc_entropy_batch_capacity.argtypes = [vp]
+    lib.pcc_entropy_batch_add.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params)]
+    lib.pcc_entropy_batch_flush.argtypes = [vp, C.POINTER(Bitstream), sz, C.POINTER(sz)]
+    lib.pcc_entropy_batch_last_error.restype = C.c_char_p
+    lib.pcc_entropy_batch_last_error.argtypes = [vp]
+    lib.pcc_pipeline_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.pcc_pipeline_create_multi.restype = vp
     lib.pcc_pipeline_create_multi.argtypes = [C.POINTER(i32), i32, i32]
     lib.pcc_multi_pipeline_destroy.argtypes = [vp]
@@ -523,6 +538,11 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        rc = self.lib.pcc_pipeline_set_option(self.h, name.encode(), int(value))
+        if rc != PCC_OK:
+            raise PccError(rc, "pipeline option " + name)
 
     def context(self, index):
         """Context `index` of n_contexts (two per worker)."""

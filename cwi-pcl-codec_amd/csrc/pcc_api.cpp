@@ -1158,6 +1158,202 @@ int pcc_get_decode_times(pcc_ctx* ctx, double out_ms[3]) {
   return PCC_OK;
 }
 
+// =====================================================================================================
+// The entropy stage of MANY frames with the range coders on the GPU (csrc/pcc_rc_device.hip: one wave per stream).
+// For hosts with fewer cores than their GPUs can feed: a CPU core codes ~700 frames/s of the headline size, a GPU
+// ~16 000 streams/s -- at 0.1 s per batch, whatever its size, hence batches of hundreds of frames.  What a frame
+// needs of its context is copied out when it is added, so the context goes straight back to the GPU stage.
+// Same bytes as pcc_entropy_encode.
+// =====================================================================================================
+struct pcc_entropy_batch {
+  pcc_ctx* ctx = nullptr;  // stream, error text
+  size_t max_frames = 0;
+  struct Frame {
+    Bytes header;                // 140-byte frame header
+    uint64_t n_branches = 0, n_leaves = 0;
+    size_t occ_off = 0, occ_len = 0, hist_off = 0, cen_off = 0, cen_len = 0, col_off = 0, col_len = 0;
+    bool has_hist = false, has_cen = false, has_col = false;
+    int job[3] = {-1, -1, -1};
+  };
+  std::vector<Frame> frames;
+  PinnedBuf<uint8_t> h_in;       // every stream of the batch, 64-byte aligned, and the occupancy counts
+  size_t in_used = 0;
+  DevBuf<uint8_t> d_in, d_out, d_packed;
+  DevBuf<RcJob> d_jobs;
+  DevBuf<uint32_t> d_lens, d_offs;
+  PinnedBuf<uint32_t> h_lens;
+  PinnedBuf<uint8_t> h_packed;
+  std::vector<Bytes> streams;    // the finished bitstreams of the last flush
+  float gpu_ms = 0.f;
+
+  uint8_t* room(size_t bytes, size_t& off) {  // grows the pinned arena, keeping what is in it
+    off = (in_used + 63) & ~(size_t)63;
+    const size_t need = off + bytes + 64;
+    if (need > h_in.cap) {
+      PinnedBuf<uint8_t> bigger;
+      if (bigger.ensure(std::max(need, 2 * h_in.cap)) != hipSuccess) return nullptr;
+      if (in_used) memcpy(bigger.p, h_in.p, in_used);
+      h_in.release();
+      h_in = bigger;
+    }
+    in_used = off + bytes;
+    return h_in.p + off;
+  }
+};
+
+pcc_entropy_batch* pcc_entropy_batch_create(int device, size_t max_frames) {
+  pcc_ctx* c = pcc_create(device);
+  if (!c) return nullptr;
+  pcc_entropy_batch* b = new pcc_entropy_batch();
+  b->ctx = c;
+  b->max_frames = max_frames ? max_frames : 256;
+  return b;
+}
+
+void pcc_entropy_batch_destroy(pcc_entropy_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  b->h_in.release(); b->d_in.release(); b->d_out.release(); b->d_packed.release(); b->d_jobs.release(); b->d_lens.release();
+  b->d_offs.release(); b->h_lens.release(); b->h_packed.release();
+  pcc_destroy(b->ctx);
+  delete b;
+}
+
+size_t pcc_entropy_batch_size(pcc_entropy_batch* b) { return b ? b->frames.size() : 0; }
+size_t pcc_entropy_batch_capacity(pcc_entropy_batch* b) { return b ? b->max_frames : 0; }
+const char* pcc_entropy_batch_last_error(pcc_entropy_batch* b) { return b ? b->ctx->err.c_str() : "no batch (no usable HIP device?)"; }
+
+int pcc_entropy_batch_add(pcc_entropy_batch* b, const pcc_hot_result* hot, const pcc_params* prm) {
+  if (!b || !hot || !prm) return PCC_ERR_ARG;
+  pcc_ctx* ctx = b->ctx;
+  if (b->frames.size() >= b->max_frames) return fail(ctx, PCC_ERR_STATE, "the batch is full: flush it first");
+  pcc_entropy_batch::Frame f;
+  frame_header_bytes(*hot, *prm, f.header);
+  f.n_branches = hot->n_branches;
+  f.n_leaves = hot->n_leaves;
+  uint8_t* p = b->room((size_t)hot->n_branches, f.occ_off);
+  if (!p) return fail(ctx, PCC_ERR_HIP, "out of page-locked memory");
+  memcpy(p, hot->occupancy, (size_t)hot->n_branches);
+  f.occ_len = (size_t)hot->n_branches;
+  if (hot->occupancy_histogram) {
+    p = b->room(1024, f.hist_off);
+    if (!p) return fail(ctx, PCC_ERR_HIP, "out of page-locked memory");
+    memcpy(p, hot->occupancy_histogram, 1024);
+    f.has_hist = true;
+  }
+  if (prm->do_voxel_centroid) {
+    f.cen_len = (size_t)(3 * hot->n_leaves);
+    p = b->room(f.cen_len, f.cen_off);
+    if (!p) return fail(ctx, PCC_ERR_HIP, "out of page-locked memory");
+    memcpy(p, hot->centroid, f.cen_len);
+    f.has_cen = true;
+  }
+  if (prm->do_color_encoding) {  // the JPEG is put together here, on the host (headers, row stitching): a fraction of a millisecond
+    Bytes payload;
+    const uint8_t* src = nullptr;
+    size_t n = 0;
+    colour_stream_source(*hot, *prm, payload, src, n);
+    f.col_len = n;
+    p = b->room(n, f.col_off);
+    if (!p) return fail(ctx, PCC_ERR_HIP, "out of page-locked memory");
+    if (n) memcpy(p, src, n);
+    f.has_col = true;
+  }
+  b->frames.push_back(std::move(f));
+  return (int)b->frames.size() - 1;
+}
+
+int pcc_entropy_batch_flush(pcc_entropy_batch* b, pcc_bitstream* out, size_t out_capacity, size_t* n_out) {
+  if (!b || (!out && out_capacity) || !n_out) return PCC_ERR_ARG;
+  pcc_ctx* ctx = b->ctx;
+  *n_out = 0;
+  const size_t nf = b->frames.size();
+  if (out_capacity < nf) return fail(ctx, PCC_ERR_ARG, "room for fewer bitstreams than frames in the batch");
+  b->streams.assign(nf, Bytes());
+  if (nf == 0) return PCC_OK;
+  PCC_HIP(hipSetDevice(ctx->device));
+  // jobs: the occupancy bytes (with their counts where the GPU stage delivered them), centroid bytes, colour payload
+  std::vector<RcJob> jobs;
+  std::vector<size_t> out_off;
+  size_t out_bytes = 0;
+  PCC_HIP(b->d_in.ensure(b->in_used + 64));
+  auto add_job = [&](size_t off, size_t len, bool hist, size_t hist_off) {
+    RcJob j;
+    j.in = b->d_in.p + off;
+    j.n = (uint32_t)len;
+    j.hist = hist ? reinterpret_cast<const uint32_t*>(b->d_in.p + hist_off) : nullptr;
+    j.out = nullptr;
+    j.out_len = nullptr;
+    out_off.push_back(out_bytes);
+    out_bytes += (1028 + len + len / 2 + 64 + 63) & ~(size_t)63;
+    jobs.push_back(j);
+    return (int)jobs.size() - 1;
+  };
+  for (auto& f : b->frames) {
+    if (f.occ_len >= (1ull << 31) || f.cen_len >= (1ull << 31) || f.col_len >= (1ull << 31)) return fail(ctx, PCC_ERR_UNSUPPORTED, "stream of 2 GB or more");
+    f.job[0] = add_job(f.occ_off, f.occ_len, f.has_hist, f.hist_off);
+    f.job[1] = f.has_cen ? add_job(f.cen_off, f.cen_len, false, 0) : -1;
+    f.job[2] = f.has_col ? add_job(f.col_off, f.col_len, false, 0) : -1;
+  }
+  const uint32_t nj = (uint32_t)jobs.size();
+  PCC_HIP(b->d_out.ensure(out_bytes + 64));
+  PCC_HIP(b->d_lens.ensure(nj));
+  PCC_HIP(b->d_offs.ensure(nj));
+  PCC_HIP(b->d_jobs.ensure(nj));
+  PCC_HIP(b->h_lens.ensure(nj));
+  for (uint32_t k = 0; k < nj; ++k) { jobs[k].out = b->d_out.p + out_off[k]; jobs[k].out_len = b->d_lens.p + k; }
+  PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(b->d_in.p, b->h_in.p, b->in_used, hipMemcpyHostToDevice, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(b->d_jobs.p, jobs.data(), (size_t)nj * sizeof(RcJob), hipMemcpyHostToDevice, ctx->stream));
+  launch_range_encode(b->d_jobs.p, nj, ctx->stream);
+  PCC_HIP(hipGetLastError());
+  PCC_HIP(hipMemcpyAsync(b->h_lens.p, b->d_lens.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  // the coded streams side by side, one copy back
+  std::vector<uint32_t> offs(nj);
+  size_t packed = 0;
+  for (uint32_t k = 0; k < nj; ++k) { offs[k] = (uint32_t)packed; packed += ((size_t)b->h_lens.p[k] + 15) & ~(size_t)15; }
+  if (packed >= (1ull << 32)) return fail(ctx, PCC_ERR_UNSUPPORTED, "more than 4 GB of coded streams in one batch");
+  PCC_HIP(b->d_packed.ensure(packed + 64));
+  PCC_HIP(b->h_packed.ensure(packed + 64));
+  PCC_HIP(hipMemcpyAsync(b->d_offs.p, offs.data(), (size_t)nj * 4, hipMemcpyHostToDevice, ctx->stream));
+  launch_pack_streams(b->d_jobs.p, b->d_offs.p, b->d_packed.p, nj, ctx->stream);
+  PCC_HIP(hipGetLastError());
+  PCC_HIP(hipMemcpyAsync(b->h_packed.p, b->d_packed.p, packed, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+  { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
+  (void)hipEventElapsedTime(&b->gpu_ms, ctx->ev_begin, ctx->ev_end);
+  // writeFrameHeader + entropyEncoding layout (impl.hpp:1682-1760)
+  for (size_t i = 0; i < nf; ++i) {
+    const pcc_entropy_batch::Frame& f = b->frames[i];
+    Bytes& s = b->streams[i];
+    s = f.header;
+    auto put = [&](const void* q, size_t n) { const uint8_t* u = static_cast<const uint8_t*>(q); s.insert(s.end(), u, u + n); };
+    auto coded = [&](int job) { put(b->h_packed.p + offs[(size_t)job], b->h_lens.p[job]); return (uint64_t)b->h_lens.p[job]; };
+    const uint64_t nb = f.n_branches;
+    put(&nb, 8);
+    out[i].perf[0] = coded(f.job[0]);
+    out[i].perf[1] = out[i].perf[2] = 0;
+    if (f.has_cen) {
+      const uint32_t n3 = (uint32_t)f.cen_len;
+      put(&n3, 4);
+      out[i].perf[1] = coded(f.job[1]);
+    }
+    if (f.has_col) {
+      const uint64_t nc = f.col_len;
+      put(&nc, 8);
+      out[i].perf[2] = coded(f.job[2]);
+    }
+    out[i].data = s.data();
+    out[i].len = s.size();
+  }
+  *n_out = nf;
+  b->frames.clear();
+  b->in_used = 0;
+  return PCC_OK;
+}
+
 int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* in, const size_t* n, uint8_t* const* out, size_t* out_len,
                             float* gpu_ms) {
   if (!ctx || n_streams < 0 || (n_streams && (!in || !n || !out || !out_len))) return PCC_ERR_ARG;

@@ -1137,6 +1137,11 @@ void colour_payload(const pcc_hot_result& hot, const pcc_params& prm, Bytes& pay
 }
 }  // namespace
 
+void frame_header_bytes(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out) { write_frame_header(hot, prm, out); }
+void colour_stream_source(const pcc_hot_result& hot, const pcc_params& prm, Bytes& payload, const uint8_t*& src, size_t& src_len) {
+  colour_payload(hot, prm, payload, src, src_len);
+}
+
 // Up to four frames at a time: every range-coder stage codes the streams of all frames in one loop
 // (StaticRangeCoder::encode_many): same bytes, a fraction of the time per frame.
 void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_params* const prm[], Bytes* const out[],

@@ -90,6 +90,10 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
 
 // decodePointCloud (impl.hpp:224-310); returns PCC_OK or PCC_ERR_STREAM
 int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info);
+// pieces of the entropy stage for callers that run the range coders elsewhere (pcc_entropy_batch: on the GPU):
+// the 140-byte frame header (impl.hpp:1472-1486), and what the colour range coder gets (jpegcc.h:115-139)
+void frame_header_bytes(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out);
+void colour_stream_source(const pcc_hot_result& hot, const pcc_params& prm, Bytes& payload, const uint8_t*& src, size_t& src_len);
 
 // The two sequential halves of decode_frame, for the decoder that does the rest on the GPU (pcc_decode_intra_gpu):
 // header + the three range-coded vectors (+ the per-voxel colour bytes unless `colours_too` is false and the colours are

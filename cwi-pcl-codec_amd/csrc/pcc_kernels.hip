@@ -21,8 +21,11 @@
 #include <algorithm>
 #include <float.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <string>
 
 #include "pcc_device.h"
 #include "pcc_kernels.h"
@@ -158,7 +161,8 @@ __device__ __forceinline__ uint64_t poll_u64(const uint64_t* p) {
 __device__ unsigned long long g_ktime[(7 + 2) * 1024 * 8];
 #define PCC_KTR(row, slot)                                                                             \
   do {                                                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_ktime[((size_t)(row) * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+    const unsigned ks_ = (gridDim.x + 1023u) / 1024u; /* every ks_-th workgroup of a large grid is sampled */ \
+    if (threadIdx.x == 0 && blockIdx.x % ks_ == 0) g_ktime[((size_t)(row) * 1024 + blockIdx.x / ks_) * 8 + (slot)] = wall_clock64(); \
   } while (0)
 #else
 #define PCC_KTR(row, slot) do { } while (0)
@@ -706,8 +710,11 @@ __global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restr
 // (tile, digit): flag | count), then scatters.  Tile ids come from a ticket counter, so a tile only
 // ever waits for tiles that have already started.  Passes beyond st->npasses return at once.
 // ------------------------------------------------------------------------------------------
+// (second launch bound = waves per SIMD the register allocation has to leave room for: four, i.e. one 1024-thread or
+// two 512-thread workgroups per CU.  Without it the 512-thread shape takes 151 registers -- it is allowed 256 -- and
+// only one workgroup fits a CU, which is the whole point of that shape gone.)
 template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
+__global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
                                                             uint64_t* out_a, uint64_t* out_b,
                                                             uint32_t* idx_a, uint32_t* idx_b, uint32_t n, int pass,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
@@ -1954,6 +1961,38 @@ __global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ 
   __syncthreads();
   const uint32_t c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
   if (c) atomicAdd(&st->occ_hist[threadIdx.x], c);
+}
+
+// developer aid: what the runtime thinks of the kernels' residency (workgroups per CU, registers, LDS)
+extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
+  std::string out;
+  char line[256];
+  hipDeviceProp_t prop;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    snprintf(line, sizeof(line), "device: CUs %d, LDS per CU %zu, LDS per block %zu, regs per CU %d, max threads per CU %d\n", prop.multiProcessorCount,
+             (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock, prop.regsPerMultiprocessor, prop.maxThreadsPerMultiProcessor);
+    out += line;
+  }
+  auto one = [&](const char* name, const void* fn, int threads) {
+    int blocks = -1;
+    hipFuncAttributes at{};
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, threads, 0);
+    (void)hipFuncGetAttributes(&at, fn);
+    snprintf(line, sizeof(line), "%-26s threads %4d: %d workgroups per CU  (regs %d, static LDS %zu, max threads %d)\n", name, threads, blocks, at.numRegs,
+             (size_t)at.sharedSizeBytes, at.maxThreadsPerBlock);
+    out += line;
+  };
+  one("k_boxes_events", (const void*)k_boxes_events, kBlock);
+  one("k_make_keys", (const void*)k_make_keys, kSortThreads);
+  one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems>, kSortThreads);
+  one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
+  one("k_leaf_scan", (const void*)k_leaf_scan, kSortThreads);
+  one("k_leaf_tile", (const void*)k_leaf_tile, kFinThreads);
+  one("k_occ_histogram", (const void*)k_occ_histogram, 256);
+  if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
+  return 0;
 }
 
 constexpr uint32_t kSortSmallGridTiles = 512;  // up to two tiles per CU the wide workgroup is used

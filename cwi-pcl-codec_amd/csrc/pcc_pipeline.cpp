@@ -64,6 +64,11 @@ struct pcc_pipeline {
   int n_entropy = 0, n_gpu = 0;
   int n_gpu_device = 0;  // of the n_gpu GPU-stage threads, how many take part when the frames already sit in HBM
   pcc_upload_lane* lane = nullptr;  // host-to-device copies of host-input jobs, one after the other
+  // Opt-in (pcc_pipeline_set_option "entropy_on_gpu"): the range coders run on the GPU, one wave per stream, in batches of
+  // `gpu_batch` frames per entropy thread -- for hosts with fewer cores than the GPU stage can feed.
+  bool entropy_on_gpu = false;
+  int gpu_batch = 256;
+  std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
   int batch_now = PCC_MAX_FRAMES_AT_ONCE;  // ... for the job at hand: short jobs spread their frames over the threads instead
   std::vector<pcc_ctx*> ctxs;
@@ -205,12 +210,83 @@ struct pcc_pipeline {
     }
   }
 
-  void entropy_thread() {
+  // the results of a flushed batch go where the host stage would have put them
+  void store_result(size_t frame, const pcc_bitstream& bs) {
+    const size_t room = (bs.len + 63) & ~(size_t)63;
+    const size_t off = arena_used.fetch_add(room);
+    results[frame] = bs;
+    if (off + room <= arena_cap) {
+      memcpy(arena + off, bs.data, bs.len);
+      results[frame].data = arena + off;
+    } else {
+      streams[frame].assign(bs.data, bs.data + bs.len);
+      results[frame].data = streams[frame].data();
+    }
+  }
+
+  // entropy stage on the GPU: take ready frames one by one, copy what their entropy stage needs into the thread's batch
+  // (the context goes back to the GPU stage at once), flush when the batch is full or the job runs out of frames
+  void entropy_thread_gpu(int index, double& te, double& ce, size_t& done) {
+    if (!batches[(size_t)index]) batches[(size_t)index] = pcc_entropy_batch_create(device, (size_t)gpu_batch);
+    pcc_entropy_batch* batch = batches[(size_t)index];
+    std::vector<size_t> frames_in_batch;
+    std::vector<pcc_bitstream> outs;
+    auto flush = [&]() {
+      if (frames_in_batch.empty()) return;
+      outs.assign(frames_in_batch.size(), pcc_bitstream());
+      size_t n = 0;
+      const int rc = batch ? pcc_entropy_batch_flush(batch, outs.data(), outs.size(), &n) : PCC_ERR_HIP;
+      for (size_t k = 0; k < frames_in_batch.size(); ++k) {
+        if (rc == PCC_OK && k < n) store_result(frames_in_batch[k], outs[k]);
+        else { std::lock_guard<std::mutex> lk(mu); status[frames_in_batch[k]] = rc == PCC_OK ? PCC_ERR_STATE : rc; }
+      }
+      if (rc != PCC_OK) { std::lock_guard<std::mutex> lk(stat_mu); if (err.empty()) err = pcc_entropy_batch_last_error(batch); }
+      done += frames_in_batch.size();
+      frames_in_batch.clear();
+    };
+    for (;;) {
+      Ready r;
+      bool have = false, finished = false;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_ready.wait(lk, [&] { return !ready.empty() || gpu_done >= job.n_frames; });
+        if (!ready.empty()) { r = ready.front(); ready.pop_front(); have = true; }
+        else finished = true;
+      }
+      if (have) {
+        Clock::time_point t0 = Clock::now();
+        const double c0 = thread_cpu_us();
+        const int rc = batch ? pcc_entropy_batch_add(batch, &r.hot, &r.prm) : PCC_ERR_HIP;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (rc < 0) status[r.frame] = rc;
+          free_ctx.push_back(r.ctx);
+        }
+        cv_free.notify_all();
+        if (rc >= 0) frames_in_batch.push_back(r.frame);
+        if ((int)frames_in_batch.size() >= gpu_batch) flush();
+        te += us_since(t0);
+        ce += thread_cpu_us() - c0;
+      }
+      if (finished) {
+        Clock::time_point t0 = Clock::now();
+        const double c0 = thread_cpu_us();
+        flush();
+        te += us_since(t0);
+        ce += thread_cpu_us() - c0;
+        break;
+      }
+    }
+  }
+
+  void entropy_thread(int index) {
     uint64_t seen = 0;
     while (next_job(seen)) {
       double te = 0, ce = 0, hu[4] = {0, 0, 0, 0};
       size_t done = 0;
-      for (;;) {
+      const bool on_gpu = entropy_on_gpu && job.mode == 0;
+      if (on_gpu) entropy_thread_gpu(index, te, ce, done);
+      while (!on_gpu) {
         constexpr int kAtOnce = PCC_MAX_FRAMES_AT_ONCE;
         Ready r[kAtOnce];
         int nr = 0;
@@ -332,7 +408,9 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   }
   p->lane = pcc_upload_lane_create(device);
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
-  for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p] { p->entropy_thread(); });
+  p->batches.assign((size_t)p->n_entropy, nullptr);
+  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_on_gpu = !strcmp(e, "gpu");
+  for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p, w] { p->entropy_thread(w); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
   // threads of one core run at about half speed each.  PCC_PIPELINE_PIN=cores gives every entropy thread a physical
   // core of its own (first hardware thread of the k-th allowed core, starting at core PCC_PIPELINE_PIN_OFFSET).
@@ -362,6 +440,7 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   p->cv_work.notify_all();
   for (std::thread& t : p->threads) t.join();
   for (pcc_ctx* c : p->ctxs) pcc_destroy(c);
+  for (pcc_entropy_batch* b : p->batches) pcc_entropy_batch_destroy(b);
   pcc_upload_lane_destroy(p->lane);
   free(p->arena);
   delete p;
@@ -377,6 +456,15 @@ int pcc_pipeline_reserve(pcc_pipeline* p, size_t n_frames, size_t bytes_per_fram
     }
   p->seen_max_len = std::max(p->seen_max_len, bytes_per_frame);
   return p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63)) ? PCC_OK : PCC_ERR_HIP;
+}
+
+int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
+  if (!p || !name) return PCC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(p->mu);  // between jobs: the threads read these when a job starts
+  if (!strcmp(name, "entropy_on_gpu")) p->entropy_on_gpu = value != 0;
+  else if (!strcmp(name, "entropy_gpu_batch")) p->gpu_batch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
+  else return PCC_ERR_ARG;
+  return PCC_OK;
 }
 
 int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }

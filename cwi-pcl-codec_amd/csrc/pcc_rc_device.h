@@ -14,5 +14,8 @@ struct RcJob {            // one stream (device pointers)
 };
 
 void launch_range_encode(const RcJob* dev_jobs, uint32_t n_jobs, hipStream_t stream);
+// after the coder: the streams packed side by side (stream j at dev_packed + dev_offsets[j], offsets multiples of 16),
+// so that one device-to-host copy of the coded bytes brings everything back
+void launch_pack_streams(const RcJob* dev_jobs, const uint32_t* dev_offsets, uint8_t* dev_packed, uint32_t n_jobs, hipStream_t stream);
 
 }  // namespace pcc

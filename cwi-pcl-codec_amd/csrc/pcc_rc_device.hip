@@ -122,7 +122,24 @@ __global__ __launch_bounds__(64) void k_range_encode(const RcJob* __restrict__ j
   }
 }
 
+// coded streams side by side: stream j's out_len[j] bytes go to packed + offset[j]
+__global__ __launch_bounds__(256) void k_pack_streams(const RcJob* __restrict__ jobs, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ packed,
+                                                      uint32_t n_jobs) {
+  const uint32_t jb = blockIdx.x;
+  if (jb >= n_jobs) return;
+  const RcJob job = jobs[jb];
+  const uint32_t len = *job.out_len;
+  uint8_t* dst = packed + offsets[jb];  // 16-byte aligned, like job.out
+  const uint32_t vec = len / 16u;
+  for (uint32_t k = threadIdx.x; k < vec; k += 256u) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(job.out)[k];
+  for (uint32_t k = vec * 16u + threadIdx.x; k < len; k += 256u) dst[k] = job.out[k];
+}
+
 }  // namespace
+
+void launch_pack_streams(const RcJob* dev_jobs, const uint32_t* dev_offsets, uint8_t* dev_packed, uint32_t n_jobs, hipStream_t stream) {
+  if (n_jobs) hipLaunchKernelGGL(k_pack_streams, dim3(n_jobs), dim3(256), 0, stream, dev_jobs, dev_offsets, dev_packed, n_jobs);
+}
 
 void launch_range_encode(const RcJob* dev_jobs, uint32_t n_jobs, hipStream_t stream) {
   if (n_jobs) hipLaunchKernelGGL(k_range_encode, dim3(n_jobs), dim3(64), 0, stream, dev_jobs, n_jobs);

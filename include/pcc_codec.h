@@ -228,6 +228,12 @@ int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 typedef struct pcc_pipeline pcc_pipeline;
 pcc_pipeline *pcc_pipeline_create(int device, int n_workers);
 void pcc_pipeline_destroy(pcc_pipeline *p);
+/* pipeline knobs (no output byte changes), to be set between calls:
+ *   "entropy_on_gpu" (default 0; environment PCC_PIPELINE_ENTROPY=gpu sets 1): the range coders of the entropy stage run
+ *                 on the GPU (pcc_entropy_batch), the entropy threads only copy, stitch JPEG rows and assemble -- for hosts
+ *                 with fewer cores than the GPU stage can feed.  A flush takes ~0.1 s whatever its size.
+ *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread. */
+int pcc_pipeline_set_option(pcc_pipeline *p, const char *name, int value);
 int pcc_pipeline_workers(pcc_pipeline *p);
 int pcc_pipeline_contexts(pcc_pipeline *p);
 pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option / pcc_set_profiling / kernel times */
@@ -352,6 +358,22 @@ int pcc_decode_delta(pcc_ctx *ctx, const pcc_point_xyzrgb *i_cloud, size_t n_i, 
  * is the measurement / test harness of the kernel, the frame pipeline does not use it yet. */
 int pcc_device_range_encode(pcc_ctx *ctx, int n_streams, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
                             size_t *out_len, float *gpu_ms);
+
+/* ---- the entropy stage of MANY frames with the range coders on the GPU ----
+ * For hosts with fewer CPU cores than their GPUs can feed (the north star keeps the serial coder on the host, and with
+ * 16 cores per GPU that is the faster place).  pcc_entropy_batch_add copies what a frame's entropy stage needs out of
+ * the frame's hot-path products -- so the context that produced it is free again -- and puts the colour JPEG together on the host;
+ * pcc_entropy_batch_flush range-codes every stream of the batch on the GPU (one wave per stream, ~0.1 s per flush
+ * whatever the batch size: use batches of hundreds of frames) and assembles the bitstreams -- byte-identical to
+ * pcc_entropy_encode.  out[i] (i-th frame added) stays valid until the next flush. */
+typedef struct pcc_entropy_batch pcc_entropy_batch;
+pcc_entropy_batch *pcc_entropy_batch_create(int device, size_t max_frames);
+void pcc_entropy_batch_destroy(pcc_entropy_batch *b);
+size_t pcc_entropy_batch_size(pcc_entropy_batch *b);
+size_t pcc_entropy_batch_capacity(pcc_entropy_batch *b);
+int pcc_entropy_batch_add(pcc_entropy_batch *b, const pcc_hot_result *hot, const pcc_params *params); /* index, or < 0 */
+int pcc_entropy_batch_flush(pcc_entropy_batch *b, pcc_bitstream *out, size_t out_capacity, size_t *n_out);
+const char *pcc_entropy_batch_last_error(pcc_entropy_batch *b);
 
 /* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
 /* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).

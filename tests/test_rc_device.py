@@ -43,3 +43,64 @@ def test_device_range_coder_many_streams_at_once(pkg, ctx):
     got, _ = ctx.device_range_encode(streams)
     assert got == [b.host_range_encode(s) for s in streams]
     assert ctx.device_range_encode([])[0] == []
+
+
+@pytest.mark.gpu
+def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
+    """pcc_entropy_batch: the entropy stage of many frames with the range coders on the GPU -- every coding mode, with and
+    without centroids, geometry only, a three-point frame; byte-identical to the oracle's bitstreams.  Then the frame
+    pipeline in that mode (pcc_pipeline_set_option "entropy_on_gpu")."""
+    import ctypes as C
+    import numpy as np
+    b = pkg.binding
+    lib = b.load_library()
+    ctx = b.Context(0)
+    batch = lib.pcc_entropy_batch_create(0, 64)
+    assert batch
+    cases = [dict(octree_bits=8, color_coding_type=1, jpeg_quality=85), dict(octree_bits=8, color_coding_type=0, color_bits=6, keep_centroid=1),
+             dict(octree_bits=7, color_coding_type=2, jpeg_quality=50), dict(octree_bits=7, color_coding_type=3, keep_centroid=1),
+             dict(octree_bits=9, color_bits=0), dict(octree_bits=8, color_coding_type=1, jpeg_quality=30, keep_centroid=1)]
+    want = []
+    try:
+        for rep in range(2):
+            want.clear()
+            for k, kw in enumerate(cases * 2):
+                n = [30_000, 3, 7_000, 90_000][k % 4]
+                pts = pkg.synthetic.sphere_shell(n, 0x600 + k)
+                want.append(oracle.encode_intra(pts, oracle.make_params(frame_id=k + 1, **kw)))
+                prm = b.make_params(frame_id=k + 1, **kw)
+                dev = ctx.upload(pts)
+                ctx.hotpath_launch(dev, n, prm)
+                hot = ctx.hotpath_finish(copy=False)
+                assert lib.pcc_entropy_batch_add(batch, C.byref(hot.raw), C.byref(prm)) == k
+                ctx.free(dev)   # the batch holds its own copies: the context and the cloud may go
+            outs = (b.Bitstream * len(want))()
+            got_n = C.c_size_t()
+            assert lib.pcc_entropy_batch_flush(batch, outs, len(want), C.byref(got_n)) == 0, lib.pcc_entropy_batch_last_error(batch)
+            assert got_n.value == len(want) and lib.pcc_entropy_batch_size(batch) == 0
+            for o, w in zip(outs, want):
+                assert C.string_at(o.data, o.len) == w.bitstream and [int(x) for x in o.perf] == list(w.perf)
+    finally:
+        lib.pcc_entropy_batch_destroy(batch)
+        ctx.close()
+    # the pipeline with its entropy stage on the GPU
+    sizes = [20_000, 5_000, 31_000, 12_345, 800, 26_000, 9_999, 2, 16_000]
+    frames = [pkg.synthetic.sphere_shell(n, 0x680 + i) for i, n in enumerate(sizes)]
+    frames[3]["z"] = np.nan   # dropped
+    kw = dict(octree_bits=8, jpeg_quality=80)
+    ref, fid = [], 2
+    for f in frames:
+        r = oracle.encode_intra(f, oracle.make_params(frame_id=fid, **kw), keep=False)
+        ref.append(b"" if r is None else r.bitstream)
+        fid += 0 if r is None else 1
+    pipe = b.Pipeline(0, workers=2)
+    try:
+        pipe.set_option("entropy_on_gpu", 1)
+        pipe.set_option("entropy_gpu_batch", 4)   # several flushes per thread and a partial one at the end
+        for rep in range(2):
+            got = pipe.encode_host(frames, b.make_params(frame_id=2, **kw))
+            assert [g[0] for g in got] == ref
+        pipe.set_option("entropy_on_gpu", 0)
+        assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
+    finally:
+        pipe.close()

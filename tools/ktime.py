@@ -11,7 +11,8 @@ cfg = syn.CONFIGS[wl]
 p = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
                   jpeg_quality=cfg["jpeg_quality"])
 ctx = b.Context(0); pts = syn.make_frame(wl); dev = ctx.upload(pts)
-ntiles = min(1024, (len(pts) + 4095) // 4096)   # stamps exist for the first 1024 workgroups of a launch
+grid = (len(pts) + 4095) // 4096
+ntiles = (grid + (grid + 1023) // 1024 - 1) // ((grid + 1023) // 1024)   # every k-th workgroup of a large grid is sampled
 for _ in range(5):
     ctx.hotpath_launch(dev, len(pts), p); hot = ctx.hotpath_finish(copy=False)
 buf = np.zeros(9 * 1024 * 8, dtype=np.uint64)
@@ -28,7 +29,14 @@ for ps in range(hot.depth * 3 // 9 + 1 if wl != "cfg2" else 4):
     print("        per workgroup (median us): ticket+totals %.2f  keys+histogram %.2f  ranking %.2f  look-back %.2f  reorder+write %.2f  whole %.2f" % (
         np.median(d[:, 1] - d[:, 0]), np.median(d[:, 2] - d[:, 1]), np.median(d[:, 4] - d[:, 3]), np.median(d[:, 7] - d[:, 4]),
         np.median(d[:, 5] - d[:, 7]), np.median(d[:, 5] - d[:, 0])))
-nlt = min(1024, hot.n_leaves // 4096 + 1)
+    order = np.argsort(d[:, 0])
+    q = max(1, len(order) // 4)
+    for name, part in (("first quarter to start", order[:q]), ("last quarter to start", order[-q:])):
+        e = d[part]
+        print("          %-22s: start at %.1f us, look-back %.2f us, whole %.2f us" % (name, np.median(e[:, 0] - d[:, 0].min()), np.median(e[:, 7] - e[:, 4]), np.median(e[:, 5] - e[:, 0])))
+    print("          launch: first start to last end %.1f us" % (d[:, 5].max() - d[:, 0].min()))
+gl = len(pts) // 4096 + 1
+nlt = (gl + (gl + 1023) // 1024 - 1) // ((gl + 1023) // 1024)
 x = t[5, :nlt, :7]
 rel = (x - x[:, 0].min()) / 100.0
 print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end:", np.round(np.median(rel, axis=0), 2))
