@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the legs that start from host memory")
     ap.add_argument("--host-frames", type=int, default=0, help="frames of the host-input legs (0 = min(steps, 256))")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
+    ap.add_argument("--traffic-json", default="",
                     help="per-kernel HBM bytes per launch from a separate rocprofv3 --pmc run (tools/pmc_traffic.py)")
     return ap.parse_args()
 
@@ -172,7 +172,8 @@ def main():
 
     # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
     # without taxing every stream (the free list is a stack: its top context takes part in every round)
-    prof_ctxs = [pipe.context(pipe.n_contexts - 1 - k) for k in range(min(4, pipe.n_contexts))]
+    # (only in long runs: a profiled frame creates its events on first use, which a 20-frame region would mostly consist of)
+    prof_ctxs = [pipe.context(pipe.n_contexts - 1 - k) for k in range(min(4, pipe.n_contexts))] if args.steps >= 256 else []
     for c in prof_ctxs:
         c.set_profiling(True)
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
@@ -213,6 +214,7 @@ def main():
     path_bytes = 32 * n_points + L * (3 if with_color else 0) + B + 16 * L  # SURVEY.md 8(d), with output_ cloud
     roofline = None
     span_frame_ms, event_frame_ms, launches = {}, {}, {}
+    pitch_ms, pitch_n = {}, {}
     path_ms = None
     if rank == 0:
         reps = 24 if n_points <= 2_000_000 else 8
@@ -224,26 +226,36 @@ def main():
                 plain.append(h.gpu_ms)
         path_ms = float(np.mean(plain))
         ctx0.set_profiling(True)
-        for k in range(reps + 2):
-            ctx0.hotpath_launch(dev_frames[k % n_distinct], n_points, params)
-            ctx0.hotpath_finish(copy=False)
-            if k < 2:
-                continue
-            for name, ms in ctx0.kernel_spans():
-                span_frame_ms[name] = span_frame_ms.get(name, 0.0) + ms / reps
-                launches[name] = launches.get(name, 0.0) + 1.0 / reps
-            for name, ms in ctx0.kernel_times():
-                event_frame_ms[name] = event_frame_ms.get(name, 0.0) + ms / reps
+        for events in (0, 1):   # the launch spans alone (launches back to back, as unprofiled), then with HIP events in between
+            ctx0.set_option("profile_events", events)
+            for k in range(reps + 2):
+                ctx0.hotpath_launch(dev_frames[k % n_distinct], n_points, params)
+                ctx0.hotpath_finish(copy=False)
+                if k < 2:
+                    continue
+                if events:
+                    for name, ms in ctx0.kernel_times():
+                        event_frame_ms[name] = event_frame_ms.get(name, 0.0) + ms / reps
+                    continue
+                for name, ms in ctx0.kernel_spans():
+                    span_frame_ms[name] = span_frame_ms.get(name, 0.0) + ms / reps
+                    launches[name] = launches.get(name, 0.0) + 1.0 / reps
+                for name, ms in ctx0.kernel_pitches():
+                    pitch_ms[name] = pitch_ms.get(name, 0.0) + ms
+                    pitch_n[name] = pitch_n.get(name, 0) + 1
         ctx0.set_profiling(False)
     if span_frame_ms:
         dominant = max(span_frame_ms, key=span_frame_ms.get)
-        dom_ms = span_frame_ms[dominant] / launches[dominant]
+        # duration of a launch = from its start to the start of the next launch of the frame: the span of its workgroups plus
+        # the dispatch and the end-of-kernel write-back, i.e. what `rocprofv3 --kernel-trace` calls the duration
+        span_ms = span_frame_ms[dominant] / launches[dominant]
+        dom_ms = pitch_ms[dominant] / pitch_n[dominant] if pitch_n.get(dominant) else span_ms
         dom_bytes = kernel_algorithmic_bytes(dominant, n_points, L, B, with_color, image_bytes)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         sum_spans = float(sum(span_frame_ms.values()))
         traffic = None
         try:
-            with open(args.traffic_json) as fh:
+            with open(args.traffic_json or os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)) as fh:
                 tj = json.load(fh)
             if tj.get("workload") == args.workload:
                 traffic = tj.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
@@ -258,15 +270,17 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
             "kernel_avg_ms": round(dom_ms, 5), "kernel_bytes_per_launch": int(dom_bytes),
             "kernel_launches_per_frame": round(launches[dominant], 2),
-            "kernel_ms_per_frame": round(span_frame_ms[dominant], 5),
+            "kernel_span_ms": round(span_ms, 5),
+            "kernel_ms_per_frame": round(dom_ms * launches[dominant], 5),
             "kernel_avg_ms_hip_events": round(event_frame_ms.get(dominant, 0.0) / max(launches[dominant], 1e-9), 5),
-            "how": "one frame at a time on one stream; span = first workgroup start to last wave end on the GPU's real-time clock",
+            "how": "one frame at a time on one stream, GPU real-time clock: kernel_avg_ms = start of the launch to start of the next "
+                   "launch of the frame (what a kernel trace reports as duration); kernel_span_ms = first workgroup start to last wave end",
             "path_bytes_per_frame": int(path_bytes), "path_gpu_ms": round(path_ms, 5),
             "path_sum_of_kernel_spans_ms": round(sum_spans, 5),
             "path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
             "path_frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
             "frames_in_flight_in_timed_region": int(min(pipe.n_contexts, 6)),
-            "kernel_avg_ms_sharing_the_gpu": round(shared.get(dominant, 0.0), 5),
+            "kernel_avg_ms_sharing_the_gpu": round(shared.get(dominant, 0.0), 5) if shared else None,
         }
 
     # ---- the same work starting from HOST memory (the reference's timed span starts there, eval.hpp:462-464) ----

@@ -31,7 +31,7 @@ EXPORTS = [
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
     "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra", "pcc_decode_intra_gpu", "pcc_get_decode_times",
-    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_host_times",
+    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
     "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_workers", "pcc_pipeline_contexts",
@@ -163,6 +163,7 @@ def load_library():
     lib.pcc_device_free.argtypes = [vp, vp]
     lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
     lib.pcc_get_kernel_spans.argtypes = [vp, C.POINTER(KernelTimes)]
+    lib.pcc_get_kernel_span_starts.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_get_host_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_set_profiling.argtypes = [vp, i32]
@@ -492,6 +493,14 @@ class Context:
         kt = KernelTimes()
         self._check(self.lib.pcc_get_kernel_spans(self.h, C.byref(kt)))
         return [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
+
+    def kernel_pitches(self):
+        """[(kernel, ms)]: from the start of a launch to the start of the next one of the frame (the last launch of the
+        frame has no successor and is left out): what the launch cost its stream."""
+        kt = KernelTimes()
+        self._check(self.lib.pcc_get_kernel_span_starts(self.h, C.byref(kt)))
+        st = [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
+        return [(st[i][0], st[i + 1][1] - st[i][1]) for i in range(len(st) - 1)]
 
 
 def pinned_array(lib, template: np.ndarray):

@@ -81,6 +81,7 @@ struct pcc_ctx {
   const void* locked_host = nullptr;  // host range page-locked for the frame in flight (released by pcc_hotpath_finish)
   std::string err;
   bool profiling = false;
+  bool profile_events = true;  // with profiling: HIP events between the launches as well (they lengthen what they measure)
   KernelTimer timer;
   std::vector<std::pair<const char*, float>> times;
   // device-side launch spans (first workgroup start .. last wave end on the GPU's real-time clock), profiling only
@@ -88,6 +89,7 @@ struct pcc_ctx {
   PinnedBuf<unsigned long long> h_spans;
   std::vector<const char*> span_names;
   std::vector<std::pair<const char*, float>> span_times;
+  std::vector<float> span_starts;  // ms from the first launch's first workgroup to this launch's first workgroup
   double wall_clock_khz = 100000.0;
 
   // HBM arena (see pcc_device.h for the layout)
@@ -289,7 +291,7 @@ int enqueue(pcc_ctx* ctx) {
   }
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
   if (ctx->profiling) ctx->timer.reset(); else ctx->times.clear();
-  launch_hot_path(ctx->args, ctx->stream, ctx->profiling ? &ctx->timer : nullptr);
+  launch_hot_path(ctx->args, ctx->stream, (ctx->profiling && ctx->profile_events) ? &ctx->timer : nullptr);
   {
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
@@ -420,6 +422,11 @@ const char* pcc_last_error(pcc_ctx* c) { return c ? c->err.c_str() : "no context
 int pcc_set_profiling(pcc_ctx* ctx, int enabled) {
   if (!ctx) return PCC_ERR_ARG;
   ctx->profiling = enabled != 0;
+  if (enabled && ctx->device >= 0) {  // the buffers of the launch spans now, not inside somebody's timed region
+    PCC_HIP(hipSetDevice(ctx->device));
+    PCC_HIP(ctx->d_spans.ensure(kSpanWords));
+    PCC_HIP(ctx->h_spans.ensure(kSpanWords));
+  }
   return PCC_OK;
 }
 
@@ -427,6 +434,7 @@ int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return PCC_ERR_ARG;
   if (!strcmp(name, "jpeg_on_gpu")) ctx->jpeg_on_gpu = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "copy_image")) ctx->copy_image = value != 0;
+  else if (!strcmp(name, "profile_events")) ctx->profile_events = value != 0;
   else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
 }
@@ -447,6 +455,16 @@ int pcc_get_kernel_spans(pcc_ctx* ctx, pcc_kernel_times* out) {
   for (int i = 0; i < out->count; ++i) {
     out->name[i] = ctx->span_times[i].first;
     out->ms[i] = ctx->span_times[i].second;
+  }
+  return PCC_OK;
+}
+
+int pcc_get_kernel_span_starts(pcc_ctx* ctx, pcc_kernel_times* out) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  out->count = (int32_t)std::min(ctx->span_starts.size(), (size_t)PCC_MAX_KERNEL_TIMES);
+  for (int i = 0; i < out->count; ++i) {
+    out->name[i] = ctx->span_times[(size_t)i].first;
+    out->ms[i] = ctx->span_starts[(size_t)i];
   }
   return PCC_OK;
 }
@@ -701,8 +719,10 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   (void)hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end);
   out->gpu_ms = ms;
   if (ctx->profiling) {
-    ctx->timer.collect(ctx->times);
+    if (ctx->profile_events) ctx->timer.collect(ctx->times); else ctx->times.clear();
     ctx->span_times.clear();
+    ctx->span_starts.clear();
+    unsigned long long origin = ~0ull;
     int sort_seen = 0;
     for (size_t i = 0; i < ctx->span_names.size() && i < (size_t)kMaxSpans; ++i) {
       const unsigned long long* w = ctx->h_spans.p + i * 2 * kSpanShards;
@@ -712,7 +732,9 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
       const bool is_sort = !strcmp(ctx->span_names[i], "k_sort_pass");
       if (is_sort && ++sort_seen > st.npasses) continue;  // enqueued, but the frame did not need the pass
       if (t0 == ~0ull || t1 < t0) continue;
+      if (origin == ~0ull) origin = t0;
       ctx->span_times.emplace_back(ctx->span_names[i], (float)((double)(t1 - t0) / ctx->wall_clock_khz));
+      ctx->span_starts.push_back((float)((double)(t0 - origin) / ctx->wall_clock_khz));
     }
   }
   if (src != PCC_OK) return src;
@@ -1848,18 +1870,14 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   }
   if (i_len) {  // the intra coded points follow the predicted ones (impl.hpp:1207-1229)
     pcc_cloud ic;
-    int rc;
-    try {
-      rc = decode_frame(i_stream, i_len, ctx->dec_points, ic);
-    } catch (const std::bad_alloc&) {
-      ctx->dec_points.clear();
-      rc = PCC_ERR_STREAM;
-    }
+    // the decoder with its data-parallel half on the GPU; it waits for the context's stream, i.e. also for the copy above
+    const int rc = pcc_decode_intra_gpu(ctx, i_stream, i_len, &ic);
     if (rc != PCC_OK) return fail(ctx, rc, "decode: intra part of the delta frame: header not found, or stream truncated/corrupt");
     out->params = ic.params; out->depth = ic.depth; out->consumed = ic.consumed;
     for (int a = 0; a < 6; ++a) out->bbox[a] = ic.bbox[a];
+    const pcc_point_xyzrgb* intra_points = ic.points;
     mark("intra part decoded");
-    const size_t n_intra = ctx->dec_points.size();
+    const size_t n_intra = ic.n;
     if (ctx->delta_cloud.cap < ctx->delta_cloud_n + n_intra + 1) {  // grow, keeping the predicted points
       if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; delta_copy_pending = false; }
       PinnedBuf<pcc_point_xyzrgb> bigger;
@@ -1868,10 +1886,9 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
       ctx->delta_cloud.release();
       ctx->delta_cloud = bigger;
     }
-    if (n_intra) memcpy(ctx->delta_cloud.p + ctx->delta_cloud_n, ctx->dec_points.data(), n_intra * sizeof(pcc_point_xyzrgb));
+    if (n_intra) memcpy(ctx->delta_cloud.p + ctx->delta_cloud_n, intra_points, n_intra * sizeof(pcc_point_xyzrgb));
     ctx->delta_cloud_n += n_intra;
   }
-  if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   if (delta_copy_pending) { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; delta_copy_pending = false; }
   mark("done");
   out->points = ctx->delta_cloud.p;

@@ -488,7 +488,20 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->arena_used = 0;
     // Four frames in one coder loop use the least CPU per frame but take four times as long to come out: worth it when
     // the frames outnumber the threads (throughput), wrong for a short call (latency) -- there every thread takes one.
-    p->batch_now = (int)std::min<size_t>((size_t)p->batch, std::max<size_t>(1, n_frames / (2 * (size_t)p->n_entropy)));
+    // Which batch finishes a call of n frames on T threads first?  A batch of b frames costs b x c(b) of wall time
+    // (c = CPU per frame with b coders in one loop: 3.3, 1.9, 1.5, 1.3 ms for the headline frame, tools/rc_speed.py) and the
+    // call needs ceil(n / (b T)) rounds of them; long calls end up at four, a call of 20 frames on 16 threads at two.
+    {
+      static const double cost[PCC_MAX_FRAMES_AT_ONCE + 1] = {0.0, 3.3, 1.9, 1.5, 1.3};
+      int best = 1;
+      double best_t = 1e300;
+      for (int b = 1; b <= p->batch && b <= PCC_MAX_FRAMES_AT_ONCE; ++b) {
+        const size_t per_round = (size_t)b * (size_t)p->n_entropy;
+        const double t = (double)((n_frames + per_round - 1) / per_round) * (double)b * cost[b];
+        if (t < best_t - 1e-9) { best_t = t; best = b; }
+      }
+      p->batch_now = best;
+    }
     p->results.assign(n_frames, pcc_bitstream());
     p->status.assign(n_frames, PCC_OK);
     p->err.clear();

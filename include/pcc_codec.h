@@ -204,6 +204,10 @@ int pcc_get_kernel_times(pcc_ctx *ctx, pcc_kernel_times *out);
  * wave, on the device's real-time clock (what a kernel trace reports; the events above sit BETWEEN the launches and
  * add a few microseconds of their own to every short kernel).  Sort passes a frame did not need are left out. */
 int pcc_get_kernel_spans(pcc_ctx *ctx, pcc_kernel_times *out);
+/* ... and when each of those launches started, milliseconds after the first one: the distance between the starts of two
+ * consecutive launches is what a launch costs its stream (its span plus the dispatch and the end-of-kernel write-back
+ * that the span leaves out) -- the figure a kernel trace calls the kernel's duration. */
+int pcc_get_kernel_span_starts(pcc_ctx *ctx, pcc_kernel_times *out);
 /* wall time of the last pcc_entropy_encode on this context, microseconds: occupancy range coder, JPEG
  * stage, colour range coder, whole stage */
 int pcc_get_host_times(pcc_ctx *ctx, double out_us[4]);
@@ -215,7 +219,10 @@ int pcc_set_profiling(pcc_ctx *ctx, int enabled);
  *                 together);  1 = up to the quantised coefficients, the host Huffman-codes;  0 = the host starts
  *                 from the image.
  *   "copy_image"  (default 1): bring the snake-mapped image itself back in pcc_hot_result.image (needed only
- *                 for inspection when jpeg_on_gpu is 1). */
+ *                 for inspection when jpeg_on_gpu is 1).
+ *   "profile_events" (default 1): with pcc_set_profiling, also record HIP events between the launches
+ *                 (pcc_get_kernel_times); 0 leaves only the launch spans on the GPU clock, so that the launches run
+ *                 back to back as they do unprofiled. */
 int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 
 /* ---- a sequence of frames on one GPU (the app's frame loop, eval.hpp:818-835) ----

@@ -20,8 +20,9 @@ ctx.set_option("copy_image", 0)
 pts = syn.make_frame(wl)
 dev = ctx.upload(pts)
 n = len(pts)
-for prof in (0, 1):
-    ctx.set_profiling(prof)
+for prof in (0, 1, 2):   # 0 unprofiled, 1 HIP events between the launches + spans, 2 spans only (launches back to back)
+    ctx.set_profiling(prof != 0)
+    ctx.set_option("profile_events", 1 if prof == 1 else 0)
     ms, wall = [], []
     agg, spans = {}, {}
     for k in range(K + 3):
@@ -32,13 +33,14 @@ for prof in (0, 1):
         if k >= 3:
             ms.append(hot.gpu_ms); wall.append(w * 1e3)
             if prof:
-                for name, v in ctx.kernel_times():
+                for name, v in (ctx.kernel_times() if prof == 1 else ctx.kernel_pitches()):
                     e = agg.setdefault(name, [0.0, 0]); e[0] += v; e[1] += 1
                 for name, v in ctx.kernel_spans():
                     e = spans.setdefault(name, [0.0, 0]); e[0] += v; e[1] += 1
     print("%s N=%d L=%d B=%d D=%d  profiling=%d: gpu %.1f us (min %.1f)  launch+finish wall %.1f us" %
           (wl, n, hot.n_leaves, hot.n_branches, hot.depth, prof, 1e3 * np.mean(ms), 1e3 * np.min(ms), 1e3 * np.mean(wall)))
     if prof:
+        print("   (%s)" % ("first column: HIP events between the launches" if prof == 1 else "first column: start of a launch to start of the next one, GPU clock"))
         for name, (tot, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
             sp = spans.get(name, [0.0, 1])
             print("   %-22s %5.1f launches/frame  %8.2f us each  %8.2f us/frame   on the GPU clock: %8.2f us each  %8.2f us/frame" %

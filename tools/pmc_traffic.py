@@ -17,6 +17,7 @@ def per_kernel(counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("pcc::", "").replace("void ", "")
+            name = re.sub(r"<.*", "", name)   # k_sort_pass<1024, 4> and k_sort_pass<512, 8> are one kernel here
             acc.setdefault(name, []).append(float(row["Counter_Value"]))
     return acc
 
@@ -35,5 +36,5 @@ for name in sorted(set(fetch) | set(write)):
                      "hbm_bytes_per_launch": int(fm * 1024 * 2 + wm * 1024), "launches_sampled": len(f)}
 res = {"workload": workload, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/gpu_latency.py; "
        "bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 correction of MI355X_MICROARCH.md)", "kernels": kernels}
-json.dump(res, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out_dir, "hbm_traffic_%s.json" % workload), "w"), indent=1)
 print(json.dumps(res, indent=1))
