@@ -1,0 +1,54 @@
+"""bench.py's contract with the driver: one JSON line with the named fields; `--gpus N` outside torchrun starts its
+ranks itself (it used to run one rank silently and print n_gpus 1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_without_a_gpu_fails_loudly():
+    """No GPU here: the bench must refuse (the hot path has no CPU fallback), not print a number."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_one_line_with_roofline_host_input_and_cpu_baseline():
+    d = _run(["--steps", "64", "--warmup", "4", "--cpu-frames", "2", "--host-frames", "32"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "host_input"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 64 and d["value"] > 0 and d["unit"] == "Mpoints/s" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["kernel"] == "k_sort_pass" and r["bound"] == "hbm" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 0.005 < r["kernel_span_ms"] <= r["kernel_avg_ms"] <= r["kernel_avg_ms_hip_events"] * 1.05
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["host_input"]["e2e_from_host_mpoints_per_s"] > 0 and "workload" in d["config"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_started_by_the_bench_itself():
+    """`python bench.py --gpus 2` with no torchrun environment: two ranks (sharing GPU 0 over gloo on a 1-GPU box), n_gpus 2,
+    value = the frames of both ranks over the slower rank's time."""
+    d = _run(["--gpus", "2", "--steps", "48", "--warmup", "4", "--no-cpu-baseline", "--no-host-input", "--workers", "6"],
+             env={"PCC_BENCH_SHARE_GPU0": "1"})
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_gpu"] == 48
