@@ -65,8 +65,8 @@ def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
         return (16 + pay) * n + (8 + pay) * n   # read xyz (+ colour word), write key (+ payload)
     if name == "k_sort_pass":
         return 2 * (8 + pay) * n           # read key + payload, write key + payload
-    if name == "k_leaf_sort":
-        return 2 * (8 + pay) * n + 17 * L + B   # read + write keys and payload (local sort); start, code, base, t per leaf; zero the DFS stream
+    if name == "k_leaf_scan":
+        return 8 * n + 17 * L + B          # read keys; write start, code, base, t per leaf; zero the DFS stream
     if name == "k_leaf_tile":
         coefs = image_bytes                # 1.5 int16 coefficients per pixel = 3 bytes per pixel
         return 17 * L + pay * n + (3 * L + coefs if with_color else 0) + 16 * L + B
@@ -179,17 +179,12 @@ def main():
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
     trace("warm-up done")
     sync_all()
-    import resource
-    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    ru1 = resource.getrusage(resource.RUSAGE_SELF)
-    trace("timed region done: %.3f s  (user %.1f ms, sys %.1f ms, minor faults %d, major %d, ctx switches %d + %d)" % (
-        elapsed, 1e3 * (ru1.ru_utime - ru0.ru_utime), 1e3 * (ru1.ru_stime - ru0.ru_stime), ru1.ru_minflt - ru0.ru_minflt,
-        ru1.ru_majflt - ru0.ru_majflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
+    trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
     ktimes, profiled = pipe.kernel_times()
     for c in prof_ctxs:

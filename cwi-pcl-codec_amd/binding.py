@@ -31,7 +31,7 @@ EXPORTS = [
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
     "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra", "pcc_decode_intra_gpu", "pcc_get_decode_times",
-    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_sort_plan", "pcc_get_host_times",
+    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
     "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_workers", "pcc_pipeline_contexts",
@@ -164,7 +164,6 @@ def load_library():
     lib.pcc_device_upload.argtypes = [vp, vp, vp, sz]
     lib.pcc_get_kernel_spans.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_get_kernel_span_starts.argtypes = [vp, C.POINTER(KernelTimes)]
-    lib.pcc_get_sort_plan.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.pcc_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     lib.pcc_get_host_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pcc_set_profiling.argtypes = [vp, i32]
@@ -494,12 +493,6 @@ class Context:
         kt = KernelTimes()
         self._check(self.lib.pcc_get_kernel_spans(self.h, C.byref(kt)))
         return [(kt.name[i].decode(), float(kt.ms[i])) for i in range(kt.count)]
-
-    def sort_plan(self):
-        """How the last finished frame was sorted: dict(hybrid, global_passes, local_bits, lsd_reruns, lsd_frames_left, device_error)."""
-        buf = (C.c_int32 * 6)()
-        self._check(self.lib.pcc_get_sort_plan(self.h, buf))
-        return dict(zip(("hybrid", "global_passes", "local_bits", "lsd_reruns", "lsd_frames_left", "device_error"), [int(v) for v in buf]))
 
     def kernel_pitches(self):
         """[(kernel, ms)]: from the start of a launch to the start of the next one of the frame (the last launch of the

@@ -161,12 +161,6 @@ struct pcc_ctx {
   // frame in flight
   HotPathArgs args{};          // what was enqueued (kept so that a frame that needs more sort passes can be re-run)
   int pass_hint = kMaxPasses;  // sort passes to enqueue: the previous frame's need (sequences are coherent)
-  // Sort plan (DESIGN.md "Sort"): hybrid unless a frame of this context needed the plain LSD plan lately (a bucket of
-  // equal high code bits did not fit one workgroup: far outliers around a dense cluster); it is tried again after
-  // `lsd_frames_left` frames.  PCC_SORT=lsd|hybrid pins the plan (tests, measurements).
-  bool hybrid = true;
-  int lsd_frames_left = 0;
-  int lsd_reruns = 0;  // frames that ran again with the plain LSD plan
   bool launched = false;
   size_t n = 0;
   pcc_params params{};
@@ -279,16 +273,6 @@ int wait_stream(pcc_ctx* ctx, int site = 2) {
   const double took = (double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec);
   usual = usual == 0.0 ? took : 0.75 * usual + 0.25 * took;
   return PCC_OK;
-}
-
-// PCC_SORT=lsd|hybrid pins the sort plan (tests, measurements): 1 plain LSD, 2 hybrid and NO fall-back to LSD (a frame
-// that needs it fails), 0 not pinned
-int sort_plan_pinned() {
-  static const int pinned = [] {
-    const char* e = getenv("PCC_SORT");
-    return !e ? 0 : (!strcmp(e, "lsd") ? 1 : (!strcmp(e, "hybrid") ? 2 : 0));
-  }();
-  return pinned;
 }
 
 // the kernel sequence of one frame + the FrameState read-back, all asynchronous on the context's stream
@@ -485,14 +469,6 @@ int pcc_get_kernel_span_starts(pcc_ctx* ctx, pcc_kernel_times* out) {
   return PCC_OK;
 }
 
-int pcc_get_sort_plan(pcc_ctx* ctx, int32_t out[6]) {
-  if (!ctx || !out) return PCC_ERR_ARG;
-  if (!ctx->h_state.p) return fail(ctx, PCC_ERR_STATE, "no frame yet");
-  const FrameState& st = *ctx->h_state.p;
-  out[0] = ctx->args.hybrid; out[1] = st.npasses; out[2] = st.local_bits; out[3] = ctx->lsd_reruns; out[4] = ctx->lsd_frames_left; out[5] = st.error;
-  return PCC_OK;
-}
-
 int pcc_get_host_times(pcc_ctx* ctx, double out_us[4]) {
   if (!ctx || !out_us) return PCC_ERR_ARG;
   for (int i = 0; i < 4; ++i) out_us[i] = ctx->host_us[i];
@@ -562,15 +538,6 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.lp.do_centroid = prm->do_voxel_centroid ? 1u : 0u;
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
   a.max_passes = std::min(std::max(ctx->pass_hint, 1), (int)kMaxPasses);
-  {
-    const int pinned = sort_plan_pinned();
-    if (!ctx->hybrid && ctx->lsd_frames_left > 0 && --ctx->lsd_frames_left == 0) {
-      ctx->hybrid = true;  // try the hybrid plan again; the pass hint of the LSD frames does not apply to it
-      ctx->pass_hint = kMaxPasses;
-      a.max_passes = kMaxPasses;
-    }
-    a.hybrid = pinned == 1 ? 0 : (pinned == 2 ? 1 : (ctx->hybrid ? 1 : 0));
-  }
   {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
@@ -684,18 +651,6 @@ static int wait_frame_state(pcc_ctx* ctx) {
   const FrameState& st = *ctx->h_state.p;
   if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
     // deeper tree than the frames before: run the frame again with every pass enqueued
-    ctx->args.max_passes = kMaxPasses;
-    const int rc = enqueue(ctx);
-    if (rc != PCC_OK) return rc;
-    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
-  }
-  if (st.error == kErrLocal && ctx->args.hybrid && sort_plan_pinned() != 2) {
-    // A bucket of equal high code bits is larger than a workgroup of k_leaf_sort can hold: this frame, and the next
-    // ones of this context, take the plain LSD plan (every bit sorted by global passes).
-    ctx->hybrid = false;
-    ctx->lsd_frames_left = 64;
-    ++ctx->lsd_reruns;
-    ctx->args.hybrid = 0;
     ctx->args.max_passes = kMaxPasses;
     const int rc = enqueue(ctx);
     if (rc != PCC_OK) return rc;
@@ -1604,7 +1559,7 @@ static int block_tree_of(pcc_ctx* owner, pcc_ctx* sc, const void* dev_points, si
   if (rc != PCC_OK) return fail(owner, rc, std::string("macroblock tree: ") + sc->err);
   const FrameState& st = *sc->h_state.p;
   if (!st.packed) return fail(owner, PCC_ERR_UNSUPPORTED, "macroblock tree: key and point index do not fit 64 bits");
-  t.sorted_keys = st.sorted_buf ? sc->d_keys_b.p : sc->d_keys_a.p;
+  t.sorted_keys = (st.npasses & 1) ? sc->d_keys_b.p : sc->d_keys_a.p;
   t.leaf_start = sc->d_leaf_start.p;
   t.leaf_code = sc->d_leaf_code.p;
   t.prefix_code = host_morton3(st.prefix[0], st.prefix[1], st.prefix[2]);

@@ -5,7 +5,7 @@
 //   OpenMP loop over blocks, impl.hpp:544-567, 974-989): here one workgroup per block,
 //   and the assembly of the residual (intra coded) points and of the predicted cloud.
 // The macroblock trees themselves are hot-path runs (defined box [0,1]^3, resolution * macroblock size, stopped
-// after k_leaf_sort): leaf = macroblock, sorted keys = points in block order.
+// after k_leaf_scan): leaf = macroblock, sorted keys = points in block order.
 //
 // ICP: PCL is not in the reference tree, so its IterativeClosestPoint cannot be matched bit for bit ("parity
 // unpinned"); what is restated is PCL 1.10's default pipeline: nearest-neighbour correspondences, Umeyama / SVD

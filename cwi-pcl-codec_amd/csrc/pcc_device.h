@@ -41,13 +41,6 @@ constexpr int kMaxPasses = 7;              // 63 code bits / 9
 constexpr uint32_t kStatusAggregate = 1u << 30, kStatusInclusive = 2u << 30, kStatusValue = (1u << 30) - 1u;
 constexpr int kLookBackGroup = 16;         // tiles per look-back group (two-level look-back)
 constexpr uint32_t kSpinLimit = 1u << 20;  // bounded polling: a lost predecessor becomes an error, not a hang
-// hybrid sort (DESIGN.md "Sort"): one or two global passes order the HIGH code bits, then every workgroup of
-// k_leaf_sort sorts the low bits of a run of whole buckets in LDS and scans the leaves while the keys are there
-constexpr int kTopBitsMax = 12;            // widest top digit: a 4096-entry table of cell numbers
-constexpr int kLsThreads = 512;            // 8 wave64; ~77 KB of LDS: two workgroups per CU
-constexpr int kLsItems = 8;
-constexpr int kLsCap = kLsThreads * kLsItems;  // 4096 keys fit one workgroup ...
-constexpr int kLsTile = 2048;              // ... which takes 2048 plus what is left of the bucket that straddles its end
 
 struct ChunkBox {          // 32 bytes
   float mn[3];
@@ -63,7 +56,6 @@ enum FrameError : int32_t {
   kErrEpochs = 3,          // more than kMaxEpochs growth epochs
   kErrPasses = 4,          // the frame needs more sort passes than the host enqueued (host re-launches)
   kErrSpin = 5,            // a look-back poll ran into kSpinLimit (should not happen)
-  kErrLocal = 6,           // hybrid sort: a bucket of equal high code bits does not fit one workgroup (host re-launches with the plain LSD plan)
 };
 
 struct FrameState {
@@ -88,12 +80,6 @@ struct FrameState {
   int32_t pass_bits[kMaxPasses];     // digit width of each pass
   int32_t pass_shift[kMaxPasses];    // bit position of each digit inside the code (add ibits for the packed key)
   int32_t passes_launched;           // what the host enqueued (k_boxes_events checks npasses against it)
-  int32_t local_bits;                // hybrid sort: the low code bits that k_leaf_sort orders inside a workgroup (0: the global passes sort everything)
-  int32_t top_bits;                  // hybrid sort: code bits under the top digit, whose value is the Morton-ordered number of the
-                                     // top cell among those the points' box touches (build_top_table; 0: plain digits only)
-  uint32_t top_lo[3], top_hi[3];     // that box, in top cells per axis
-  int32_t top_sh[3];                 // key bits of each axis below its top-cell coordinate
-  int32_t sorted_buf;                // which of the ping-pong buffers holds the sorted keys / payload in the end (0: a, 1: b)
   uint32_t prefix[3];                // constant high key bits per axis (in place)
   // ---- leaves ----
   uint32_t n_leaves;                 // L

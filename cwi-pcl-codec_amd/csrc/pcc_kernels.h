@@ -63,7 +63,6 @@ struct HotPathArgs {
   LeafParams lp;
   int max_passes;  // sort passes to enqueue (the device decides how many do work; more needed => kErrPasses)
   int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
-  int hybrid;      // sort plan: 1 = global passes on the high code bits + k_leaf_sort on the low ones, 0 = plain LSD over all bits
   FixedBox box;    // defineBoundingBox before addPointsFromInputCloud
   int stop_after_leaf_scan;  // macroblock trees: only the sorted points and the leaf (= block) arrays are wanted
   uint64_t* boxes;     // eight {value, frame_seq} words per 2048-point chunk (zeroed when allocated)

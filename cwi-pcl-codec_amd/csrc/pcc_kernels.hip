@@ -5,10 +5,10 @@
 //   P1/P2  addPointsFromInputCloud + adoptBoundingBoxToPoint   -> k_boxes_events (chunk boxes + growth replay in one launch)
 //   P3     genOctreeKeyforPoint                                -> k_make_keys
 //   P4     createLeafRecursive + addPointIndex                 -> LSD radix sort (k_make_keys histograms, k_digit_totals, k_sort_pass)
-//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_sort (leaf scan) + k_leaf_tile
-//   C2/P6  serializeTreeCallback / encodeAverageOfPoints       -> k_leaf_tile
-//   C3b    SnakeGridMapping::doMapping                         -> k_leaf_tile (closed-form position)
-//   C4     PointCodingV2::encodePoint                          -> k_leaf_tile
+//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_scan + k_leaf_finalize
+//   C2/P6  serializeTreeCallback / encodeAverageOfPoints       -> k_leaf_finalize
+//   C3b    SnakeGridMapping::doMapping                         -> k_leaf_finalize (closed-form position)
+//   C4     PointCodingV2::encodePoint                          -> k_leaf_finalize
 //
 // All of it is integer / byte / fp64-scalar work bound by HBM bandwidth and launch latency:
 // no MFMA anywhere (there is no dense contraction in this path).
@@ -272,7 +272,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int passes_launched, int do_color, int hybrid, FixedBox box,
+                                                         int force_pairs, int passes_launched, int do_color, FixedBox box,
                                                          FrameState* __restrict__ st, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (pending == 0x7fffffff) {  // no finite point: the reference drops the frame (impl.hpp:206-212)
       if (threadIdx.x == 0) {
         st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
-        st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone; st->local_bits = 0; st->sorted_buf = 0;
-        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->top_bits = 0;
+        st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
+        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0;
         st->passes_launched = passes_launched;
       }
       return;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (depth > kMaxDepth && err == kErrNone) err = kErrDepth;
     // varying key bits from the global AABB under the final origin, +-1 voxel of slack
     int vb = 0;
-    unsigned kmin[3], kmax[3];
+    unsigned kmin[3];
     const unsigned klim = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u);
     for (int a = 0; a < 3; ++a) {
       float gmin = FLT_MAX, gmax = -FLT_MAX;
@@ -555,7 +555,6 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       kl = kl > 0 ? kl - 1 : 0;
       kh = kh < klim ? kh + 1 : klim;
       kmin[a] = kl;
-      kmax[a] = kh;
       const unsigned x = kl ^ kh;
       const int nb = x ? 32 - __clz((int)x) : 0;
       vb = max(vb, nb);
@@ -565,57 +564,21 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     // index payload (12 B/key/pass).  The stable sort makes both orders identical.
     const int packed = (3 * vb + ibits <= 64 && !force_pairs) ? 1 : 0;
     if (!packed) ibits = 0;
-    // Digit plan.  Plain LSD: as few passes as 9-bit digits allow over ALL code bits.
-    // Hybrid (the default): the global passes only order the HIGH code bits -- one pass for clouds a single workgroup
-    // can hold, two up to 16 M points, three beyond -- and k_leaf_sort orders the low `local_bits` inside a workgroup; a bucket of equal
-    // high bits that does not fit a workgroup makes the frame run again as plain LSD.  The top digit is up to 12 bits
-    // wide: the varying bits come from an XOR of the box corners, so a cloud that straddles the middle of its cube
-    // uses a fraction of the top cells (1100 voxels across a 4096 grid: 5 of 16 cells per axis).  The cells of the top
-    // `top_bits` that the points' box touches are numbered in Morton order (build_top_table, in the LDS of whoever needs it),
-    // at most 512 of them, and that number is the digit: two passes then resolve 21 bits instead of 18.
+    // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
     const int vbits = 3 * vb;
-    const unsigned vm = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    int gbits = vbits, local_bits = 0, top_bits = 0, top_digit_bits = 0, np;
-    unsigned tlo[3] = {0, 0, 0}, thi[3] = {0, 0, 0};
-    int tsh[3] = {0, 0, 0};
-    if (hybrid && vbits > 0) {
-      const unsigned nf = s_nfin;
-      const int gp = nf <= (unsigned)kLsCap ? 1 : (nf <= (16u << 20) ? 2 : 3);  // one pass: whatever the buckets, a tile holds them
-      unsigned cells = 1;
-      for (int T = min(kTopBitsMax, vbits); T >= 1; --T) {
-        cells = 1;
-        for (int a = 0; a < 3; ++a) {
-          tsh[a] = vb - (T + 2 - a) / 3;  // bits of axis a below the top T code bits (x takes the first bit of a triple)
-          tlo[a] = (kmin[a] & vm) >> tsh[a];
-          thi[a] = (kmax[a] & vm) >> tsh[a];
-          cells *= thi[a] - tlo[a] + 1u;
-        }
-        top_bits = T;
-        if (cells <= (unsigned)kMaxBins) break;  // always true at T <= 9
-      }
-      top_digit_bits = cells > 1u ? 32 - __clz((int)(cells - 1u)) : 1;
-      gbits = min(vbits, top_bits + kMaxDigitBits * (gp - 1));
-      local_bits = vbits - gbits;
-      np = 1 + (gbits - top_bits + kMaxDigitBits - 1) / kMaxDigitBits;
-    } else {
-      np = (gbits + kMaxDigitBits - 1) / kMaxDigitBits;
-      if (np < 1) np = 1;
-    }
+    int np = (vbits + kMaxDigitBits - 1) / kMaxDigitBits;
+    if (np < 1) np = 1;
     if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
     const int p = lane_id();
     if (p < kMaxPasses) {
-      // the passes below the top digit share their bits evenly; plain LSD: all passes do
-      const int nlow = top_bits ? np - 1 : np, lowbits = gbits - top_bits;
-      int bits = 0, sh = local_bits;
+      int bits = 0, sh = 0;
       for (int q = 0; q <= p; ++q) {
         int bq = 0;
-        if (q < nlow) {
-          bq = lowbits / nlow + (q < lowbits % nlow ? 1 : 0);
+        if (q < np) {
+          bq = vbits / np + (q < vbits % np ? 1 : 0);
           if (bq < 1) bq = 1;
-        } else if (q < np) {
-          bq = top_bits;  // the top digit's position in the code; its width as a digit is top_digit_bits
         }
-        if (q < p) sh += bq; else bits = (q < np && q >= nlow) ? top_digit_bits : bq;
+        if (q < p) sh += bq; else bits = bq;
       }
       st->pass_bits[p] = bits;
       st->pass_shift[p] = sh;
@@ -628,11 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->packed = packed;
       st->payload = packed ? (do_color ? 2 : 0) : 1;
       st->npasses = err != kErrNone ? 0 : np;
-      st->local_bits = local_bits;
-      st->top_bits = top_bits;
-      st->sorted_buf = (np + (local_bits > 0 ? 1 : 0)) & 1;  // every pass, global or local, flips the ping-pong buffers
       st->error = err;
-      for (int a = 0; a < 3; ++a) { st->top_lo[a] = tlo[a]; st->top_hi[a] = thi[a]; st->top_sh[a] = tsh[a]; }
     }
   }
   PCC_KTR(6, 6);
@@ -645,61 +604,17 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
 // ------------------------------------------------------------------------------------------
 constexpr uint64_t kInvalidKey = ~0ull;
 
-// The top digit of the hybrid sort plan (k_boxes_events, "Digit plan"): s_top[t] = Morton-ordered number of top cell t
-// among the cells the points' box touches, 0xffff for the others.  t = the top `top_bits` bits of a code: x, y, z
-// bits in turn from the most significant one.  Every workgroup that needs the table makes it in its own LDS while its
-// global loads are in flight (<= 4096 entries, a handful per thread, one barrier inside; the caller's next barrier
-// publishes it).
-template <int THREADS>
-__device__ __forceinline__ void build_top_table(uint16_t* s_top, const FrameState* __restrict__ st, uint32_t* s_tmp /*[THREADS / 64]*/) {
-  const int T = st->top_bits;
-  const uint32_t total = 1u << T, per = (total + THREADS - 1u) / THREADS;
-  const uint32_t t0 = min(threadIdx.x * per, total), t1 = min(t0 + per, total);
-  uint32_t lo[3], hi[3];
-  int nb[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { lo[a] = st->top_lo[a]; hi[a] = st->top_hi[a]; nb[a] = (T + 2 - a) / 3; }
-  uint32_t inside = 0, cnt = 0;
-  for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t tt = t << (kTopBitsMax - T);  // bit 11 - j = j-th bit from the top
-    bool in = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const uint32_t v = tt >> (2 - a);  // bits 0, 3, 6, 9 of v belong to axis a
-      const uint32_t c4 = (v & 1u) | ((v >> 2) & 2u) | ((v >> 4) & 4u) | ((v >> 6) & 8u);
-      const uint32_t c = c4 >> (4 - nb[a]);
-      in &= c >= lo[a] && c <= hi[a];
-    }
-    if (in) { inside |= 1u << (t - t0); ++cnt; }
-  }
-  const uint32_t incl = wave_incl_scan_u32(cnt);
-  if (lane_id() == 63) s_tmp[wave_id()] = incl;
-  __syncthreads();
-  uint32_t rank = incl - cnt;
-#pragma unroll
-  for (int w = 0; w < THREADS / 64; ++w)
-    if (w < wave_id()) rank += s_tmp[w];
-  for (uint32_t t = t0; t < t1; ++t) {
-    const bool in = (inside >> (t - t0)) & 1u;
-    s_top[t] = in ? (uint16_t)rank : (uint16_t)0xffffu;
-    rank += in ? 1u : 0u;
-  }
-}
-
 
 __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
                                                             uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
-  __shared__ __attribute__((aligned(4))) uint16_t s_top[1 << kTopBitsMax];  // hybrid sort: cell numbers of the top digit
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
   const int np = st->npasses;
-  const int top_bits = st->top_bits;
-  const uint32_t tmask = (1u << top_bits) - 1u;
-  __shared__ uint32_t s_tmp[kSortThreads / 64];
   for (int k = threadIdx.x; k < np * kMaxBins; k += kSortThreads) (&s_h[0][0])[k] = 0u;
+  __syncthreads();
   const int vb = st->vbits_axis, ibits = st->ibits;
   const bool packed_mode = st->packed != 0;
   const int payload = st->payload;
@@ -711,26 +626,12 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
   uint32_t pmask[kMaxPasses];
 #pragma unroll
   for (int p = 0; p < kMaxPasses; ++p) { pshift[p] = st->pass_shift[p]; pmask[p] = (1u << st->pass_bits[p]) - 1u; }
-  // the points are requested first; the table of the top digit is made (and the histogram cleared) while they travel
-  float px[kSortItems], py[kSortItems], pz[kSortItems];
-  uint32_t pc[kSortItems];
-#pragma unroll
-  for (int k = 0; k < kSortItems; ++k) {
-    const uint32_t i = base + k * kSortThreads + threadIdx.x;
-    px[k] = py[k] = pz[k] = __builtin_nanf("");
-    pc[k] = 0u;
-    if (i < n) {
-      load_xyz(pv, i, px[k], py[k], pz[k]);
-      if (payload == 2) pc[k] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
-    }
-  }
-  if (top_bits) build_top_table<kSortThreads>(s_top, st, s_tmp);
-  __syncthreads();
 #pragma unroll
   for (int k = 0; k < kSortItems; ++k) {
     const uint32_t i = base + k * kSortThreads + threadIdx.x;
     if (i >= n) break;
-    const float x = px[k], y = py[k], z = pz[k];
+    float x, y, z;
+    load_xyz(pv, i, x, y, z);
     uint64_t key = kInvalidKey;
     if (finite3(x, y, z) && (int)i >= ep0) {
       int e = ne - 1;
@@ -752,18 +653,11 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
       const uint64_t code = morton3(kk[0] & m, kk[1] & m, kk[2] & m);
 #pragma unroll
       for (int p = 0; p < kMaxPasses; ++p)
-        if (p < np) {
-          uint32_t d = (uint32_t)(code >> pshift[p]) & pmask[p];
-          if (top_bits && p == np - 1) {
-            d = s_top[(uint32_t)(code >> pshift[p]) & tmask];
-            if (d == 0xffffu) { st->error = kErrLocal; d = 0u; }  // a key outside the box the table was made for: plain LSD will do
-          }
-          atomicAdd(&s_h[p][d], 1u);
-        }
+        if (p < np) atomicAdd(&s_h[p][(uint32_t)(code >> pshift[p]) & pmask[p]], 1u);
       key = packed_mode ? ((code << ibits) | (uint64_t)i) : code;
     }
     if (payload == 1) idx[i] = i;
-    else if (payload == 2) idx[i] = pc[k];
+    else if (payload == 2) idx[i] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
     keys[i] = key;
   }
   __syncthreads();
@@ -829,7 +723,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
                                                             uint32_t n_tiles_max, unsigned long long* span) {
   const KSpan kspan(span);
   PCC_KT(0);
-  if (pass >= st->npasses || st->error != kErrNone) return;
+  if (pass >= st->npasses) return;
   constexpr int NW = THREADS / 64;
   static_assert(THREADS * ITEMS == kSortTile && THREADS >= kMaxBins, "a tile is 4096 keys (the histogram rows of k_make_keys); one thread per digit");
   // s_raw is used twice: while ranking, one 64-bit lane mask per (wave, digit); afterwards the tile's
@@ -845,7 +739,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   __shared__ uint16_t s_dstart[kMaxBins];   // position of a digit's first key in s_keys
   __shared__ uint32_t s_scan[NW];
   __shared__ uint32_t s_tile;
-  __shared__ __attribute__((aligned(4))) uint16_t s_top[1 << kTopBitsMax];  // hybrid sort, top pass: cell numbers (build_top_table)
 
   const uint32_t count = pass == 0 ? n : st->n_finite;  // pass 0 still holds the non-finite markers
   const uint32_t out_count = st->n_finite;
@@ -865,9 +758,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins; k += THREADS) s_match[k] = 0ull;
   for (int k = threadIdx.x; k < kMaxBins; k += THREADS) s_hist[k] = 0u;
-  const int top_bits = pass == st->npasses - 1 ? st->top_bits : 0;  // the top digit of the hybrid plan goes through the table
-  __shared__ uint32_t s_tt[NW];
-  if (top_bits) build_top_table<THREADS>(s_top, st, s_tt);  // while the ticket and the digit totals are on their way
   if (threadIdx.x == 0) s_tile = ticket;
   // global start of every digit = exclusive scan of the digit totals (its barriers also cover the LDS set up above)
   uint32_t gsum;
@@ -878,11 +768,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 
   const bool with_payload = st->payload != 0;
   const int shift = st->ibits + st->pass_shift[pass];
-  const uint32_t tmask = (1u << top_bits) - 1u;
-  auto digit_of = [&](uint64_t k) -> uint32_t {
-    const uint32_t v = (uint32_t)(k >> shift);
-    return top_bits ? ((uint32_t)s_top[v & tmask] & (uint32_t)(kMaxBins - 1)) : (v & mask);
-  };
   const uint64_t* in = (pass & 1) ? buf_b : buf_a;  // ping-pong: pass 0 reads a writes b
   uint64_t* out = (pass & 1) ? out_a : out_b;
   const uint32_t* pay_in = (pass & 1) ? idx_b : idx_a;
@@ -913,7 +798,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const bool valid = key[r] != kInvalidKey;
-    const uint32_t d = digit_of(key[r]);
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
     const uint64_t vm = __ballot(valid);
     if (vm) {
       const int first = __ffsll((long long)vm) - 1;
@@ -982,7 +867,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const bool valid = key[r] != kInvalidKey;
-    const uint32_t d = digit_of(key[r]);
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
     // the peers of the row's first key come from one ballot (see the histogram above), the others through LDS
     const uint64_t vm = __ballot(valid);
     const int first = vm ? __ffsll((long long)vm) - 1 : 0;
@@ -1078,7 +963,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     if (key[r] != kInvalidKey) {
-      const uint32_t d = digit_of(key[r]);
+      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
       const uint32_t lp = (uint32_t)s_dstart[d] + s_cnt[wave][d] + lrank[r];
       s_keys[lp] = key[r];
       if (with_payload) s_pay[lp] = pay[r];
@@ -1091,7 +976,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
     const uint32_t lp = (uint32_t)k * THREADS + threadIdx.x;
     if (lp < tile_valid) {
       const uint64_t kk = s_keys[lp];
-      const uint32_t d = digit_of(kk);
+      const uint32_t d = (uint32_t)(kk >> shift) & mask;
       const uint32_t pos = s_gofs[d] + lp;
       if (pos < out_count) {  // always true unless a look-back gave up (kErrSpin)
         out[pos] = kk;
@@ -1119,412 +1004,45 @@ __device__ __forceinline__ uint64_t head_t(uint64_t code, uint64_t prev, bool is
 __device__ __forceinline__ uint64_t scan_pack(uint64_t ht) { return ((ht >> 32) << 30) | (ht & 0x3fffffffull); }
 __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30) & 0xffffffffull) << 32) | (w & 0x3fffffffull); }
 
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint64_t u = __shfl_xor(v, o);
-    v = u > v ? u : v;
-  }
-  return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// Stage 3b + 4 in ONE launch, "k_leaf_sort": the last stage of the hybrid sort and the leaf scan.
-//
-// After the global passes the keys are ordered by their HIGH code bits only (bucket = key >> (ibits + local_bits)).
-// A workgroup takes the keys [s, e): its nominal 2048 positions, moved forward at both ends to the next bucket
-// boundary, so it owns whole buckets and nobody else touches them (a bucket that straddles several nominal tiles
-// belongs to the first one; the others come out empty).  It sorts them in LDS by (bucket rank inside the tile, low
-// bits) with a stable LSD radix sort -- 8-bit digits, the ranking scheme of k_sort_pass, no look-back, no global
-// scatter -- writes them to the other ping-pong buffer as one contiguous run, and, the sorted codes still being in
-// registers, does what k_leaf_scan did: head flags, t(j), the chained scan of (leaf id, DFS offset) over the tiles,
-// the leaf arrays, zeroing its piece of the DFS stream.  The code before the tile's first key -- the largest code of
-// the bucket before it -- is found by looking BEHIND s in the unsorted input (one row of 64 keys, usually), so tiles
-// do not wait for each other's sort.  With local_bits == 0 (plain LSD plan) the sorting part is skipped.
-// Per 2048 keys this costs about what one global pass costs, and replaces two of them plus k_leaf_scan.
-// A tile that would need more than 4096 slots sets kErrLocal: the host runs the frame again with the plain LSD plan.
-// ------------------------------------------------------------------------------------------
-constexpr int kLsWaves = kLsThreads / 64;
-constexpr int kLsDigitBits = 8, kLsBins = 1 << kLsDigitBits;
-constexpr int kLsCountingMax = 384;  // buckets up to this size are sorted by counting (quadratic in the bucket), larger ones by radix passes
-constexpr int kLsPrefetch = 5;  // rows of 512 keys requested before the ends of the tile are known (2048 + 512 of slack)
-
-__global__ __launch_bounds__(kLsThreads, 4) void k_leaf_sort(const uint64_t* buf_a, const uint64_t* buf_b, uint64_t* out_a, uint64_t* out_b,
-                                                             uint32_t* idx_a, uint32_t* idx_b,
-                                                             FrameState* st, uint64_t* leaf_status, uint64_t* leaf_max, uint32_t* ticket,
-                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
-                                                             uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
-                                                             uint8_t* __restrict__ occ, unsigned long long* span) {
+__global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                            FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
+                                                            uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
+                                                            uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
+                                                            uint8_t* __restrict__ occ, unsigned long long* span) {
   const KSpan kspan(span);
-  constexpr int NW = kLsWaves;
+  constexpr int NW = kSortThreads / 64;
   constexpr uint64_t kFlagAgg = 1ull << 62, kFlagIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
-  __shared__ __attribute__((aligned(16))) uint64_t s_keys[kLsCap];
-  __shared__ uint32_t s_pay[kLsCap];
-  __shared__ uint16_t s_bid[kLsCap];
-  __shared__ uint64_t s_match[NW][kLsBins];  // one lane mask per (wave, digit) while ranking
-  __shared__ uint16_t s_cnt[NW][kLsBins];    // per-wave running digit counts, then start ranks
-  __shared__ uint32_t s_scan[NW];
   __shared__ uint64_t s_w[NW];
-  __shared__ uint64_t s_lbm[2][NW], s_lbs[NW];  // look-back: not-ready / inclusive lane masks and partial sums per wave
-  __shared__ uint32_t s_tile, s_lo, s_hi;
-  PCC_KTR(4, 0);
+  __shared__ uint64_t s_prefix;
+  __shared__ uint32_t s_tile;
   const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
-  if (threadIdx.x == 0) {
-    s_tile = atomicAdd(ticket, 1u);  // tile id = ticket: see k_sort_pass
-    s_lo = 0xffffffffu;
-    s_hi = 0xffffffffu;
-  }
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tile id = ticket: see k_sort_pass
   __syncthreads();
   const uint32_t tile = s_tile;
-  if ((uint64_t)tile * kLsTile >= nfin) return;
-  const int np = st->npasses, lbits = st->local_bits, ibits = st->ibits, depth = st->depth;
-  const bool sorting = lbits > 0;
-  const uint64_t* in = (np & 1) ? buf_b : buf_a;
-  uint64_t* out = (np & 1) ? out_a : out_b;
-  const uint32_t* pay_in = (np & 1) ? idx_b : idx_a;
-  uint32_t* pay_out = (np & 1) ? idx_a : idx_b;
-  const bool with_payload = st->payload != 0;
-  const int bshift = ibits + lbits;  // bucket = key >> bshift (at least one code bit is left: the global passes sort >= 1)
+  if ((uint64_t)tile * kSortTile >= nfin) return;
+  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const int ibits = st->ibits, depth = st->depth;
   const int lane = lane_id(), wave = wave_id();
-  const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-  const uint32_t p0 = tile * (uint32_t)kLsTile, p1 = min(p0 + (uint32_t)kLsTile, nfin);
-  const uint32_t wend = min(p0 + (uint32_t)kLsCap, nfin);  // what a workgroup can hold, from p0 on
-
-  // ---- the keys from p0 on go to LDS as they lie (window index = position - p0); the tile's ends are the first
-  //      bucket boundaries at or behind p0 and p1 ----
-  const uint32_t pre_end = sorting ? min(p0 + (uint32_t)(kLsPrefetch * kLsThreads), wend) : p1;
-  {
-    uint64_t lk[kLsPrefetch];
-    uint32_t lq[kLsPrefetch];
+  // Every wave owns 512 consecutive sorted keys, read as 8 rows of 64 (coalesced); element (r, lane)
+  // is key wbase + 64 r + lane, so scan order is row-major inside the wave, then wave-major.
+  const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
+  uint64_t ht[kSortItems], code[kSortItems], inc[kSortItems];
 #pragma unroll
-    for (int k = 0; k < kLsPrefetch; ++k) {
-      const uint32_t pos = p0 + (uint32_t)k * kLsThreads + threadIdx.x;
-      lk[k] = pos < pre_end ? in[pos] : kInvalidKey;
-      lq[k] = (with_payload && pos < pre_end) ? pay_in[pos] : 0u;
-    }
-    const uint64_t key_before = (sorting && threadIdx.x == 0 && p0 > 0u) ? in[p0 - 1u] : 0ull;
-#pragma unroll
-    for (int k = 0; k < kLsPrefetch; ++k) {
-      const uint32_t w = (uint32_t)k * kLsThreads + threadIdx.x;
-      if (p0 + w < pre_end) { s_keys[w] = lk[k]; s_pay[w] = lq[k]; }
-    }
-    if (!sorting) {
-      if (threadIdx.x == 0) { s_lo = p0; s_hi = p1; }
-    } else {
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        if (p0 == 0u) atomicMin(&s_lo, 0u);
-        if (p1 == nfin) atomicMin(&s_hi, nfin);
-      }
-#pragma unroll
-      for (int k = 0; k < kLsPrefetch; ++k) {
-        const uint32_t w = (uint32_t)k * kLsThreads + threadIdx.x, pos = p0 + w;
-        if (pos < pre_end && pos > 0u) {
-          const uint64_t prev = w == 0u ? key_before : s_keys[w - 1u];
-          if ((lk[k] >> bshift) != (prev >> bshift)) {
-            atomicMin(&s_lo, pos);
-            if (pos >= p1) atomicMin(&s_hi, pos);
-          }
-        }
-      }
-    }
+  for (int r = 0; r < kSortItems; ++r) {
+    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+    code[r] = i < nfin ? (keys[i] >> ibits) : 0ull;
   }
-  __syncthreads();
-  // a long last bucket: more of the window, 512 keys at a time, until the boundary behind p1 shows up
-  for (uint32_t q = pre_end; sorting && s_hi == 0xffffffffu && q < wend; q += kLsThreads) {
-    const uint32_t pos = q + threadIdx.x, w = pos - p0;
-    uint64_t k = kInvalidKey;
-    if (pos < wend) {
-      k = in[pos];
-      s_keys[w] = k;
-      s_pay[w] = with_payload ? pay_in[pos] : 0u;
-    }
-    __syncthreads();
-    if (pos < wend && (k >> bshift) != (s_keys[w - 1u] >> bshift)) {  // w >= 1 here
-      atomicMin(&s_lo, pos);
-      if (pos >= p1) atomicMin(&s_hi, pos);
-    }
-    __syncthreads();
-  }
-  uint32_t s = s_lo, e = s_hi;
-  if (e == 0xffffffffu && wend == nfin) {  // the cloud ends inside the window: so does the last bucket
-    e = nfin;
-    if (s == 0xffffffffu) s = nfin;
-  }
-  if (e == 0xffffffffu) {  // the bucket that straddles p1 does not end within what a workgroup can hold
-    if (threadIdx.x == 0) {
-      st->error = kErrLocal;
-      publish_u64(leaf_status + tile, kFlagIncl);  // nobody waits for this tile; everything downstream sees the error
-    }
-    return;
-  }
-  if (s > e) s = e;
-  const uint32_t c = e - s;  // keys of this tile: window [s - p0, e - p0)
-  uint64_t* const sk = s_keys + (s - p0);
-  uint32_t* const sp = s_pay + (s - p0);
-  uint16_t* const sb = s_bid + (s - p0);
-  PCC_KTR(4, 1);
-
-  // The code that precedes this tile's first one = the largest code of the tile before (tiles own whole buckets, and
-  // buckets are in order): every tile publishes its largest code as soon as its keys are in registers, long before it
-  // has sorted them (self-describing word, bit 63 = there).  Requested now, looked at when the leaf scan needs it.
-  constexpr uint64_t kThere = 1ull << 63;
-  uint64_t prev_word = 0ull;
-  if (threadIdx.x == 0 && s > 0u) prev_word = sorting ? poll_u64(leaf_max + tile - 1u) : ((in[s - 1u] >> ibits) | kThere);
-  PCC_KTR(4, 2);
-
-  // ---- registers in (wave, row, lane) order: every wave owns `span` consecutive keys, read as rows of 64 ----
-  const uint32_t span_w = max(64u, (((c + NW - 1u) / NW) + 63u) & ~63u);
-  const int rows = (int)(span_w / 64u);  // <= 8
-  const uint32_t jbase = (uint32_t)wave * span_w + (uint32_t)lane;
-  uint64_t key[kLsItems];
-  uint32_t pay[kLsItems], bid[kLsItems];
-  uint64_t kmax = 0ull;
-#pragma unroll
-  for (int r = 0; r < kLsItems; ++r) {
-    const uint32_t j = jbase + (uint32_t)r * 64u;
-    const bool valid = r < rows && j < c;
-    key[r] = valid ? sk[j] : kInvalidKey;
-    pay[r] = valid ? sp[j] : 0u;
-    bid[r] = 0u;
-    if (valid && key[r] > kmax) kmax = key[r];
-  }
-  if (sorting) {
-    kmax = wave_max_u64(kmax);
-    if (lane == 0) s_w[wave] = kmax;
-    // bucket rank inside the tile = number of bucket boundaries up to the key
-    uint32_t running = 0, edges = 0;  // edges: bit r = the key of row r opens a bucket
-#pragma unroll
-    for (int r = 0; r < kLsItems; ++r) {
-      if (r < rows) {
-        const uint32_t j = jbase + (uint32_t)r * 64u;
-        const bool valid = j < c;
-        uint64_t prev = __shfl_up(key[r], 1);
-        if (lane == 0) prev = (valid && j > 0u) ? sk[j - 1u] : key[r];
-        const bool edge = valid && j > 0u && (key[r] >> bshift) != (prev >> bshift);
-        edges |= (edge || (valid && j == 0u)) ? (1u << r) : 0u;
-        const uint64_t m = __ballot(edge);
-        bid[r] = running + (uint32_t)__popcll(m & (lt_mask | (1ull << lane)));
-        running += (uint32_t)__popcll(m);
-      }
-    }
-    if (lane == 0) s_scan[wave] = running;
-    __syncthreads();
-    if (threadIdx.x == 0) {  // the tile's largest code, for the tile behind it
-      uint64_t word;
-      if (c > 0u) {
-        uint64_t mx = 0ull;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mx = max(mx, s_w[w]);
-        word = (mx >> ibits) | kThere;
-      } else {  // an empty tile (its bucket belongs to a tile before it) hands on what precedes it
-        uint32_t spins = 0;
-        while (!(prev_word & kThere)) {
-          __builtin_amdgcn_s_sleep(2);
-          prev_word = poll_u64(leaf_max + tile - 1u);
-          if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
-        }
-        word = prev_word | kThere;
-      }
-      publish_u64(leaf_max + tile, word);
-    }
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t x = s_scan[w];
-      if (w < wave) before += x;
-      all += x;
-    }
-#pragma unroll
-    for (int r = 0; r < kLsItems; ++r) bid[r] += before;
-    // where every bucket starts (window-relative position of its first key); all + 1 buckets, the end of the last one = c
-    uint16_t* const bstart = s_bid;  // (the radix path below uses the array for something else, later)
-#pragma unroll
-    for (int r = 0; r < kLsItems; ++r)
-      if (edges & (1u << r)) bstart[bid[r]] = (uint16_t)(jbase + (uint32_t)r * 64u);
-    if (threadIdx.x == 0) bstart[all + 1u] = (uint16_t)c;
-    __syncthreads();
-    uint32_t b0[kLsItems], b1[kLsItems];
-    bool big = false;
-#pragma unroll
-    for (int r = 0; r < kLsItems; ++r) {
-      b0[r] = b1[r] = 0u;
-      if (r < rows && jbase + (uint32_t)r * 64u < c) {
-        b0[r] = bstart[bid[r]];
-        b1[r] = bstart[bid[r] + 1u];
-        big |= b1[r] - b0[r] > (uint32_t)kLsCountingMax;
-      }
-    }
-    const bool by_counting = __syncthreads_or(big ? 1 : 0) == 0;
-    PCC_KTR(4, 6);
-    if (by_counting) {
-      // Small buckets (the usual case: some hundred points): the rank of a key inside its bucket = the number of the
-      // bucket's keys that come before it, counted directly.  The lanes of a wave hold consecutive keys, mostly of one
-      // bucket, so the bucket's keys are read as LDS broadcasts; no barrier, no counters, no digit passes.
-      uint32_t dst[kLsItems];
-#pragma unroll
-      for (int r = 0; r < kLsItems; ++r) {
-        dst[r] = 0u;
-        if (r < rows) {
-          const uint32_t j = jbase + (uint32_t)r * 64u;
-          const uint64_t mine = key[r];  // invalid: b0 == b1, the loop does nothing
-          uint32_t cnt = 0;
-          for (uint32_t i = b0[r]; i < b1[r]; ++i) {
-            const uint64_t other = sk[i];
-            cnt += (other < mine || (other == mine && i < j)) ? 1u : 0u;
-          }
-          dst[r] = b0[r] + cnt;
-        }
-      }
-      __syncthreads();  // everybody has read the unsorted keys
-#pragma unroll
-      for (int r = 0; r < kLsItems; ++r)
-        if (r < rows && jbase + (uint32_t)r * 64u < c) { sk[dst[r]] = key[r]; sp[dst[r]] = pay[r]; }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < kLsItems; ++r) {
-        const uint32_t j = jbase + (uint32_t)r * 64u;
-        if (r < rows && j < c) { key[r] = sk[j]; pay[r] = sp[j]; }
-      }
-    }
-    // Large buckets: stable LSD radix sort on the composite key (bucket rank << local_bits) | low code bits, taken apart
-    // into digits of <= 8 bits
-    const int bl = all ? 32 - __clz((int)all) : 0;  // ranks 0 .. all
-    const int cb = lbits + bl;
-    const int npass = by_counting ? 0 : (cb + kLsDigitBits - 1) / kLsDigitBits;
-    const uint64_t lmask = (1ull << lbits) - 1ull;
-    if (!by_counting)
-      for (int k = lane; k < kLsBins; k += 64) s_match[wave][k] = 0ull;
-    int sh = 0;
-    for (int q = 0; q < npass; ++q) {
-      const int bits = cb / npass + (q < cb % npass ? 1 : 0);
-      const uint32_t nbins = 1u << bits, mask = nbins - 1u;
-      for (int k = lane; k < kLsBins / 2; k += 64) reinterpret_cast<uint32_t*>(&s_cnt[wave][0])[k] = 0u;  // own row: no barrier
-      uint64_t* wmatch = &s_match[wave][0];
-      if (q == 0) PCC_KTR(3, 0);
-      uint32_t dg[kLsItems];
-      uint16_t lrank[kLsItems];
-#pragma unroll
-      for (int r = 0; r < kLsItems; ++r) {
-        dg[r] = 0u; lrank[r] = 0;
-        if (r < rows) {
-          const bool valid = jbase + (uint32_t)r * 64u < c;
-          const uint64_t comp = ((uint64_t)bid[r] << lbits) | ((key[r] >> ibits) & lmask);
-          const uint32_t d = (uint32_t)(comp >> sh) & mask;
-          dg[r] = d;
-          // peers = lanes of this wave with the same digit (k_sort_pass: ballot for the row's first digit, LDS masks for the rest)
-          const uint64_t vm = __ballot(valid);
-          const int first = vm ? __ffsll((long long)vm) - 1 : 0;
-          const uint32_t d0 = __shfl(d, first);
-          const uint64_t same = __ballot(valid && d == d0);
-          const bool via_lds = valid && d != d0;
-          if (via_lds) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
-          const uint64_t peers = via_lds ? wmatch[d] : (valid ? same : 0ull);
-          const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-          const uint32_t prior = s_cnt[wave][d];
-          if (valid && rank == 0) {
-            if (via_lds) wmatch[d] = 0ull;
-            s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
-          }
-          lrank[r] = (uint16_t)(prior + rank);
-        }
-      }
-      if (q == 0) PCC_KTR(3, 1);
-      __syncthreads();
-      if (q == 0) PCC_KTR(3, 2);
-      // start rank of every (digit, wave): exclusive scan over the digits, the waves of a digit in order
-      uint32_t tot = 0;
-      if (threadIdx.x < nbins) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          const uint32_t x = s_cnt[w][threadIdx.x];
-          s_cnt[w][threadIdx.x] = (uint16_t)tot;
-          tot += x;
-        }
-      }
-      const uint32_t incl = wave_incl_scan_u32(tot);
-      if (lane == 63) s_scan[wave] = incl;
-      __syncthreads();
-      uint32_t off = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-        if (w < wave) off += s_scan[w];
-      const uint32_t dstart = off + incl - tot;
-      if (threadIdx.x < nbins) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s_cnt[w][threadIdx.x] = (uint16_t)(s_cnt[w][threadIdx.x] + dstart);
-      }
-      __syncthreads();
-      if (q == 0) PCC_KTR(3, 3);
-#pragma unroll
-      for (int r = 0; r < kLsItems; ++r) {
-        if (r < rows && jbase + (uint32_t)r * 64u < c) {
-          const uint32_t dst = (uint32_t)s_cnt[wave][dg[r]] + lrank[r];
-          sk[dst] = key[r];
-          sp[dst] = pay[r];
-          sb[dst] = (uint16_t)bid[r];
-        }
-      }
-      __syncthreads();
-      if (q == 0) PCC_KTR(3, 4);
-#pragma unroll
-      for (int r = 0; r < kLsItems; ++r) {
-        const uint32_t j = jbase + (uint32_t)r * 64u;
-        if (r < rows && j < c) {
-          key[r] = sk[j];
-          pay[r] = sp[j];
-          bid[r] = sb[j];
-        }
-      }
-      if (q == 0) PCC_KTR(3, 5);
-      sh += bits;
-    }
-    PCC_KTR(4, 7);
-    // the sorted run, into the other ping-pong buffer
-#pragma unroll
-    for (int r = 0; r < kLsItems; ++r) {
-      const uint32_t j = jbase + (uint32_t)r * 64u;
-      if (r < rows && j < c) {
-        out[s + j] = key[r];
-        if (with_payload) pay_out[s + j] = pay[r];
-      }
-    }
-  }
-  PCC_KTR(4, 3);
-
-  // ---- leaves: scan order is row-major inside the wave, then wave-major (the order of the sorted keys) ----
-  uint64_t ht[kLsItems], inc[kLsItems], code[kLsItems];
-#pragma unroll
-  for (int r = 0; r < kLsItems; ++r) code[r] = (r < rows && jbase + (uint32_t)r * 64u < c) ? (key[r] >> ibits) : 0ull;
-  uint64_t carry = 0ull;  // code before the wave's first key
-  {
-    const uint32_t j0 = (uint32_t)wave * span_w;
-    if (lane == 0 && j0 < c) {
-      if (j0 != 0u) {
-        carry = sk[j0 - 1u] >> ibits;
-      } else if (s > 0u) {  // wave 0: the word requested at the top, polled again if the tile before was not that far yet
-        uint32_t spins = 0;
-        while (!(prev_word & kThere)) {
-          __builtin_amdgcn_s_sleep(2);
-          prev_word = poll_u64(leaf_max + tile - 1u);
-          if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
-        }
-        carry = prev_word & ~kThere;
-      }
-    }
-  }
+  uint64_t carry = (lane == 0 && wbase > 0 && wbase < nfin) ? (keys[wbase - 1] >> ibits) : 0ull;  // key before the segment
   uint64_t wave_tot = 0;
 #pragma unroll
-  for (int r = 0; r < kLsItems; ++r) {
-    ht[r] = 0ull; inc[r] = wave_tot;
-    if (r < rows) {
-      const uint32_t j = jbase + (uint32_t)r * 64u;
-      uint64_t prev = __shfl_up(code[r], 1);
-      if (lane == 0) prev = carry;
-      ht[r] = j < c ? head_t(code[r], prev, s + j == 0u, depth) : 0ull;
-      carry = __shfl(code[r], 63);
-      inc[r] = wave_incl_scan_u64(ht[r]) + wave_tot;
-      wave_tot = __shfl(inc[r], 63);
-    }
+  for (int r = 0; r < kSortItems; ++r) {
+    const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+    uint64_t prev = __shfl_up(code[r], 1);
+    if (lane == 0) prev = carry;
+    ht[r] = i < nfin ? head_t(code[r], prev, i == 0, depth) : 0ull;
+    carry = __shfl(code[r], 63);  // lane 0 of the next row compares against the end of this one
+    inc[r] = wave_incl_scan_u64(ht[r]) + wave_tot;
+    wave_tot = __shfl(inc[r], 63);
   }
   if (lane == 63) s_w[wave] = wave_tot;
   __syncthreads();
@@ -1535,52 +1053,43 @@ __global__ __launch_bounds__(kLsThreads, 4) void k_leaf_sort(const uint64_t* buf
     if (w < wave) woff += x;
     tot += x;
   }
-  // Look-back with every thread: 512 earlier tiles per step (the tiles of a frame finish their sorting at about the
-  // same time, so inclusive prefixes are rare when a tile gets here; walking back 64 tiles per round trip took longer
-  // than the sort).  Every thread ends up with the same sum.
-  const uint64_t mine = scan_pack(tot);
-  uint64_t before = 0;
-  if (threadIdx.x == 0) publish_u64(leaf_status + tile, (tile == 0 ? kFlagIncl : kFlagAgg) | mine);
-  if (tile > 0) {
-    int j = (int)tile - 1;
-    uint32_t spins = 0;
-    for (;;) {
-      const int jj = j - (int)threadIdx.x;
-      const uint64_t v = jj >= 0 ? poll_u64(leaf_status + jj) : kFlagIncl;  // before tile 0: an inclusive zero
-      const uint32_t f = (uint32_t)(v >> 62);
-      const uint64_t nr = __ballot(f == 0), in2 = __ballot(f == 2);
-      if (lane == 0) { s_lbm[0][wave] = nr; s_lbm[1][wave] = in2; }
-      __syncthreads();
-      int first_nr = kLsThreads, first_in = kLsThreads;  // nearest tile first
-#pragma unroll
-      for (int w = NW - 1; w >= 0; --w) {
-        const uint64_t m0 = s_lbm[0][w], m1 = s_lbm[1][w];
-        if (m0) first_nr = 64 * w + __ffsll((long long)m0) - 1;
-        if (m1) first_in = 64 * w + __ffsll((long long)m1) - 1;
+  if (wave == 0) {  // one wave looks back, 64 earlier tiles per step
+    const uint64_t mine = scan_pack(tot);
+    uint64_t before = 0;
+    if (tile == 0) {
+      if (lane == 0) publish_u64(leaf_status, kFlagIncl | mine);
+    } else {
+      if (lane == 0) publish_u64(leaf_status + tile, kFlagAgg | mine);
+      int j = (int)tile - 1;
+      uint32_t spins = 0;
+      while (j >= 0) {
+        const int jj = j - lane;
+        const uint64_t v = jj >= 0 ? poll_u64(leaf_status + jj) : kFlagIncl;
+        const uint32_t f = (uint32_t)(v >> 62);
+        const uint64_t not_ready = __ballot(f == 0), incl = __ballot(f == 2);
+        const int first_nr = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+        const int first_in = incl ? __ffsll((long long)incl) - 1 : 64;
+        const int take = first_in < first_nr ? first_in + 1 : first_nr;  // lanes [0, take) are usable
+        before += wave_sum_u64(lane < take ? (v & kVal) : 0ull);
+        if (first_in < first_nr) break;
+        j -= take;
+        if (take == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit) { if (lane == 0) st->error = kErrSpin; break; }
+        }
       }
-      const int take = first_in < first_nr ? first_in + 1 : first_nr;  // threads [0, take) hold usable words
-      const uint64_t part = wave_sum_u64((int)threadIdx.x < take ? (v & kVal) : 0ull);
-      if (lane == 0) s_lbs[wave] = part;
-      __syncthreads();
-#pragma unroll
-      for (int w = 0; w < NW; ++w) before += s_lbs[w];
-      if (first_in < first_nr) break;
-      j -= take;
-      if (take == 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit) { if (threadIdx.x == 0) st->error = kErrSpin; break; }
-      }
+      if (lane == 0) publish_u64(leaf_status + tile, kFlagIncl | ((before + mine) & kVal));
     }
-    if (threadIdx.x == 0) publish_u64(leaf_status + tile, kFlagIncl | ((before + mine) & kVal));
+    if (lane == 0) s_prefix = scan_unpack(before);
   }
-  PCC_KTR(4, 4);
-  const uint64_t pre = scan_unpack(before);
+  __syncthreads();
+  const uint64_t pre = s_prefix;
 #pragma unroll
-  for (int r = 0; r < kLsItems; ++r) {
+  for (int r = 0; r < kSortItems; ++r) {
     if (ht[r] & 1ull) {
       const uint64_t ex = pre + woff + inc[r] - ht[r];
       const uint32_t id = (uint32_t)(ex & 0xffffffffu);
-      leaf_start[id] = s + jbase + (uint32_t)r * 64u;
+      leaf_start[id] = wbase + (uint32_t)r * 64u + (uint32_t)lane;
       leaf_code[id] = code[r];
       leaf_base[id] = (uint32_t)(ex >> 32);
       leaf_t[id] = (uint8_t)(ht[r] >> 32);
@@ -1589,19 +1098,18 @@ __global__ __launch_bounds__(kLsThreads, 4) void k_leaf_sort(const uint64_t* buf
   // zero the piece of the DFS stream this tile's leaves open: bytes [b0, b1)
   const uint32_t b0 = (uint32_t)(pre >> 32), b1 = b0 + (uint32_t)(tot >> 32);
   const uint32_t a0 = min((b0 + 15u) & ~15u, b1), a1 = max(b1 & ~15u, a0);
-  for (uint32_t k = b0 + threadIdx.x; k < a0; k += kLsThreads) occ[k] = 0;
-  for (uint32_t k = a0 + threadIdx.x * 16u; k < a1; k += kLsThreads * 16u) *reinterpret_cast<uint4*>(occ + k) = make_uint4(0, 0, 0, 0);
-  for (uint32_t k = a1 + threadIdx.x; k < b1; k += kLsThreads) occ[k] = 0;
-  if ((uint64_t)(tile + 1) * kLsTile >= nfin && threadIdx.x == 0) {  // the last tile closes the frame
+  for (uint32_t k = b0 + threadIdx.x; k < a0; k += kSortThreads) occ[k] = 0;
+  for (uint32_t k = a0 + threadIdx.x * 16u; k < a1; k += kSortThreads * 16u) *reinterpret_cast<uint4*>(occ + k) = make_uint4(0, 0, 0, 0);
+  for (uint32_t k = a1 + threadIdx.x; k < b1; k += kSortThreads) occ[k] = 0;
+  if ((uint64_t)(tile + 1) * kSortTile >= nfin && threadIdx.x == 0) {  // the last tile closes the frame
     const uint64_t all = pre + tot;
     const uint32_t L = (uint32_t)(all & 0xffffffffu);
     st->n_leaves = L;
     st->n_branches = (uint32_t)(all >> 32);
     leaf_start[L] = nfin;
-    // keep the dword that holds the last stream byte clean beyond B (k_leaf_tile ORs whole dwords)
+    // keep the dword that holds the last stream byte clean beyond B (k_leaf_finalize ORs whole dwords)
     for (uint32_t k = b1; k < ((b1 + 3u) & ~3u); ++k) occ[k] = 0;
   }
-  PCC_KTR(4, 5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1755,12 +1263,12 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   int* s_ws = reinterpret_cast<int*>(s_scratch);
   static_assert(sizeof(uint32_t) * (kFinTile + kOccWindow) >= sizeof(int) * 96 * 8 * 9, "FDCT workspace must fit");
 
-  const uint64_t* keys = st->sorted_buf ? buf_b : buf_a;
+  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, D = st->depth;
   const int lane = lane_id(), wave = wave_id();
   IndexOf index_of;
   index_of.keys = keys;
-  const uint32_t* pay_sorted = st->sorted_buf ? idx_b : idx_a;
+  const uint32_t* pay_sorted = (st->npasses & 1) ? idx_b : idx_a;
   index_of.idx = st->payload == 1 ? pay_sorted : nullptr;
   index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
   const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
@@ -2419,9 +1927,8 @@ extern "C" int pcc_debug_read_ktime(unsigned long long* out, size_t count) {
 
 size_t sync_area_bytes(uint32_t n, int passes) {
   const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
-  const size_t ls_tiles = ((size_t)n + kLsTile - 1) / kLsTile;
   size_t b = 64;                                   // tickets
-  b += 2 * (((ls_tiles * sizeof(uint64_t) + 15) / 16) * 16);  // k_leaf_sort, per 2048 keys: leaf scan status word, largest-code word
+  b += ((tiles * sizeof(uint64_t) + 15) / 16) * 16;  // leaf scan status
   const size_t groups = (tiles + kLookBackGroup - 1) / kLookBackGroup;
   b += (size_t)passes * (tiles + groups) * kMaxBins * sizeof(uint32_t);  // sort status: per tile, per group of tiles
   return b;
@@ -2481,7 +1988,7 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_make_keys", (const void*)k_make_keys, kSortThreads);
   one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems>, kSortThreads);
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
-  one("k_leaf_sort", (const void*)k_leaf_sort, kLsThreads);
+  one("k_leaf_scan", (const void*)k_leaf_scan, kSortThreads);
   one("k_leaf_tile", (const void*)k_leaf_tile, kFinThreads);
   one("k_occ_histogram", (const void*)k_occ_histogram, 256);
   if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
@@ -2504,14 +2011,11 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   uint8_t* sync = a.sync_area;
   uint32_t* tickets = reinterpret_cast<uint32_t*>(sync);
   uint64_t* leaf_status = reinterpret_cast<uint64_t*>(sync + 64);
-  const uint32_t ls_tiles = (n + kLsTile - 1) / kLsTile;         // k_leaf_sort tiles (2048 keys, nominally)
-  const size_t ls_bytes = (((size_t)ls_tiles * sizeof(uint64_t) + 15) / 16) * 16;
-  uint64_t* leaf_max = reinterpret_cast<uint64_t*>(sync + 64 + ls_bytes);
-  uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + 64 + 2 * ls_bytes);
+  uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + 64 + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, passes, (int)a.lp.do_color, a.hybrid, a.box, a.state, span("k_boxes_events"));
+                     a.res, a.force_pairs, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
   PCC_STAMP("k_make_keys");
@@ -2534,9 +2038,9 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                          n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass"));
     PCC_STAMP("k_sort_pass");
   }
-  hipLaunchKernelGGL(k_leaf_sort, dim3(ls_tiles), dim3(kLsThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state, leaf_status, leaf_max,
-                     tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_sort"));
-  PCC_STAMP("k_leaf_sort");
+  hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
+                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
+  PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,

@@ -208,10 +208,6 @@ int pcc_get_kernel_spans(pcc_ctx *ctx, pcc_kernel_times *out);
  * consecutive launches is what a launch costs its stream (its span plus the dispatch and the end-of-kernel write-back
  * that the span leaves out) -- the figure a kernel trace calls the kernel's duration. */
 int pcc_get_kernel_span_starts(pcc_ctx *ctx, pcc_kernel_times *out);
-/* how the last finished frame of this context was sorted: {plan enqueued (1 hybrid, 0 plain LSD), global radix passes, code
- * bits ordered inside the workgroups of k_leaf_sort, frames of this context that had to run again as plain LSD so far,
- * frames left until the hybrid plan is tried again, device error code of the last frame} */
-int pcc_get_sort_plan(pcc_ctx *ctx, int32_t out[6]);
 /* wall time of the last pcc_entropy_encode on this context, microseconds: occupancy range coder, JPEG
  * stage, colour range coder, whole stage */
 int pcc_get_host_times(pcc_ctx *ctx, double out_us[4]);

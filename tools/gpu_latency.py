@@ -39,7 +39,6 @@ for prof in (0, 1, 2):   # 0 unprofiled, 1 HIP events between the launches + spa
                     e = spans.setdefault(name, [0.0, 0]); e[0] += v; e[1] += 1
     print("%s N=%d L=%d B=%d D=%d  profiling=%d: gpu %.1f us (min %.1f)  launch+finish wall %.1f us" %
           (wl, n, hot.n_leaves, hot.n_branches, hot.depth, prof, 1e3 * np.mean(ms), 1e3 * np.min(ms), 1e3 * np.mean(wall)))
-    print("   sort plan:", ctx.sort_plan())
     if prof:
         print("   (%s)" % ("first column: HIP events between the launches" if prof == 1 else "first column: start of a launch to start of the next one, GPU clock"))
         for name, (tot, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
