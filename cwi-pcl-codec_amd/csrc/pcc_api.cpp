@@ -686,7 +686,16 @@ int pcc_reserve(pcc_ctx* ctx, size_t max_points, size_t bitstream_bytes) {
     const int rc = reserve(ctx, max_points);
     if (rc != PCC_OK) return rc;
     // landing buffers of the usual products (occupancy bytes: about one per point for surfaces; more is fetched on demand)
+    const size_t had = ctx->h_occ.cap;
     PCC_HIP(ctx->h_occ.ensure(tiles_region(max_points) + std::max(max_points + max_points / 4, 2 * bitstream_bytes) + 16));
+    if (ctx->h_occ.cap != had) {
+      // The FIRST device-to-host copy into a fresh page-locked buffer costs the calling thread 2-7 ms (measured with
+      // PCC_FINISH_TRACE: the runtime maps the buffer for the copy engine then); it belongs here, not into the first
+      // frame that lands in the buffer.
+      const size_t bytes = std::min(ctx->h_occ.cap, ctx->d_occ.cap);
+      PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      PCC_HIP(hipStreamSynchronize(ctx->stream));
+    }
   }
   if (bitstream_bytes) {
     const size_t want = 2 * bitstream_bytes + 4096;
@@ -709,7 +718,19 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   memset(out, 0, sizeof(*out));
   if (ctx->n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
   PCC_HIP(hipSetDevice(ctx->device));
+  // developer aid (PCC_FINISH_TRACE=1): calls that take longer than 2 ms say where the time went (wall / CPU of this thread)
+  static const bool trace = [] { const char* e = getenv("PCC_FINISH_TRACE"); return e && e[0] == '1'; }();
+  auto now_pair = [](double t[2]) {
+    timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b);
+    t[0] = a.tv_sec * 1e3 + a.tv_nsec * 1e-6;
+    t[1] = b.tv_sec * 1e3 + b.tv_nsec * 1e-6;
+  };
+  double tr0[2] = {0, 0}, tr1[2] = {0, 0}, tr2[2] = {0, 0}, tr3[2] = {0, 0};
+  if (trace) now_pair(tr0);
   const int src = wait_frame_state(ctx);
+  if (trace) now_pair(tr1);
   if (ctx->locked_host) {  // the upload was over before the first kernel started
     unlock_host_range(ctx->locked_host);
     ctx->locked_host = nullptr;
@@ -783,7 +804,14 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
     PCC_HIP(ctx->h_lines.ensure(words + 16));
     PCC_HIP(hipMemcpyAsync(ctx->h_lines.p, ctx->d_lines.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   }
+  if (trace) now_pair(tr2);
   { const int wrc = wait_stream(ctx, 1); if (wrc != PCC_OK) return wrc; }
+  if (trace) {
+    now_pair(tr3);
+    if (tr3[0] - tr0[0] > 2.0)
+      fprintf(stderr, "[pcc_hotpath_finish %p] wait for the kernels %.3f ms (cpu %.3f), copies enqueued %.3f (cpu %.3f), wait for the copies %.3f (cpu %.3f); gpu %.3f ms\n",
+              (void*)ctx, tr1[0] - tr0[0], tr1[1] - tr0[1], tr2[0] - tr1[0], tr2[1] - tr1[1], tr3[0] - tr2[0], tr3[1] - tr2[1], (double)ms);
+  }
   bool lines_ok = lines_on_gpu;
   if (lines_on_gpu) {
     for (size_t i = 0; i < n_lines; ++i)

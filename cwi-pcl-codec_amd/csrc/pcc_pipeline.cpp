@@ -70,7 +70,20 @@ struct pcc_pipeline {
   int gpu_batch = 256;
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
-  int batch_now = PCC_MAX_FRAMES_AT_ONCE;  // ... for the job at hand: short jobs spread their frames over the threads instead
+  size_t taken = 0;  // frames of the job at hand that entropy threads have taken so far
+  // How many frames the next entropy thread should code in one loop.  Four coders in one loop use the least CPU per frame
+  // (1.3 ms against 3.3 ms for one alone) but the frames come out later: right while the frames outnumber the threads,
+  // wrong for the last frames of a call and for short calls.  So: what is left, spread over HALF the entropy threads (the
+  // CPUs of a job are usually hardware-thread pairs, and two coders on one core run at half speed each; measured on the
+  // GPU box with tools/short_calls.py: 20 frames on 16 threads 7.5 ms with a divisor of 16, 6.0 ms with 8, 6.6 ms with
+  // 5; PCC_PIPELINE_SPREAD = 16 / divisor) -- a call of 20 frames on 16 threads runs as 3 3 2 2 2 2 2 1 1 1 1, the early
+  // frames in the larger batches; a long call runs in fours and tapers off at its end.  (Callers hold `mu`.)
+  size_t batch_wanted() const {
+    const size_t left = job.n_frames > taken ? job.n_frames - taken : 0;
+    static const double spread = [] { const char* e = getenv("PCC_PIPELINE_SPREAD"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 2.0; }();
+    const size_t per = (size_t)(((double)left * spread + (double)n_entropy - 1.0) / (double)std::max(n_entropy, 1));
+    return std::min<size_t>(std::max<size_t>(per, 1), (size_t)batch);
+  }
   std::vector<pcc_ctx*> ctxs;
   std::vector<std::thread> threads;
   std::mutex mu;  // guards everything below up to `stat_mu`
@@ -194,7 +207,7 @@ struct pcc_pipeline {
             free_ctx.push_back(r.ctx);
             cv_free.notify_one();
           }
-          wake_one = ready.size() >= (size_t)batch_now;  // a full batch is waiting: one entropy thread is enough
+          wake_one = ready.size() >= batch_wanted();  // a full batch is waiting: one entropy thread is enough
           wake_all = gpu_done >= job.n_frames;
         }
         if (wake_all) cv_ready.notify_all();
@@ -294,9 +307,12 @@ struct pcc_pipeline {
           std::unique_lock<std::mutex> lk(mu);
           // Four frames in one coder loop cost 1.5 ms of CPU per frame, one frame alone 3.3 ms (tools/rc_speed.py), and
           // the CPU is what limits the pipeline: wait for a full batch unless the GPU stage has nothing more to give.
-          cv_ready.wait(lk, [&] { return ready.size() >= (size_t)batch_now || gpu_done >= job.n_frames; });
-          while (nr < kAtOnce && nr < batch_now && !ready.empty()) { r[nr++] = ready.front(); ready.pop_front(); }
+          cv_ready.wait(lk, [&] { return ready.size() >= batch_wanted() || gpu_done >= job.n_frames; });
+          const size_t want = batch_wanted();
+          while (nr < kAtOnce && (size_t)nr < want && !ready.empty()) { r[nr++] = ready.front(); ready.pop_front(); }
           if (nr == 0) break;  // every frame went through the GPU stage and the queue is empty
+          taken += (size_t)nr;
+          if (!ready.empty() && ready.size() >= batch_wanted()) cv_ready.notify_one();  // enough left for another thread
         }
         pcc_bitstream bs[kAtOnce];
         memset(bs, 0, sizeof(bs));
@@ -486,22 +502,7 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->streams.assign(n_frames, std::vector<uint8_t>());
     if (mode == 0 && p->seen_max_len) p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63));
     p->arena_used = 0;
-    // Four frames in one coder loop use the least CPU per frame but take four times as long to come out: worth it when
-    // the frames outnumber the threads (throughput), wrong for a short call (latency) -- there every thread takes one.
-    // Which batch finishes a call of n frames on T threads first?  A batch of b frames costs b x c(b) of wall time
-    // (c = CPU per frame with b coders in one loop: 3.3, 1.9, 1.5, 1.3 ms for the headline frame, tools/rc_speed.py) and the
-    // call needs ceil(n / (b T)) rounds of them; long calls end up at four, a call of 20 frames on 16 threads at two.
-    {
-      static const double cost[PCC_MAX_FRAMES_AT_ONCE + 1] = {0.0, 3.3, 1.9, 1.5, 1.3};
-      int best = 1;
-      double best_t = 1e300;
-      for (int b = 1; b <= p->batch && b <= PCC_MAX_FRAMES_AT_ONCE; ++b) {
-        const size_t per_round = (size_t)b * (size_t)p->n_entropy;
-        const double t = (double)((n_frames + per_round - 1) / per_round) * (double)b * cost[b];
-        if (t < best_t - 1e-9) { best_t = t; best = b; }
-      }
-      p->batch_now = best;
-    }
+    p->taken = 0;
     p->results.assign(n_frames, pcc_bitstream());
     p->status.assign(n_frames, PCC_OK);
     p->err.clear();
