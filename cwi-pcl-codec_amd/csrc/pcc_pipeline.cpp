@@ -397,7 +397,10 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   pcc_pipeline* p = new pcc_pipeline();
   p->device = device;
   p->n_entropy = n_workers;
-  p->n_gpu_device = n_workers < 6 ? n_workers : 6;  // frames in flight on the GPU: a handful saturates it
+  // frames in flight on the GPU: six saturate it to within a few per cent (tools/gpu_throughput.py: 4 streams 6 600, 8 streams
+  // 7 750, 12 streams 8 070 frames/s); with the entropy stage no longer the bottleneck the last per cent count
+  // (tools/sweep_gpu_threads.sh: 7 000 frames/s end to end with 6 threads, 7 400-7 500 with 10 or 12)
+  p->n_gpu_device = n_workers < 10 ? n_workers : 10;
   if (const char* e = getenv("PCC_PIPELINE_GPU_THREADS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) p->n_gpu_device = v;
