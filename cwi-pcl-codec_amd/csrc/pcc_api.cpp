@@ -850,7 +850,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   out->jpeg_tiles = tiles_ok ? h_tiles : nullptr;
   out->jpeg_tile_words = kJpegTileWords;
   out->jpeg_n_tiles = (uint32_t)n_tiles;
-  memcpy(ctx->occ_hist, ctx->h_state.p->occ_hist, sizeof(ctx->occ_hist));  // counted on the GPU (k_leaf_scan + k_leaf_tile), came back with the FrameState
+  memcpy(ctx->occ_hist, ctx->h_state.p->occ_hist, sizeof(ctx->occ_hist));  // counted by k_occ_histogram, came back with the FrameState
   out->occupancy_histogram = ctx->occ_hist;
   out->image_w = image ? W : 0;
   out->image_h = image ? H : 0;

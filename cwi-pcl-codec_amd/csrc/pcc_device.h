@@ -86,7 +86,7 @@ struct FrameState {
   uint32_t n_branches;               // B
   int32_t error;                     // FrameError
   // ---- for the host entropy stage ----
-  uint32_t occ_hist[256];            // how often each occupancy byte value occurs (k_leaf_scan + k_leaf_tile): the range coder's table
+  uint32_t occ_hist[256];            // how often each occupancy byte value occurs (k_occ_histogram): the range coder's table
   uint32_t jpeg_line_words;          // colour coding type 2: words of the strips' bit strings written so far (cursor of k_jpeg_lines)
 };
 

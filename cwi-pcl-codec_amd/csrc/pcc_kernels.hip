@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
   //         does not fit the bounding box as it stands.  A thread takes its chunks in ascending order and comes back
   //         to the first one that was not there yet.
   if (threadIdx.x == 0) s_nfin = 0;
-  st->occ_hist[threadIdx.x] = 0u;  // kBlock = 256 threads: one counter each (k_leaf_scan adds B zeros, k_leaf_tile moves the counts as it sets bits)
+  st->occ_hist[threadIdx.x] = 0u;  // kBlock = 256 threads: one counter each (filled by k_occ_histogram at the end of the frame)
   if (threadIdx.x == 0) st->jpeg_line_words = 0u;
   int first = 0x7fffffff, cand = 0x7fffffff;
   unsigned nfin = 0;
@@ -1106,7 +1106,6 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
     const uint32_t L = (uint32_t)(all & 0xffffffffu);
     st->n_leaves = L;
     st->n_branches = (uint32_t)(all >> 32);
-    atomicAdd(&st->occ_hist[0], (uint32_t)(all >> 32));  // every stream byte starts as 0 (k_leaf_tile moves the counts as it sets bits)
     leaf_start[L] = nfin;
     // keep the dword that holds the last stream byte clean beyond B (k_leaf_finalize ORs whole dwords)
     for (uint32_t k = b1; k < ((b1 + 3u) & ~3u); ++k) occ[k] = 0;
@@ -1117,26 +1116,8 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
 // Stage 5: one thread per leaf: colour mean (P6), voxel centre / centroid (C2, C4), snake-mapped
 // image pixel (C3b), and the leaf's contributions to the occupancy bytes (P5).
 // ------------------------------------------------------------------------------------------
-// The range coder's table = how often each byte value occurs in the finished occupancy stream.  Every byte starts as 0
-// (k_leaf_scan counts B zeros) and only ever gains bits through the atomic ORs below; an OR returns the dword it found, so
-// whoever changes a byte moves one count from its old value to its new one (LDS, signed; flushed per workgroup).  The
-// transitions of a byte chain up whatever the order of the ORs, so the sums are those of the final stream -- and the
-// separate pass over the stream that used to count them (k_occ_histogram: a launch, 1 MB read again) is gone.
-// (bytes that were 0 -- nearly all of them -- are only counted by the caller, which takes them off the zero bin in one go)
-__device__ __forceinline__ void note_byte_change(int* s_ohist, uint32_t old_dw, uint32_t new_dw, int& zeros_gone) {
-  uint32_t diff = old_dw ^ new_dw;
-  while (diff) {
-    const uint32_t b = (uint32_t)(__ffs((int)diff) - 1) >> 3;
-    const uint32_t was = (old_dw >> (8u * b)) & 0xffu;
-    if (was) atomicSub(&s_ohist[was], 1); else ++zeros_gone;
-    atomicAdd(&s_ohist[(new_dw >> (8u * b)) & 0xffu], 1);
-    diff &= ~(0xffu << (8u * b));
-  }
-}
-__device__ __forceinline__ void or_byte(uint8_t* occ, uint32_t off, uint32_t bits, int* s_ohist, int& zeros_gone) {
-  const uint32_t add = bits << (8u * (off & 3u));
-  const uint32_t old = atomicOr(reinterpret_cast<unsigned int*>(occ + (off & ~3u)), add);
-  note_byte_change(s_ohist, old, old | add, zeros_gone);
+__device__ __forceinline__ void or_byte(uint8_t* occ, uint32_t off, uint32_t bits) {
+  atomicOr(reinterpret_cast<unsigned int*>(occ + (off & ~3u)), bits << (8u * (off & 3u)));
 }
 
 // SnakeGridIterator (snake.h:46-71) in closed form: linear element i -> pixel index, W multiple of 8
@@ -1248,8 +1229,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
                                                            uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
                                                            uint8_t* __restrict__ image, float4* __restrict__ simplified,
                                                            JpegQuant jq, int16_t* __restrict__ coefs,
-                                                           uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff,
-                                                           uint32_t* occ_hist, unsigned long long* span) {
+                                                           uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff, unsigned long long* span) {
   const KSpan kspan(span);
   PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
@@ -1276,7 +1256,6 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   __shared__ unsigned long long s_slotbits[kMaxDepth + 2];  // per level v: which slots hold a leaf with t >= v
   __shared__ uint32_t s_far[kMaxDepth + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
   __shared__ uint64_t s_probe[64];
-  __shared__ int s_ohist[256];  // occupancy byte values: counts gained minus counts lost through this workgroup's ORs
   uint32_t* s_base = s_scratch;
   uint32_t* s_occ = s_scratch + kFinTile;
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
@@ -1296,7 +1275,6 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
   if (threadIdx.x < kMaxDepth + 2) s_slotbits[threadIdx.x] = 0ull;
-  if (threadIdx.x < 256) s_ohist[threadIdx.x] = 0;
   __syncthreads();
   PCC_KTR(7, 0);
   // first probes of the parent search below (the same for every level): requested together with the leaf records
@@ -1416,7 +1394,6 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   const uint32_t seg1 = nl ? s_base[nl - 1] + s_t[nl - 1] : 0u;
   const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
 
-  int zeros_gone = 0;  // stream bytes this thread turned from 0 into something (histogram bookkeeping, see or_byte)
   // ---- A2: per leaf ----
 #pragma unroll
   for (int r = 0; r < kFinRounds; ++r) {
@@ -1497,7 +1474,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       const uint32_t child = (uint32_t)(fullcode >> (3 * (D - 1 - level))) & 7u;
       const uint32_t lo = base[r] + (uint32_t)q - seg0;
       if ((lo >> 2) < (uint32_t)kOccWindow) atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
-      else or_byte(occ, base[r] + (uint32_t)q, 1u << child, s_ohist, zeros_gone);
+      else or_byte(occ, base[r] + (uint32_t)q, 1u << child);
     }
     if (j > 0) {
       const int v = tt + 1;  // t < D for every leaf but the first
@@ -1522,7 +1499,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       }
       const uint32_t rel = off - seg0;
       if (off >= seg0 && (rel >> 2) < (uint32_t)kOccWindow) atomicOr(&s_occ[rel >> 2], (1u << child) << (8u * (rel & 3u)));
-      else or_byte(occ, off, 1u << child, s_ohist, zeros_gone);
+      else or_byte(occ, off, 1u << child);
     }
     if (r == 0) PCC_KTR(5, 4);
   }
@@ -1535,10 +1512,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     unsigned int* dst = reinterpret_cast<unsigned int*>(occ + seg0);
     for (uint32_t k = threadIdx.x; k < ndw; k += kFinThreads) {
       const uint32_t v = s_occ[k];
-      if (v) {  // neighbouring tiles share the boundary dwords and set parent bits here
-        const uint32_t old = atomicOr(dst + k, v);
-        note_byte_change(s_ohist, old, old | v, zeros_gone);
-      }
+      if (v) atomicOr(dst + k, v);  // neighbouring tiles share the boundary dwords and set parent bits here
     }
   }
   if (lp.do_color && nl) {
@@ -1552,14 +1526,8 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     uint32_t* dsti = reinterpret_cast<uint32_t*>(image + (size_t)16u * m * 768u);
     for (uint32_t k = threadIdx.x; k < ndw; k += kFinThreads) dsti[k] = reinterpret_cast<const uint32_t*>(s_img)[k];
   }
-  if (zeros_gone) atomicSub(&s_ohist[0], zeros_gone);
-  PCC_KTR(7, 4);
-  __syncthreads();  // s_ohist is complete; the scratch area changes hands
-  if (!lp.simplify_only && threadIdx.x < 256) {
-    const int d = s_ohist[threadIdx.x];
-    if (d) atomicAdd(&occ_hist[threadIdx.x], (uint32_t)d);  // modulo 2^32: the negative parts cancel against other workgroups' counts
-  }
   if (!(lp.write_image && coefs)) return;
+  __syncthreads();  // the scratch area changes hands
 
   // ---- B: JPEG front end on the 16-row window: thread = (8x8 block, line) ----
   const int y_hb = (int)(H + 7u) / 8, ch = (int)(H + 1u) / 2, Hi = (int)H, row0 = 16 * (int)m;
@@ -1631,14 +1599,12 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     }
   }
   __syncthreads();
-  PCC_KTR(7, 5);
   int16_t* out = coefs + (size_t)m * 16 * 6 * 64;
   for (int k = threadIdx.x; k < 96 * 64; k += kFinThreads) {
     const int b = k >> 6, nat = kZigzagDev[k & 63];
     out[k] = (int16_t)s_ws[b * 72 + (nat >> 3) * 9 + (nat & 7)];
   }
   if (!jpeg_tiles) return;
-  PCC_KTR(7, 6);
 
   // ---- C: Huffman coding of the 96 blocks (jchuff.c encode_one_block), one wave per block, lane = zigzag
   // index.  The row's bit string is assembled in LDS; the DC codes of the first Y, Cb and Cr block depend on
@@ -1702,7 +1668,6 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     hb[i] = bits; hlen[i] = len; ho[i] = incl - len;
     if (lane == 63) s_blen[b] = incl;
   }
-  PCC_KTR(7, 7);
   __syncthreads();
   if (wave == 0) {  // exclusive scan of the 96 block lengths
     const uint32_t l0 = s_blen[lane], l1 = lane < 32 ? s_blen[64 + lane] : 0u;
@@ -1969,6 +1934,35 @@ size_t sync_area_bytes(uint32_t n, int passes) {
   return b;
 }
 
+// ---- k_occ_histogram: the range coder's symbol counts of the occupancy stream ----
+// The static range coder starts with a histogram of its input (one more serial pass over ~1 MB on the host, an
+// eighth of the host stage); the bytes are final here, so the counts ride back inside the FrameState for free.
+__global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ st, const uint8_t* __restrict__ occ, unsigned long long* span) {
+  const KSpan kspan(span);
+  __shared__ uint32_t s_h[4][256];  // four copies: runs of equal bytes do not pile up on one LDS word
+  if (st->error != kErrNone || st->n_epochs == 0) return;
+  for (int k = threadIdx.x; k < 4 * 256; k += 256) (&s_h[0][0])[k] = 0u;
+  __syncthreads();
+  const uint32_t B = st->n_branches;
+  const uint32_t vec = B / 16u;
+  const uint4* v = reinterpret_cast<const uint4*>(occ);
+  const int copy = threadIdx.x & 3;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < vec; i += gridDim.x * 256u) {
+    const uint4 q = v[i];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&s_h[copy][w[k] & 0xffu], 1u); atomicAdd(&s_h[copy][(w[k] >> 8) & 0xffu], 1u);
+      atomicAdd(&s_h[copy][(w[k] >> 16) & 0xffu], 1u); atomicAdd(&s_h[copy][w[k] >> 24], 1u);
+    }
+  }
+  if (blockIdx.x == 0)  // the tail
+    for (uint32_t i = vec * 16u + threadIdx.x; i < B; i += 256u) atomicAdd(&s_h[0][occ[i]], 1u);
+  __syncthreads();
+  const uint32_t c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+  if (c) atomicAdd(&st->occ_hist[threadIdx.x], c);
+}
+
 // developer aid: what the runtime thinks of the kernels' residency (workgroups per CU, registers, LDS)
 extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   std::string out;
@@ -1996,6 +1990,7 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
   one("k_leaf_scan", (const void*)k_leaf_scan, kSortThreads);
   one("k_leaf_tile", (const void*)k_leaf_tile, kFinThreads);
+  one("k_occ_histogram", (const void*)k_occ_histogram, 256);
   if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
   return 0;
 }
@@ -2050,13 +2045,19 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
-                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff, &a.state->occ_hist[0], span("k_leaf_tile"));
+                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff, span("k_leaf_tile"));
   PCC_STAMP("k_leaf_tile");
   if (a.jpeg_lines_dir) {
     const uint32_t max_lines = std::max(1u, n / 2048u);
     hipLaunchKernelGGL(k_jpeg_lines, dim3(max_lines), dim3(kLineThreads), 0, stream, a.state, a.bgr, a.jq, a.huff, a.jpeg_lines_dir, a.jpeg_lines_data,
                        a.jpeg_lines_capacity, span("k_jpeg_lines"));
     PCC_STAMP("k_jpeg_lines");
+  }
+  if (!a.lp.simplify_only) {
+    // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64
+    const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));
+    hipLaunchKernelGGL(k_occ_histogram, dim3(hist_wgs), dim3(256), 0, stream, a.state, a.occ, span("k_occ_histogram"));
+    PCC_STAMP("k_occ_histogram");
   }
 }
 

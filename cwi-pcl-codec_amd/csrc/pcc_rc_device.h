@@ -8,7 +8,7 @@ namespace pcc {
 struct RcJob {            // one stream (device pointers)
   const uint8_t* in;      // symbols
   uint32_t n;
-  const uint32_t* hist;   // 256 symbol counts if somebody has them already (the GPU counts them for the occupancy stream), else null
+  const uint32_t* hist;   // 256 symbol counts if somebody has them already (k_occ_histogram), else null
   uint8_t* out;           // 1028-byte table + payload + 4 flush bytes; room for 1028 + n + n / 2 + 64 bytes, 4-byte aligned
   uint32_t* out_len;      // bytes written
 };

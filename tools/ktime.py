@@ -44,9 +44,6 @@ print("            stamps (max us):", np.round(rel.max(axis=0), 2))
 x = t[7, :nlt, :4]
 rel = (x - t[5, :nlt, 0:1]) / 100.0
 print("k_leaf_tile A1 (median us since kernel start): first barrier, records landed + masks, barrier, parent search done:", np.round(np.median(rel, axis=0), 2))
-x = t[7, :nlt, 4:8]
-rel = (x - t[5, :nlt, 0:1]) / 100.0
-print("k_leaf_tile tail (median us since kernel start): A3 writes done, FDCT + quantisation done, coefficients written, Huffman codes made:", np.round(np.median(rel, axis=0), 2))
 x8 = t[8, 0, :8]
 x = t[6, 0, :7]
 print("k_boxes_events replay rounds (us since start, after each block-wide minimum):", np.round((x8 - x[0]) / 100.0, 2))
