@@ -734,7 +734,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   uint64_t* s_keys = s_raw;
   uint32_t* s_pay = reinterpret_cast<uint32_t*>(s_raw + kSortTile);
   __shared__ uint16_t s_cnt[NW][kMaxBins];  // per-wave running digit counts, then wave start ranks
-  __shared__ uint32_t s_hist[kMaxBins];     // digit counts of the tile
   __shared__ uint32_t s_gofs[kMaxBins];     // global position of a digit's first key minus its position in s_keys
   __shared__ uint16_t s_dstart[kMaxBins];   // position of a digit's first key in s_keys
   __shared__ uint32_t s_scan[NW];
@@ -757,7 +756,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   const uint32_t dtot = d_me < nbins ? digit_tot[(size_t)pass * kMaxBins + d_me] : 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins; k += THREADS) s_match[k] = 0ull;
-  for (int k = threadIdx.x; k < kMaxBins; k += THREADS) s_hist[k] = 0u;
   if (threadIdx.x == 0) s_tile = ticket;
   // global start of every digit = exclusive scan of the digit totals (its barriers also cover the LDS set up above)
   uint32_t gsum;
@@ -792,29 +790,65 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
     key[r] = i < count ? in[i] : kInvalidKey;
     pay[r] = (with_payload && i < count) ? pay_in[i] : 0u;
   }
-  // ---- the tile's digit counts first, so that later tiles learn them as early as possible ----
-  // (the digit of the row's first key is counted with one ballot: the most significant digit of a clustered
-  // cloud has few values, and 64 lanes adding to one LDS word would serialise)
+  // ---- ranking first: the tile's digit counts fall out of it (sum of the per-wave counts), so the separate counting
+  //      pass over the keys that used to come first is gone; the tile's word is published right after, and the keys go
+  //      into digit order in LDS BEFORE the look-back, whose round trips then have something to overlap with (and the
+  //      registers of keys, payload and ranks are free by then).
+  // Peers = lanes of this wave whose key has the same digit.  Every lane ORs its lane bit
+  // into the (wave, digit) mask in LDS and reads the mask back: three LDS operations instead of one ballot
+  // and a handful of 64-bit VALU operations per digit bit.  The first peer clears the mask again and advances
+  // the wave's digit counter (LDS operations of one wave execute in program order, so no barrier is needed).
+  uint64_t* wmatch = s_match + (size_t)wave * kMaxBins;
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const bool valid = key[r] != kInvalidKey;
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    // the peers of the row's first key come from one ballot (the most significant digit of a clustered cloud has few
+    // values, and 64 lanes ORing into one LDS word would serialise), the others through LDS
     const uint64_t vm = __ballot(valid);
-    if (vm) {
-      const int first = __ffsll((long long)vm) - 1;
-      const uint32_t d0 = __shfl(d, first);
-      const uint64_t same = __ballot(valid && d == d0);
-      if (lane == first) atomicAdd(&s_hist[d0], (uint32_t)__popcll(same));
-      else if (valid && d != d0) atomicAdd(&s_hist[d], 1u);
+    const int first = vm ? __ffsll((long long)vm) - 1 : 0;
+    const uint32_t d0 = __shfl(d, first);
+    const uint64_t same = __ballot(valid && d == d0);
+    const bool via_lds = valid && d != d0;
+    if (via_lds) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
+    const uint64_t peers = via_lds ? wmatch[d] : (valid ? same : 0ull);
+    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+    const uint32_t prior = s_cnt[wave][d];
+    if (valid && rank == 0) {
+      if (via_lds) wmatch[d] = 0ull;
+      s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
     }
+    lrank[r] = (uint16_t)(prior + rank);
   }
   __syncthreads();
-  const uint32_t run = d_me < nbins ? s_hist[d_me] : 0u;
+  PCC_KT(4);
+  uint32_t run = 0;  // keys of this tile with digit d_me
+  if (d_me < nbins) {  // per-wave counts -> wave start ranks inside the tile
+    uint32_t sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = s_cnt[w][d_me];
+      s_cnt[w][d_me] = (uint16_t)sum;
+      sum += c;
+    }
+    run = sum;
+  }
   if (pass != 0 && d_me < nbins) publish_u32(status + (size_t)tile * kMaxBins + d_me, kStatusAggregate | run);
   uint32_t tile_valid;
   const uint32_t dstart = block_excl_scan<NW, uint32_t>(run, s_scan, tile_valid);
+  if (d_me < nbins) s_dstart[d_me] = (uint16_t)dstart;
+  __syncthreads();
   PCC_KT(2);
-
+  // keys into digit order in LDS ...
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    if (key[r] != kInvalidKey) {
+      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+      const uint32_t lp = (uint32_t)s_dstart[d] + s_cnt[wave][d] + lrank[r];
+      s_keys[lp] = key[r];
+      if (with_payload) s_pay[lp] = pay[r];
+    }
+  }
   // Two-level decoupled look-back over one self-describing word per (tile, digit) / (group of 16 tiles, digit).
   // To keep the polling traffic off the memory system only ONE lane per awaited tile polls (the digit-0 word)
   // until it is there; then every thread reads its own digit's words.
@@ -850,51 +884,14 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
       if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
     }
   };
-  // The last tile of a group publishes the group's count BEFORE it ranks its own keys: the two hops of the
-  // look-back (tile counts -> group count -> the tiles that need it) then overlap with everybody's ranking.
+  // The last tile of a group publishes the group's count before it looks back itself: the two hops of the
+  // look-back (tile counts -> group count -> the tiles that need it) then overlap.
   if (pass != 0 && closes_group) {
     wait_group_mates(false);
     if (d_me < nbins) read_group_mates();
     if (d_me < nbins) publish_u32(gstatus + (size_t)g * kMaxBins + d_me, (g == 0 ? kStatusInclusive : kStatusAggregate) | (partial + run));
   }
   PCC_KT(3);
-
-  // ---- ranking.  Peers = lanes of this wave whose key has the same digit.  Every lane ORs its lane bit
-  // into the (wave, digit) mask in LDS and reads the mask back: three LDS operations instead of one ballot
-  // and a handful of 64-bit VALU operations per digit bit.  The first peer clears the mask again and advances
-  // the wave's digit counter (LDS operations of one wave execute in program order, so no barrier is needed).
-  uint64_t* wmatch = s_match + (size_t)wave * kMaxBins;
-#pragma unroll
-  for (int r = 0; r < ITEMS; ++r) {
-    const bool valid = key[r] != kInvalidKey;
-    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-    // the peers of the row's first key come from one ballot (see the histogram above), the others through LDS
-    const uint64_t vm = __ballot(valid);
-    const int first = vm ? __ffsll((long long)vm) - 1 : 0;
-    const uint32_t d0 = __shfl(d, first);
-    const uint64_t same = __ballot(valid && d == d0);
-    const bool via_lds = valid && d != d0;
-    if (via_lds) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
-    const uint64_t peers = via_lds ? wmatch[d] : (valid ? same : 0ull);
-    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-    const uint32_t prior = s_cnt[wave][d];
-    if (valid && rank == 0) {
-      if (via_lds) wmatch[d] = 0ull;
-      s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));
-    }
-    lrank[r] = (uint16_t)(prior + rank);
-  }
-  __syncthreads();
-  PCC_KT(4);
-  if (d_me < nbins) {  // per-wave counts -> wave start ranks inside the tile
-    uint32_t sum = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t c = s_cnt[w][d_me];
-      s_cnt[w][d_me] = (uint16_t)sum;
-      sum += c;
-    }
-  }
 
   // ---- keys of each digit in the tiles before this one ----
   uint32_t acc = 0;
@@ -953,23 +950,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
       acc = before + partial;
     }
   }
-  if (d_me < nbins) {
-    s_dstart[d_me] = (uint16_t)dstart;
-    s_gofs[d_me] = gbase + acc - dstart;
-  }
+  if (d_me < nbins) s_gofs[d_me] = gbase + acc - dstart;
   __syncthreads();
   PCC_KT(7);
-  // keys into digit order in LDS ...
-#pragma unroll
-  for (int r = 0; r < ITEMS; ++r) {
-    if (key[r] != kInvalidKey) {
-      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-      const uint32_t lp = (uint32_t)s_dstart[d] + s_cnt[wave][d] + lrank[r];
-      s_keys[lp] = key[r];
-      if (with_payload) s_pay[lp] = pay[r];
-    }
-  }
-  __syncthreads();
   // ... and out in runs: consecutive lanes hold consecutive keys of (mostly) the same digit
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -1004,13 +987,17 @@ __device__ __forceinline__ uint64_t head_t(uint64_t code, uint64_t prev, bool is
 __device__ __forceinline__ uint64_t scan_pack(uint64_t ht) { return ((ht >> 32) << 30) | (ht & 0x3fffffffull); }
 __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30) & 0xffffffffull) << 32) | (w & 0x3fffffffull); }
 
-__global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+// (two workgroup shapes, like k_sort_pass: 1024 threads x 4 keys for small grids, 512 x 8 -- two workgroups per CU, one
+// looks back while the other scans -- for the rest)
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
                                                             uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
                                                             uint8_t* __restrict__ occ, unsigned long long* span) {
   const KSpan kspan(span);
-  constexpr int NW = kSortThreads / 64;
+  constexpr int NW = THREADS / 64;
+  static_assert(THREADS * ITEMS == kSortTile, "a tile is 4096 keys");
   constexpr uint64_t kFlagAgg = 1ull << 62, kFlagIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
   __shared__ uint64_t s_w[NW];
   __shared__ uint64_t s_prefix;
@@ -1026,16 +1013,16 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
   // Every wave owns 512 consecutive sorted keys, read as 8 rows of 64 (coalesced); element (r, lane)
   // is key wbase + 64 r + lane, so scan order is row-major inside the wave, then wave-major.
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
-  uint64_t ht[kSortItems], code[kSortItems], inc[kSortItems];
+  uint64_t ht[ITEMS], code[ITEMS], inc[ITEMS];
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
     code[r] = i < nfin ? (keys[i] >> ibits) : 0ull;
   }
   uint64_t carry = (lane == 0 && wbase > 0 && wbase < nfin) ? (keys[wbase - 1] >> ibits) : 0ull;  // key before the segment
   uint64_t wave_tot = 0;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
     uint64_t prev = __shfl_up(code[r], 1);
     if (lane == 0) prev = carry;
@@ -1085,7 +1072,7 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
   __syncthreads();
   const uint64_t pre = s_prefix;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     if (ht[r] & 1ull) {
       const uint64_t ex = pre + woff + inc[r] - ht[r];
       const uint32_t id = (uint32_t)(ex & 0xffffffffu);
@@ -1098,9 +1085,9 @@ __global__ __launch_bounds__(kSortThreads) void k_leaf_scan(const uint64_t* __re
   // zero the piece of the DFS stream this tile's leaves open: bytes [b0, b1)
   const uint32_t b0 = (uint32_t)(pre >> 32), b1 = b0 + (uint32_t)(tot >> 32);
   const uint32_t a0 = min((b0 + 15u) & ~15u, b1), a1 = max(b1 & ~15u, a0);
-  for (uint32_t k = b0 + threadIdx.x; k < a0; k += kSortThreads) occ[k] = 0;
-  for (uint32_t k = a0 + threadIdx.x * 16u; k < a1; k += kSortThreads * 16u) *reinterpret_cast<uint4*>(occ + k) = make_uint4(0, 0, 0, 0);
-  for (uint32_t k = a1 + threadIdx.x; k < b1; k += kSortThreads) occ[k] = 0;
+  for (uint32_t k = b0 + threadIdx.x; k < a0; k += THREADS) occ[k] = 0;
+  for (uint32_t k = a0 + threadIdx.x * 16u; k < a1; k += THREADS * 16u) *reinterpret_cast<uint4*>(occ + k) = make_uint4(0, 0, 0, 0);
+  for (uint32_t k = a1 + threadIdx.x; k < b1; k += THREADS) occ[k] = 0;
   if ((uint64_t)(tile + 1) * kSortTile >= nfin && threadIdx.x == 0) {  // the last tile closes the frame
     const uint64_t all = pre + tot;
     const uint32_t L = (uint32_t)(all & 0xffffffffu);
@@ -1988,14 +1975,19 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_make_keys", (const void*)k_make_keys, kSortThreads);
   one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems>, kSortThreads);
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
-  one("k_leaf_scan", (const void*)k_leaf_scan, kSortThreads);
+  one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems>, kSortThreads);
+  one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8>, 512);
   one("k_leaf_tile", (const void*)k_leaf_tile, kFinThreads);
   one("k_occ_histogram", (const void*)k_occ_histogram, 256);
   if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
   return 0;
 }
 
-constexpr uint32_t kSortSmallGridTiles = 512;  // up to two tiles per CU the wide workgroup is used
+// Up to this many tiles the wide workgroup (1024 threads x 4 keys: 16 waves share a tile's latency-bound steps) is used,
+// beyond it the narrow one (512 x 8: two workgroups per CU).  One frame at a time the wide shape is a little faster at 1 M
+// points (176.5 against 179.8 us per frame), but with frames in flight on other streams the narrow one wins by more
+// (cfg2, ten streams: 9 170 against 8 550 frames/s), and throughput is what the pipeline is for.
+constexpr uint32_t kSortSmallGridTiles = 96;
 
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) {
   int span_slot = 0;
@@ -2038,8 +2030,12 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                          n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass"));
     PCC_STAMP("k_sort_pass");
   }
-  hipLaunchKernelGGL(k_leaf_scan, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
-                     a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
+  if (many_tiles)
+    hipLaunchKernelGGL((k_leaf_scan<512, 8>), dim3(s_tiles), dim3(512), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
+                       a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
+  else
+    hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
+                       a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
   PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
