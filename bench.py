@@ -67,9 +67,10 @@ def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
         return 2 * (8 + pay) * n           # read key + payload, write key + payload
     if name == "k_leaf_scan":
         return 8 * n + 17 * L + B          # read keys; write start, code, base, t per leaf; zero the DFS stream
-    if name == "k_leaf_tile":
-        coefs = image_bytes                # 1.5 int16 coefficients per pixel = 3 bytes per pixel
-        return 17 * L + pay * n + (3 * L + coefs if with_color else 0) + 16 * L + B
+    if name == "k_leaf_tile":              # leaf records, colour words; bgr, image rows, simplified cloud, DFS stream
+        return 17 * L + pay * n + (3 * L + image_bytes if with_color else 0) + 16 * L + B
+    if name == "k_jpeg_rows":              # image rows in; 1.5 int16 coefficients per pixel = 3 bytes per pixel out
+        return 2 * image_bytes if with_color else 0
     return 0
 
 

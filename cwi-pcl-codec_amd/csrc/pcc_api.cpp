@@ -555,7 +555,7 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
     BaselineJpeg::quantiser(prm->jpeg_quality, a.jq.half, a.jq.magic);
   }
   // the snake image itself only leaves the chip if somebody wants to look at it, or the host does the JPEG
-  a.image = (a.lp.write_image && (ctx->copy_image || !a.coefs)) ? ctx->d_image.p : nullptr;
+  a.image = a.lp.write_image ? ctx->d_image.p : nullptr;  // k_leaf_tile -> k_jpeg_rows; it only leaves the chip if somebody wants to look at it, or the host does the JPEG
   a.jpeg_tiles = (a.coefs && ctx->jpeg_on_gpu >= 2) ? reinterpret_cast<uint32_t*>(ctx->d_occ.p) : nullptr;
   ctx->lines_dir_words = 0;
   if (a.lp.do_color && prm->color_coding_type == 2 && ctx->jpeg_on_gpu >= 2 && !simplify_only && !stop_after_leaf_scan) {

@@ -1187,25 +1187,24 @@ __device__ const uint8_t kZigzagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 2
                                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // ------------------------------------------------------------------------------------------
-// Stage 5+6: one workgroup per MCU ROW of the snake-mapped image.  In snake order (snake.h:46-71) the
-// 16 image rows of an MCU row are filled by ONE contiguous range of leaves (two 8-row block rows of
-// 2048 leaves; the last, partial block row holds 256 x (H mod 8)), so a workgroup owns <= 4096
-// consecutive leaves and everything they produce:
+// Stage 5: one workgroup per BLOCK ROW (8 image rows) of the snake-mapped image.  In snake order (snake.h:46-71) the
+// 8 image rows of a block row are filled by ONE contiguous range of 2048 leaves (the last, partial block row holds
+// 256 x (H mod 8)), so a workgroup owns <= 2048 consecutive leaves and everything they produce:
 //   per leaf   colour mean (P6), voxel centre / centroid (C2, C4), simplified-cloud point, the leaf's
 //              bits of the occupancy stream (P5; collected in an LDS window of the DFS stream)
-//   per tile   the 16 x 256 image window in LDS (never written to HBM unless the caller wants the image),
-//              libjpeg's front end on it (jpeg_io.hpp:259-314: RGB->YCbCr, h2v2 downsample, islow FDCT,
-//              quantisation) -> 96 blocks of 64 zigzag-ordered coefficients; only Huffman coding is left
-//              for the host.
-// All global writes are contiguous runs (bgr, simplified, coefficients, image rows).
+//   per tile   the 8 x 256 image window, assembled in LDS and written as whole rows (k_jpeg_rows reads them)
+// All global writes are contiguous runs (bgr, simplified, image rows).
+// Round 1 had one 1024-thread workgroup per MCU row do this AND the JPEG stage: 118 KB of LDS, one workgroup per CU
+// for 40 us.  Now two 512-thread workgroups share a CU (56 KB each), and the JPEG stage (45 KB, 768 threads, no
+// per-leaf state) is a launch of its own: more boundaries for a lone frame, less CU time per frame when frames overlap.
 // ------------------------------------------------------------------------------------------
-constexpr int kFinThreads = 1024;
+constexpr int kFinThreads = 512;
 constexpr int kFinRounds = 4;                          // leaves per thread
-constexpr int kFinTile = kFinThreads * kFinRounds;     // 4096 leaf positions
+constexpr int kFinTile = kFinThreads * kFinRounds;     // 2048 leaf positions
 constexpr int kFinSlots = kFinTile / 64;               // (wave, round) slots of 64 consecutive leaves
-constexpr int kOccWindow = 8192;                       // dwords of the DFS stream collected in LDS
+constexpr int kOccWindow = 4096;                       // dwords of the DFS stream collected in LDS
 constexpr int kMaskStride = kMaxDepth + 1;
-constexpr int kColourStage = 6144;                     // colour words staged in LDS per tile (1.5 points per leaf)
+constexpr int kColourStage = 3072;                     // colour words staged in LDS per tile (1.5 points per leaf)
 
 __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double res, LeafParams lp,
                                                            const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
@@ -1214,32 +1213,24 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
                                                            const uint32_t* __restrict__ leaf_start, const uint64_t* __restrict__ leaf_code,
                                                            const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
                                                            uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
-                                                           uint8_t* __restrict__ image, float4* __restrict__ simplified,
-                                                           JpegQuant jq, int16_t* __restrict__ coefs,
-                                                           uint32_t* __restrict__ jpeg_tiles, const JpegHuffTables* __restrict__ huff, unsigned long long* span) {
+                                                           uint8_t* __restrict__ image, float4* __restrict__ simplified, unsigned long long* span) {
   const KSpan kspan(span);
   PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
   if (L == 0 || st->error != kErrNone) return;  // after an error upstream the leaf arrays are not to be trusted
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
-  const uint32_t m = blockIdx.x;               // MCU row
-  if (16u * m >= H) return;
+  const uint32_t br = blockIdx.x;              // block row: image rows [8 br, 8 br + 8)
+  if (8u * br >= H) return;
   const uint32_t full = H / 8u, hl = H % 8u;
-  const uint32_t br0 = 2u * m;
-  const uint32_t cnt0 = br0 < full ? 2048u : 256u * hl;  // br0 <= full here
-  const uint32_t cnt1 = br0 + 1u < full ? 2048u : (br0 + 1u == full ? 256u * hl : 0u);
-  const uint32_t pos0 = 2048u * br0, npos = cnt0 + cnt1;   // leaf positions [pos0, pos0 + npos) fill this MCU row
+  const uint32_t pos0 = 2048u * br, npos = br < full ? 2048u : 256u * hl;  // leaf positions [pos0, pos0 + npos) fill this block row (br <= full here)
   const uint32_t nl = min(npos, L - pos0);                  // real leaves among them (pos0 <= L always)
 
-  __shared__ __attribute__((aligned(16))) uint8_t s_img[16 * 768];
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[8 * 768];
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[3 * kFinTile];
-  // phase A: s_base | s_occ | s_mask | s_t ; phase B: the FDCT workspace
+  // s_base | s_occ | s_mask | s_t
   __shared__ __attribute__((aligned(16))) uint32_t s_scratch[kFinTile + kOccWindow + kFinSlots * kMaskStride * 2 + kFinTile / 4];
   __shared__ uint32_t s_col[kColourStage];  // the tile's sorted colour words, loaded as one contiguous run
   __shared__ uint32_t s_pad;
-  __shared__ uint32_t s_hbits[kJpegTileWords];  // header + Huffman bits of this MCU row
-  __shared__ uint32_t s_hdc[2 * 12], s_hac[2 * 256];
-  __shared__ uint32_t s_blen[96], s_boff[96];
   __shared__ unsigned long long s_slotbits[kMaxDepth + 2];  // per level v: which slots hold a leaf with t >= v
   __shared__ uint32_t s_far[kMaxDepth + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
   __shared__ uint64_t s_probe[64];
@@ -1247,8 +1238,6 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   uint32_t* s_occ = s_scratch + kFinTile;
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
   uint8_t* s_t = reinterpret_cast<uint8_t*>(s_mask + kFinSlots * kMaskStride);
-  int* s_ws = reinterpret_cast<int*>(s_scratch);
-  static_assert(sizeof(uint32_t) * (kFinTile + kOccWindow) >= sizeof(int) * 96 * 8 * 9, "FDCT workspace must fit");
 
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, D = st->depth;
@@ -1387,7 +1376,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     const uint32_t slot = (uint32_t)wave * kFinRounds + r, lj = slot * 64u + (uint32_t)lane, j = pos0 + lj;
     if (lj >= nl) {
       if (lp.write_image && lj < npos) {
-        const uint32_t px = snake_pos(j, W, H) - 16u * m * W;
+        const uint32_t px = snake_pos(j, W, H) - 8u * br * W;
         s_img[3 * px] = (uint8_t)s_pad; s_img[3 * px + 1] = (uint8_t)(s_pad >> 8); s_img[3 * px + 2] = (uint8_t)(s_pad >> 16);
       }
       continue;
@@ -1410,7 +1399,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
       }
       s_bgr[3 * lj] = (uint8_t)cb; s_bgr[3 * lj + 1] = (uint8_t)cg; s_bgr[3 * lj + 2] = (uint8_t)cr;
       if (lp.write_image) {
-        const uint32_t px = snake_pos(j, W, H) - 16u * m * W;
+        const uint32_t px = snake_pos(j, W, H) - 8u * br * W;
         s_img[3 * px] = (uint8_t)cb; s_img[3 * px + 1] = (uint8_t)cg; s_img[3 * px + 2] = (uint8_t)cr;
       }
     }
@@ -1509,18 +1498,50 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
     for (uint32_t k = 4u * ndw + threadIdx.x; k < nbytes; k += kFinThreads) dstb[k] = s_bgr[k];
   }
   if (lp.write_image && image) {
-    const uint32_t rows_here = min(16u, H - 16u * m), ndw = rows_here * 768u / 4u;
-    uint32_t* dsti = reinterpret_cast<uint32_t*>(image + (size_t)16u * m * 768u);
+    const uint32_t rows_here = min(8u, H - 8u * br), ndw = rows_here * 768u / 4u;
+    uint32_t* dsti = reinterpret_cast<uint32_t*>(image + (size_t)8u * br * 768u);
     for (uint32_t k = threadIdx.x; k < ndw; k += kFinThreads) dsti[k] = reinterpret_cast<const uint32_t*>(s_img)[k];
   }
-  if (!(lp.write_image && coefs)) return;
-  __syncthreads();  // the scratch area changes hands
+  PCC_KTR(5, 6);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 6: one workgroup per MCU ROW (16 image rows) of the snake-mapped image: libjpeg's front end on it
+// (jpeg_io.hpp:259-314: RGB->YCbCr, h2v2 downsample, islow FDCT, quantisation) -> 96 blocks of 64 zigzag-ordered
+// coefficients, and their Huffman coding (jchuff.c); the host adds the file headers and stitches the rows.
+// The rows come from k_leaf_tile through `image` (2.8 MB per 1 M-voxel frame, written and read once).
+// ------------------------------------------------------------------------------------------
+constexpr int kJpegThreads = 768;  // thread = (8x8 block, line) in the FDCT; 12 waves x 8 blocks in the Huffman stage
+
+__global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(const FrameState* __restrict__ st, const uint8_t* __restrict__ image,
+                                                            JpegQuant jq, int16_t* __restrict__ coefs, uint32_t* __restrict__ jpeg_tiles,
+                                                            const JpegHuffTables* __restrict__ huff, unsigned long long* span) {
+  const KSpan kspan(span);
+  const uint32_t L = st->n_leaves;
+  if (L == 0 || st->error != kErrNone) return;
+  const uint32_t H = L / 256u + 1u;  // jpegcc.h:194-198; the image is 256 pixels wide
+  const uint32_t m = blockIdx.x;     // MCU row
+  if (16u * m >= H) return;
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[16 * 768];
+  __shared__ int s_ws[96 * 8 * 9];  // FDCT workspace: 96 blocks of 8 lines, 9 ints apart
+  __shared__ uint32_t s_hbits[kJpegTileWords];  // header + Huffman bits of this MCU row
+  __shared__ uint32_t s_hdc[2 * 12], s_hac[2 * 256];
+  __shared__ uint32_t s_blen[96], s_boff[96];
+  const int lane = lane_id(), wave = wave_id();
+  {
+    const uint32_t rows_here = min(16u, H - 16u * m), ndw = rows_here * 768u / 4u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(image + (size_t)16u * m * 768u);
+    for (uint32_t k = threadIdx.x; k < ndw; k += kJpegThreads) reinterpret_cast<uint32_t*>(s_img)[k] = src[k];
+  }
+  __syncthreads();
+  PCC_KTR(7, 4);
+
 
   // ---- B: JPEG front end on the 16-row window: thread = (8x8 block, line) ----
   const int y_hb = (int)(H + 7u) / 8, ch = (int)(H + 1u) / 2, Hi = (int)H, row0 = 16 * (int)m;
   const int blk = threadIdx.x >> 3, line = threadIdx.x & 7;
   const int mx = blk / 6, slot6 = blk % 6;
-  const bool active = threadIdx.x < 96 * 8;
+  const bool active = true;  // 768 threads = 96 blocks x 8 lines
   bool dummy = false;
   if (active) {
     int d0, d1, d2, d3, d4, d5, d6, d7;
@@ -1587,7 +1608,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   }
   __syncthreads();
   int16_t* out = coefs + (size_t)m * 16 * 6 * 64;
-  for (int k = threadIdx.x; k < 96 * 64; k += kFinThreads) {
+  for (int k = threadIdx.x; k < 96 * 64; k += kJpegThreads) {
     const int b = k >> 6, nat = kZigzagDev[k & 63];
     out[k] = (int16_t)s_ws[b * 72 + (nat >> 3) * 9 + (nat & 7)];
   }
@@ -1596,11 +1617,11 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   // ---- C: Huffman coding of the 96 blocks (jchuff.c encode_one_block), one wave per block, lane = zigzag
   // index.  The row's bit string is assembled in LDS; the DC codes of the first Y, Cb and Cr block depend on
   // the MCU row before and are left to the host, which stitches the rows together.
-  for (int k = threadIdx.x; k < kJpegTileWords; k += kFinThreads) s_hbits[k] = 0u;
-  for (int k = threadIdx.x; k < 24; k += kFinThreads) s_hdc[k] = (&huff->dc[0][0])[k];
-  for (int k = threadIdx.x; k < 512; k += kFinThreads) s_hac[k] = (&huff->ac[0][0])[k];
+  for (int k = threadIdx.x; k < kJpegTileWords; k += kJpegThreads) s_hbits[k] = 0u;
+  for (int k = threadIdx.x; k < 24; k += kJpegThreads) s_hdc[k] = (&huff->dc[0][0])[k];
+  for (int k = threadIdx.x; k < 512; k += kJpegThreads) s_hac[k] = (&huff->ac[0][0])[k];
   __syncthreads();
-  constexpr int kBlocksPerWave = 96 / (kFinThreads / 64);  // 6
+  constexpr int kBlocksPerWave = 96 / (kJpegThreads / 64);  // 6
   uint64_t hb[kBlocksPerWave];
   uint32_t hlen[kBlocksPerWave], ho[kBlocksPerWave];
   // effective DC of a block: a dummy block below the image carries the DC of the block before its row (Y01)
@@ -1611,7 +1632,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   };
 #pragma unroll
   for (int i = 0; i < kBlocksPerWave; ++i) {
-    const int b = wave + i * (kFinThreads / 64);
+    const int b = wave + i * (kJpegThreads / 64);
     const int bmx = b / 6, bs = b % 6, comp = bs < 4 ? 0 : 1;
     const bool dmy = bs >= 2 && bs < 4 && (2 * (int)m + 1) >= y_hb;
     const int nat = kZigzagDev[lane];
@@ -1673,7 +1694,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   const bool fits = s_hbits[3] == 0u;
 #pragma unroll
   for (int i = 0; i < kBlocksPerWave; ++i) {
-    const int b = wave + i * (kFinThreads / 64);
+    const int b = wave + i * (kJpegThreads / 64);
     uint32_t n = hlen[i];
     if (n && fits) {
       uint32_t p = s_boff[b] + ho[i];
@@ -1695,7 +1716,7 @@ __global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double 
   {
     const uint32_t words = kJpegTileHeader + (fits ? (s_hbits[0] + 31u) / 32u : 0u);
     uint32_t* rec = jpeg_tiles + (size_t)m * kJpegTileWords;
-    for (uint32_t k = threadIdx.x; k < words; k += kFinThreads) rec[k] = s_hbits[k];
+    for (uint32_t k = threadIdx.x; k < words; k += kJpegThreads) rec[k] = s_hbits[k];
   }
   PCC_KTR(5, 6);
 }
@@ -1978,6 +1999,7 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems>, kSortThreads);
   one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8>, 512);
   one("k_leaf_tile", (const void*)k_leaf_tile, kFinThreads);
+  one("k_jpeg_rows", (const void*)k_jpeg_rows, kJpegThreads);
   one("k_occ_histogram", (const void*)k_occ_histogram, 256);
   if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
   return 0;
@@ -2039,10 +2061,14 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
-  hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 15u) / 16u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+  hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 7u) / 8u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
-                     reinterpret_cast<float4*>(a.simplified), a.jq, a.coefs, a.jpeg_tiles, a.huff, span("k_leaf_tile"));
+                     reinterpret_cast<float4*>(a.simplified), span("k_leaf_tile"));
   PCC_STAMP("k_leaf_tile");
+  if (a.lp.write_image && a.coefs && a.image) {
+    hipLaunchKernelGGL(k_jpeg_rows, dim3((max_h + 15u) / 16u), dim3(kJpegThreads), 0, stream, a.state, a.image, a.jq, a.coefs, a.jpeg_tiles, a.huff, span("k_jpeg_rows"));
+    PCC_STAMP("k_jpeg_rows");
+  }
   if (a.jpeg_lines_dir) {
     const uint32_t max_lines = std::max(1u, n / 2048u);
     hipLaunchKernelGGL(k_jpeg_lines, dim3(max_lines), dim3(kLineThreads), 0, stream, a.state, a.bgr, a.jq, a.huff, a.jpeg_lines_dir, a.jpeg_lines_data,
