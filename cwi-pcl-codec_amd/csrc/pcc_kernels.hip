@@ -990,7 +990,7 @@ __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30)
 // (two workgroup shapes, like k_sort_pass: 1024 threads x 4 keys for small grids, 512 x 8 -- two workgroups per CU, one
 // looks back while the other scans -- for the rest)
 template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
                                                             uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
@@ -1202,11 +1202,13 @@ constexpr int kFinThreads = 512;
 constexpr int kFinRounds = 4;                          // leaves per thread
 constexpr int kFinTile = kFinThreads * kFinRounds;     // 2048 leaf positions
 constexpr int kFinSlots = kFinTile / 64;               // (wave, round) slots of 64 consecutive leaves
-constexpr int kOccWindow = 4096;                       // dwords of the DFS stream collected in LDS
+constexpr int kOccWindow = 3072;                       // dwords of the DFS stream collected in LDS (a surface needs ~300, a dense cloud ~1 800)
 constexpr int kMaskStride = kMaxDepth + 1;
-constexpr int kColourStage = 3072;                     // colour words staged in LDS per tile (1.5 points per leaf)
+constexpr int kColourStage = 2560;                     // colour words staged in LDS per tile (1.25 points per leaf)
 
-__global__ __launch_bounds__(kFinThreads) void k_leaf_tile(PointView pv, double res, LeafParams lp,
+// (second launch bound: six waves per SIMD, i.e. three of these workgroups per CU -- the kernel spends two thirds of its
+// time waiting for its leaf records and for the parent search, and only other workgroups can fill that)
+__global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, double res, LeafParams lp,
                                                            const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
                                                            const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
                                                            const FrameState* __restrict__ st,

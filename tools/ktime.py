@@ -35,7 +35,7 @@ for ps in range(hot.depth * 3 // 9 + 1 if wl != "cfg2" else 4):
         e = d[part]
         print("          %-22s: start at %.1f us, look-back %.2f us, whole %.2f us" % (name, np.median(e[:, 0] - d[:, 0].min()), np.median(e[:, 7] - e[:, 4]), np.median(e[:, 5] - e[:, 0])))
     print("          launch: first start to last end %.1f us" % (d[:, 5].max() - d[:, 0].min()))
-gl = len(pts) // 4096 + 1
+gl = len(pts) // 2048 + 1   # k_leaf_tile: one workgroup per block row of 2048 leaves
 nlt = (gl + (gl + 1023) // 1024 - 1) // ((gl + 1023) // 1024)
 x = t[5, :nlt, :7]
 rel = (x - x[:, 0].min()) / 100.0
