@@ -990,7 +990,7 @@ __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30)
 // (two workgroup shapes, like k_sort_pass: 1024 threads x 4 keys for small grids, 512 x 8 -- two workgroups per CU, one
 // looks back while the other scans -- for the rest)
 template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
                                                             uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
