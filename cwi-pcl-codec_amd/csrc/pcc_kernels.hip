@@ -1507,6 +1507,44 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   PCC_KTR(5, 6);
 }
 
+// ---- the range coder's symbol counts of the occupancy stream ----
+// The static range coder starts with a histogram of its input (one more serial pass over ~1 MB on the host, an
+// eighth of the host stage); the bytes are final once k_leaf_tile is through, so the counts ride back inside the
+// FrameState for free.  Workgroup `wg` of `n_wgs`, the first `threads` threads of each (a multiple of 256 is not needed:
+// any count >= 256 works).  Runs as extra workgroups of k_jpeg_rows (both only need k_leaf_tile to be over) or, for
+// frames without a JPEG stage, as the launch k_occ_histogram.
+template <int THREADS>
+__device__ __forceinline__ void occ_histogram_block(FrameState* __restrict__ st, const uint8_t* __restrict__ occ, uint32_t wg, uint32_t n_wgs) {
+  __shared__ uint32_t s_h[4][256];  // four copies: runs of equal bytes do not pile up on one LDS word
+  if (st->error != kErrNone || st->n_epochs == 0) return;
+  for (int k = threadIdx.x; k < 4 * 256; k += THREADS) (&s_h[0][0])[k] = 0u;
+  __syncthreads();
+  const uint32_t B = st->n_branches;
+  const uint32_t vec = B / 16u;
+  const uint4* v = reinterpret_cast<const uint4*>(occ);
+  const int copy = threadIdx.x & 3;
+  for (uint32_t i = wg * THREADS + threadIdx.x; i < vec; i += n_wgs * THREADS) {
+    const uint4 q = v[i];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&s_h[copy][w[k] & 0xffu], 1u); atomicAdd(&s_h[copy][(w[k] >> 8) & 0xffu], 1u);
+      atomicAdd(&s_h[copy][(w[k] >> 16) & 0xffu], 1u); atomicAdd(&s_h[copy][w[k] >> 24], 1u);
+    }
+  }
+  if (wg == 0)  // the tail
+    for (uint32_t i = vec * 16u + threadIdx.x; i < B; i += THREADS) atomicAdd(&s_h[0][occ[i]], 1u);
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const uint32_t c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
+    if (c) atomicAdd(&st->occ_hist[threadIdx.x], c);
+  }
+}
+__global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ st, const uint8_t* __restrict__ occ, unsigned long long* span) {
+  const KSpan kspan(span);
+  occ_histogram_block<256>(st, occ, blockIdx.x, gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------
 // Stage 6: one workgroup per MCU ROW (16 image rows) of the snake-mapped image: libjpeg's front end on it
 // (jpeg_io.hpp:259-314: RGB->YCbCr, h2v2 downsample, islow FDCT, quantisation) -> 96 blocks of 64 zigzag-ordered
@@ -1515,10 +1553,15 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
 // ------------------------------------------------------------------------------------------
 constexpr int kJpegThreads = 768;  // thread = (8x8 block, line) in the FDCT; 12 waves x 8 blocks in the Huffman stage
 
-__global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(const FrameState* __restrict__ st, const uint8_t* __restrict__ image,
+__global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(FrameState* st, const uint8_t* __restrict__ image,
                                                             JpegQuant jq, int16_t* __restrict__ coefs, uint32_t* __restrict__ jpeg_tiles,
-                                                            const JpegHuffTables* __restrict__ huff, unsigned long long* span) {
+                                                            const JpegHuffTables* __restrict__ huff, uint32_t n_row_wgs, const uint8_t* __restrict__ occ,
+                                                            unsigned long long* span) {
   const KSpan kspan(span);
+  if (blockIdx.x >= n_row_wgs) {  // the workgroups behind the MCU rows count the occupancy bytes (see occ_histogram_block)
+    occ_histogram_block<kJpegThreads>(st, occ, blockIdx.x - n_row_wgs, gridDim.x - n_row_wgs);
+    return;
+  }
   const uint32_t L = st->n_leaves;
   if (L == 0 || st->error != kErrNone) return;
   const uint32_t H = L / 256u + 1u;  // jpegcc.h:194-198; the image is 256 pixels wide
@@ -1944,35 +1987,6 @@ size_t sync_area_bytes(uint32_t n, int passes) {
   return b;
 }
 
-// ---- k_occ_histogram: the range coder's symbol counts of the occupancy stream ----
-// The static range coder starts with a histogram of its input (one more serial pass over ~1 MB on the host, an
-// eighth of the host stage); the bytes are final here, so the counts ride back inside the FrameState for free.
-__global__ __launch_bounds__(256) void k_occ_histogram(FrameState* __restrict__ st, const uint8_t* __restrict__ occ, unsigned long long* span) {
-  const KSpan kspan(span);
-  __shared__ uint32_t s_h[4][256];  // four copies: runs of equal bytes do not pile up on one LDS word
-  if (st->error != kErrNone || st->n_epochs == 0) return;
-  for (int k = threadIdx.x; k < 4 * 256; k += 256) (&s_h[0][0])[k] = 0u;
-  __syncthreads();
-  const uint32_t B = st->n_branches;
-  const uint32_t vec = B / 16u;
-  const uint4* v = reinterpret_cast<const uint4*>(occ);
-  const int copy = threadIdx.x & 3;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < vec; i += gridDim.x * 256u) {
-    const uint4 q = v[i];
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      atomicAdd(&s_h[copy][w[k] & 0xffu], 1u); atomicAdd(&s_h[copy][(w[k] >> 8) & 0xffu], 1u);
-      atomicAdd(&s_h[copy][(w[k] >> 16) & 0xffu], 1u); atomicAdd(&s_h[copy][w[k] >> 24], 1u);
-    }
-  }
-  if (blockIdx.x == 0)  // the tail
-    for (uint32_t i = vec * 16u + threadIdx.x; i < B; i += 256u) atomicAdd(&s_h[0][occ[i]], 1u);
-  __syncthreads();
-  const uint32_t c = s_h[0][threadIdx.x] + s_h[1][threadIdx.x] + s_h[2][threadIdx.x] + s_h[3][threadIdx.x];
-  if (c) atomicAdd(&st->occ_hist[threadIdx.x], c);
-}
-
 // developer aid: what the runtime thinks of the kernels' residency (workgroups per CU, registers, LDS)
 extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   std::string out;
@@ -2067,9 +2081,15 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
                      reinterpret_cast<float4*>(a.simplified), span("k_leaf_tile"));
   PCC_STAMP("k_leaf_tile");
+  // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64 x 256 threads
+  const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));
+  bool counted = a.lp.simplify_only != 0;  // (the simplified cloud alone: no stream, nothing to count)
   if (a.lp.write_image && a.coefs && a.image) {
-    hipLaunchKernelGGL(k_jpeg_rows, dim3((max_h + 15u) / 16u), dim3(kJpegThreads), 0, stream, a.state, a.image, a.jq, a.coefs, a.jpeg_tiles, a.huff, span("k_jpeg_rows"));
+    const uint32_t row_wgs = (max_h + 15u) / 16u, extra = counted ? 0u : (hist_wgs + 2u) / 3u;  // 768 threads each instead of 256
+    hipLaunchKernelGGL(k_jpeg_rows, dim3(row_wgs + extra), dim3(kJpegThreads), 0, stream, a.state, a.image, a.jq, a.coefs, a.jpeg_tiles, a.huff, row_wgs,
+                       a.occ, span("k_jpeg_rows"));
     PCC_STAMP("k_jpeg_rows");
+    counted = true;
   }
   if (a.jpeg_lines_dir) {
     const uint32_t max_lines = std::max(1u, n / 2048u);
@@ -2077,9 +2097,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                        a.jpeg_lines_capacity, span("k_jpeg_lines"));
     PCC_STAMP("k_jpeg_lines");
   }
-  if (!a.lp.simplify_only) {
-    // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64
-    const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));
+  if (!counted) {
     hipLaunchKernelGGL(k_occ_histogram, dim3(hist_wgs), dim3(256), 0, stream, a.state, a.occ, span("k_occ_histogram"));
     PCC_STAMP("k_occ_histogram");
   }
