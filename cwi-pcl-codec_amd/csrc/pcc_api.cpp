@@ -57,7 +57,7 @@ struct PinnedBuf {  // grow-only page-locked host allocation (D2H landing zone)
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
-    const size_t want = std::max(count, (size_t)4096);
+    const size_t want = std::max(count, (4096 + sizeof(T) - 1) / sizeof(T));  // at least a page (not 4096 elements: a FrameState is 3 KB)
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
     return e;

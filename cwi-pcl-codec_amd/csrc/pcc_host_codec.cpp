@@ -1173,6 +1173,21 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
     for (int k = 0; k < m; ++k) got[idx[k]] = g2[k];
   };
 
+  // One or two frames leave coder slots free (four streams share a loop, and one coder alone uses a fraction of a
+  // core): their colour streams ride along with their occupancy streams instead of waiting for them -- a lone frame's
+  // stage 3.3 -> 2.9 ms.  The colour stream is coded into a buffer of its own and appended where it belongs.
+  const bool ride_along = 2 * n <= kMax;
+  Bytes payload[kMax], colour_rc[kMax];
+  uint64_t colour_got[kMax] = {0, 0, 0, 0};
+  size_t colour_len[kMax] = {0, 0, 0, 0};
+  const uint8_t* colour_src[kMax] = {nullptr, nullptr, nullptr, nullptr};
+  Clock::time_point t0 = Clock::now();
+  if (ride_along) {
+    for (int i = 0; i < n; ++i)
+      if (prm[i]->do_color_encoding != 0) colour_payload(*hot[i], *prm[i], payload[i], colour_src[i], colour_len[i]);
+    t_jpeg = us_since(t0);
+  }
+
   // --- header, occupancy bytes (impl.hpp:1692-1697) ---
   for (int i = 0; i < n; ++i) {
     write_frame_header(*hot[i], *prm[i], *out[i]);
@@ -1180,8 +1195,25 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
     use[i] = true; src[i] = hot[i]->occupancy; len[i] = (size_t)hot[i]->n_branches;
     cnt[i] = hot[i]->occupancy_histogram;
   }
-  Clock::time_point t0 = Clock::now();
-  stage();
+  t0 = Clock::now();
+  if (ride_along) {
+    const uint8_t* s2[kMax];
+    size_t l2[kMax], g2[kMax];
+    Bytes* o2[kMax];
+    const uint32_t* c2[kMax];
+    int m = 0, col_slot[kMax];
+    for (int i = 0; i < n; ++i) { s2[m] = hot[i]->occupancy; l2[m] = (size_t)hot[i]->n_branches; o2[m] = out[i]; c2[m] = hot[i]->occupancy_histogram; ++m; }
+    for (int i = 0; i < n; ++i) {
+      col_slot[i] = -1;
+      if (prm[i]->do_color_encoding != 0) {
+        col_slot[i] = m; s2[m] = colour_src[i]; l2[m] = colour_len[i]; o2[m] = &colour_rc[i]; c2[m] = nullptr; ++m;
+      }
+    }
+    StaticRangeCoder::encode_many(m, s2, l2, o2, g2, c2);
+    for (int i = 0; i < n; ++i) { got[i] = g2[i]; if (col_slot[i] >= 0) colour_got[i] = g2[col_slot[i]]; }
+  } else {
+    stage();
+  }
   t_occ = us_since(t0);
   for (int i = 0; i < n; ++i) cnt[i] = nullptr;
   for (int i = 0; i < n; ++i) perf[i][0] = got[i];
@@ -1198,19 +1230,29 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
   for (int i = 0; i < n; ++i) perf[i][1] = got[i];
 
   // --- colour (impl.hpp:1713-1723) ---
-  Bytes payload[kMax];
-  t0 = Clock::now();
-  for (int i = 0; i < n; ++i) {
-    use[i] = prm[i]->do_color_encoding != 0;
-    if (use[i]) {
-      colour_payload(*hot[i], *prm[i], payload[i], src[i], len[i]);
-      put_le<uint64_t>(*out[i], (uint64_t)len[i]);
+  if (ride_along) {  // coded above, next to the occupancy bytes
+    for (int i = 0; i < n; ++i) {
+      got[i] = 0;
+      if (prm[i]->do_color_encoding != 0) {
+        put_le<uint64_t>(*out[i], (uint64_t)colour_len[i]);
+        out[i]->insert(out[i]->end(), colour_rc[i].begin(), colour_rc[i].end());
+        got[i] = colour_got[i];
+      }
     }
+  } else {
+    t0 = Clock::now();
+    for (int i = 0; i < n; ++i) {
+      use[i] = prm[i]->do_color_encoding != 0;
+      if (use[i]) {
+        colour_payload(*hot[i], *prm[i], payload[i], src[i], len[i]);
+        put_le<uint64_t>(*out[i], (uint64_t)len[i]);
+      }
+    }
+    t_jpeg = us_since(t0);
+    t0 = Clock::now();
+    stage();
+    t_col = us_since(t0);
   }
-  t_jpeg = us_since(t0);
-  t0 = Clock::now();
-  stage();
-  t_col = us_since(t0);
   for (int i = 0; i < n; ++i) perf[i][2] = got[i];
 
   const double total = us_since(t_begin);
