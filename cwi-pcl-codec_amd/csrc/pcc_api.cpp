@@ -687,7 +687,7 @@ int pcc_reserve(pcc_ctx* ctx, size_t max_points, size_t bitstream_bytes) {
     if (rc != PCC_OK) return rc;
     // landing buffers of the usual products (occupancy bytes: about one per point for surfaces; more is fetched on demand)
     const size_t had = ctx->h_occ.cap;
-    PCC_HIP(ctx->h_occ.ensure(tiles_region(max_points) + std::max(max_points + max_points / 4, 2 * bitstream_bytes) + 16));
+    PCC_HIP(ctx->h_occ.ensure(tiles_region(max_points) + std::max(2 * max_points, 2 * bitstream_bytes) + 16));
     if (ctx->h_occ.cap != had) {
       // The FIRST device-to-host copy into a fresh page-locked buffer costs the calling thread 2-7 ms (measured with
       // PCC_FINISH_TRACE: the runtime maps the buffer for the copy engine then); it belongs here, not into the first
@@ -767,7 +767,9 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
 
   const size_t off = ctx->out_off;
   const bool tiles_too = image && ctx->jpeg_on_gpu >= 2;  // records + occupancy bytes in one copy
-  PCC_HIP(ctx->h_occ.ensure(off + B + 16));
+  // (two bytes per point even if this frame needs fewer: the buffer then survives pcc_reserve and the other frames of a
+  // sequence -- freeing and re-allocating page-locked memory in the middle of a sequence is what makes later copies slow)
+  PCC_HIP(ctx->h_occ.ensure(off + std::max<size_t>(B, 2 * ctx->n) + 16));
   if (tiles_too) PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, off + B, hipMemcpyDeviceToHost, ctx->stream));
   else PCC_HIP(hipMemcpyAsync(ctx->h_occ.p + off, ctx->d_occ.p + off, B, hipMemcpyDeviceToHost, ctx->stream));
   const uint32_t* h_tiles = reinterpret_cast<const uint32_t*>(ctx->h_occ.p);
