@@ -686,12 +686,17 @@ int pcc_reserve(pcc_ctx* ctx, size_t max_points, size_t bitstream_bytes) {
     const int rc = reserve(ctx, max_points);
     if (rc != PCC_OK) return rc;
     // landing buffers of the usual products (occupancy bytes: about one per point for surfaces; more is fetched on demand)
-    const size_t had = ctx->h_occ.cap;
     PCC_HIP(ctx->h_occ.ensure(tiles_region(max_points) + std::max(2 * max_points, 2 * bitstream_bytes) + 16));
-    if (ctx->h_occ.cap != had) {
-      // The FIRST device-to-host copy into a fresh page-locked buffer costs the calling thread 2-7 ms (measured with
-      // PCC_FINISH_TRACE: the runtime maps the buffer for the copy engine then); it belongs here, not into the first
-      // frame that lands in the buffer.
+    {
+      // A device-to-host copy into the landing buffer, here and now, behind a device-wide synchronisation.
+      // hipMemcpyAsync into a page-locked buffer sometimes costs the calling thread 2-15 ms of CPU (PCC_FINISH_TRACE shows
+      // it as "copies enqueued"): always the first copy into a fresh buffer -- but whole short sequences also ran at half
+      // speed with buffers that had been copied into before, unless the runtime had been through a hipDeviceSynchronize
+      // (or a hipHostFree, which implies one) since the sequences before (tools/bench20.sh, 20-frame calls after a
+      // 92-frame warm-up: 15 of 17 calls at 900-1 600 Mpoints/s without it, 0 of 24 with it; event queries, stream
+      // queries and stream synchronisations do not have that effect).  A reservation is where a caller prepares a
+      // sequence, the GPU is idle, and the synchronisation costs nothing.
+      PCC_HIP(hipDeviceSynchronize());
       const size_t bytes = std::min(ctx->h_occ.cap, ctx->d_occ.cap);
       PCC_HIP(hipMemcpyAsync(ctx->h_occ.p, ctx->d_occ.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
       PCC_HIP(hipStreamSynchronize(ctx->stream));
