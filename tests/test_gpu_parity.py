@@ -433,6 +433,28 @@ def test_jpeg_huffman_rows_that_do_not_fit_fall_back_to_coefficients(pkg, oracle
     assert stream == want.bitstream
 
 
+@pytest.mark.parametrize("color_coding_type,keep_centroid", [(1, 0), (1, 1), (0, 1), (2, 0)])
+def test_short_calls_of_every_length(pkg, oracle, color_coding_type, keep_centroid):
+    """Calls of 1..6 frames on two entropy threads: the batch of a coder loop follows what is left of the call (4, 3, 2, 1
+    frames in one loop), and with one or two frames in a loop the colour streams are coded next to the occupancy
+    streams -- with and without a centroid stream in between, for every colour coding -- the bitstreams must stay
+    those of the serial loop."""
+    b = pkg.binding
+    sizes = [21_000, 3_000, 30_500, 8_191, 12_000, 26_000]
+    frames = [pkg.synthetic.sphere_shell(n, 0xA00 + i) for i, n in enumerate(sizes)]
+    kw = dict(octree_bits=8, color_coding_type=color_coding_type, jpeg_quality=75, keep_centroid=keep_centroid)
+    pipe = b.Pipeline(0, workers=2)
+    ctx = pipe.context(0)
+    devs = [ctx.upload(f) for f in frames]
+    for count in range(1, len(frames) + 1):
+        want = [oracle.encode_intra(f, oracle.make_params(frame_id=5 + i, **kw), keep=False).bitstream for i, f in enumerate(frames[:count])]
+        got = pipe.encode(devs[:count], sizes[:count], b.make_params(frame_id=5, **kw))
+        assert [g[0] for g in got] == want, count
+    for d in devs:
+        ctx.free(d)
+    pipe.close()
+
+
 def test_pipeline_gives_the_serial_loop_bitstreams(pkg, oracle):
     """pcc_pipeline_encode: frames of different sizes in flight on several contexts, host stage for up to four
     frames at once -- the bitstreams must be those of the reference's serial frame loop; a dropped frame (all
