@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pcc_codec.h"
@@ -1128,15 +1129,24 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     if (out->depth > (uint32_t)kMaxDepth || L >= (1ull << 31) || L == 0) host_only = true;
     if (!host_only && out->params.do_voxel_centroid && fs.cen.size() < 3 * L) host_only = true;
     if (!host_only && fs.with_color && !jpeg && fs.col.size() < 3 * L) host_only = true;
-    if (!host_only && jpeg) {
-      if (!BaselineJpeg::decode_coefs(fs.payload.data(), fs.payload.size(), img_w, img_h, ctx->dec_coefs) || img_w % 8 != 0 ||
-          (size_t)img_w * (size_t)img_h < L)
-        host_only = true;
-    }
-    if (!host_only) {
-      rc = walk_leaf_parents(fs.occ, out->depth, fs.count, lp);
-      if (rc != PCC_OK) return fail(ctx, rc, "decode: occupancy stream does not describe the announced number of voxels");
-    }
+    // the JPEG's Huffman decoding and the walk over the occupancy stream are both sequential, but not on each other:
+    // they run side by side (a second thread for the time of the call)
+    bool jpeg_ok = true, jpeg_oom = false;
+    std::thread jpeg_thread;
+    if (!host_only && jpeg)
+      jpeg_thread = std::thread([&] {
+        try {
+          jpeg_ok = BaselineJpeg::decode_coefs(fs.payload.data(), fs.payload.size(), img_w, img_h, ctx->dec_coefs);
+        } catch (const std::bad_alloc&) {
+          jpeg_ok = false;
+          jpeg_oom = true;
+        }
+      });
+    if (!host_only) rc = walk_leaf_parents(fs.occ, out->depth, fs.count, lp);
+    if (jpeg_thread.joinable()) jpeg_thread.join();
+    if (jpeg_oom) throw std::bad_alloc();
+    if (!host_only && rc != PCC_OK) return fail(ctx, rc, "decode: occupancy stream does not describe the announced number of voxels");
+    if (!host_only && jpeg && (!jpeg_ok || img_w % 8 != 0 || (size_t)img_w * (size_t)img_h < L)) host_only = true;
     if (host_only) {
       rc = decode_frame(stream, len, ctx->dec_points, *out);
       out->points = ctx->dec_points.data();

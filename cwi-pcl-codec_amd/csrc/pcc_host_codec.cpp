@@ -266,8 +266,9 @@ size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, 
       if (freq[sy + 1] > freq[sy]) memset(lut.data() + freq[sy], (int)sy, freq[sy + 1] - freq[sy]);
   }
   const uint8_t* const table = lut.empty() ? nullptr : lut.data();
+  const InvariantDiv32 by_total(total >= 2 ? total : 2);  // the same divisor for every symbol: a multiply instead of a divide
   for (size_t i = 0; i < n; ++i) {
-    range /= total;
+    range = total >= 2 ? by_total.div(range) : range / total;
     if (range == 0) return 0;  // corrupt table: PCL would divide by zero here
     const uint32_t count = (code - low) / range;
     unsigned sym = 0;
