@@ -56,6 +56,7 @@ struct Ready {  // a context whose GPU stage is done
   size_t frame;
   pcc_params prm;
   pcc_hot_result hot;
+  Clock::time_point since;  // when it joined the ready queue
 };
 }  // namespace
 
@@ -70,6 +71,12 @@ struct pcc_pipeline {
   int gpu_batch = 256;
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
+  // developer aid (PCC_PIPELINE_TRACE=1): when each frame of a call left the GPU stage, when its coder loop started and ended,
+  // how many frames shared the loop (microseconds since the call started; printed to stderr for calls of up to 64 frames)
+  struct FrameTrace { double launched = 0, gpu_done = 0, ent_start = 0, ent_end = 0; int batch = 0, thread = -1; };
+  std::vector<FrameTrace> trace;
+  Clock::time_point job_t0;
+  bool tracing = false;
   size_t taken = 0;  // frames of the job at hand that entropy threads have taken so far
   // How many frames the next entropy thread should code in one loop.  Four coders in one loop use the least CPU per frame
   // (1.3 ms against 3.3 ms for one alone) but the frames come out later: right while the frames outnumber the threads,
@@ -170,6 +177,7 @@ struct pcc_pipeline {
         r.prm = job.params;
         r.prm.frame_id = job.params.frame_id + (uint32_t)r.frame;  // frame_ID_ by sequence index
         Clock::time_point t0 = Clock::now();
+        if (tracing) trace[r.frame].launched = us_since(job_t0);
         double c0 = thread_cpu_us();
         int rc = job.host_input
                      ? pcc_hotpath_launch_host(r.ctx, lane, job.frames[r.frame], job.counts[r.frame], job.stride, job.rgb_offset, &r.prm)
@@ -196,18 +204,21 @@ struct pcc_pipeline {
           ++k_frames;
         }
         note_error(r.ctx, rc);
+        if (tracing) trace[r.frame].gpu_done = us_since(job_t0);
         bool wake_one = false, wake_all = false;
         {
           std::lock_guard<std::mutex> lk(mu);
           status[r.frame] = rc;
           ++gpu_done;
           if (rc == PCC_OK && job.mode == 0) {
+            r.since = Clock::now();
             ready.push_back(r);
           } else {  // nothing for the host stage to do: the context is free again
             free_ctx.push_back(r.ctx);
             cv_free.notify_one();
           }
-          wake_one = ready.size() >= batch_wanted();  // a full batch is waiting: one entropy thread is enough
+          // a full batch is waiting: one entropy thread is enough (short calls: somebody has to start the frame's clock)
+          wake_one = ready.size() >= batch_wanted() || (job.n_frames <= 4 * (size_t)n_entropy && job.mode == 0);
           wake_all = gpu_done >= job.n_frames;
         }
         if (wake_all) cv_ready.notify_all();
@@ -307,7 +318,20 @@ struct pcc_pipeline {
           std::unique_lock<std::mutex> lk(mu);
           // Four frames in one coder loop cost 1.5 ms of CPU per frame, one frame alone 3.3 ms (tools/rc_speed.py), and
           // the CPU is what limits the pipeline: wait for a full batch unless the GPU stage has nothing more to give.
-          cv_ready.wait(lk, [&] { return ready.size() >= batch_wanted() || gpu_done >= job.n_frames; });
+          // Short calls: a frame does not sit in the queue for long just because the thread would like a larger batch -- the
+          // frames of a short call trickle out of the GPU stage 100-400 us apart, and a loop that waits for its third
+          // frame ends last (PCC_PIPELINE_TRACE: 20 frames, the triple that waited 430 us finished 400 us behind everybody else).
+          const bool impatient = job.n_frames <= 4 * (size_t)n_entropy;
+          auto enough = [&] { return ready.size() >= batch_wanted() || gpu_done >= job.n_frames; };
+          while (!enough()) {
+            if (impatient && !ready.empty()) {
+              const Clock::time_point deadline = ready.front().since + std::chrono::microseconds(150);
+              if (Clock::now() >= deadline) break;
+              cv_ready.wait_until(lk, deadline);
+            } else {
+              cv_ready.wait(lk);
+            }
+          }
           const size_t want = batch_wanted();
           while (nr < kAtOnce && (size_t)nr < want && !ready.empty()) { r[nr++] = ready.front(); ready.pop_front(); }
           if (nr == 0) break;  // every frame went through the GPU stage and the queue is empty
@@ -324,7 +348,9 @@ struct pcc_pipeline {
         for (int i = 0; i < nr; ++i) { c[i] = r[i].ctx; h[i] = &r[i].hot; pp[i] = &r[i].prm; o[i] = &bs[i]; }
         Clock::time_point t0 = Clock::now();
         const double c0 = thread_cpu_us();
+        if (tracing) for (int i = 0; i < nr; ++i) { trace[r[i].frame].ent_start = us_since(job_t0); trace[r[i].frame].batch = nr; trace[r[i].frame].thread = index; }
         const int rc_all = pcc_entropy_encode_many(nr, c, h, pp, o);
+        if (tracing) for (int i = 0; i < nr; ++i) trace[r[i].frame].ent_end = us_since(job_t0);
         for (int i = 0; i < nr; ++i) rc[i] = rc_all;
         te += us_since(t0);
         ce += thread_cpu_us() - c0;
@@ -506,6 +532,12 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     if (mode == 0 && p->seen_max_len) p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63));
     p->arena_used = 0;
     p->taken = 0;
+    {
+      static const bool want = [] { const char* e = getenv("PCC_PIPELINE_TRACE"); return e && e[0] == '1'; }();
+      p->tracing = want && mode == 0 && n_frames <= 64;
+      if (p->tracing) p->trace.assign(n_frames, pcc_pipeline::FrameTrace());
+      p->job_t0 = Clock::now();
+    }
     p->results.assign(n_frames, pcc_bitstream());
     p->status.assign(n_frames, PCC_OK);
     p->err.clear();
@@ -525,6 +557,14 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
   {
     std::unique_lock<std::mutex> lk(p->mu);
     p->cv_done.wait(lk, [&] { return p->busy == 0; });
+  }
+  if (p->tracing) {
+    fprintf(stderr, "[pcc_pipeline] call of %zu frames done after %.0f us\n", n_frames, us_since(p->job_t0));
+    for (size_t f = 0; f < n_frames; ++f) {
+      const pcc_pipeline::FrameTrace& t = p->trace[f];
+      fprintf(stderr, "  frame %2zu: launched %6.0f  left the GPU stage %6.0f  coder loop %6.0f .. %6.0f  (%d in the loop, entropy thread %d)\n", f, t.launched,
+              t.gpu_done, t.ent_start, t.ent_end, t.batch, t.thread);
+    }
   }
   // frame_ID_ is only incremented for frames that are not dropped (impl.hpp:133 vs :206-212): renumber the
   // headers in sequence order (u32 behind the two 28 + 20 byte identifiers)
