@@ -182,9 +182,11 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
+    t_call = time.perf_counter()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    trace("timed region: the call %.3f ms, the synchronisation behind it %.3f ms" % (1e3 * (t_call - t0), 1e3 * (t1 - t_call)))
     trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
     ktimes, profiled = pipe.kernel_times()

@@ -73,7 +73,7 @@ struct pcc_pipeline {
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
   // developer aid (PCC_PIPELINE_TRACE=1): when each frame of a call left the GPU stage, when its coder loop started and ended,
   // how many frames shared the loop (microseconds since the call started; printed to stderr for calls of up to 64 frames)
-  struct FrameTrace { double launched = 0, gpu_done = 0, ent_start = 0, ent_end = 0; int batch = 0, thread = -1; };
+  struct FrameTrace { double launched = 0, gpu_done = 0, ent_start = 0, ent_end = 0, stored = 0; int batch = 0, thread = -1; };
   std::vector<FrameTrace> trace;
   Clock::time_point job_t0;
   bool tracing = false;
@@ -116,7 +116,11 @@ struct pcc_pipeline {
     if (bytes <= arena_cap) return true;
     uint8_t* q = static_cast<uint8_t*>(malloc(bytes));
     if (!q) return false;
-    memset(q, 0, bytes);  // first touch here, not inside the frame loop
+    // first touch here, not inside the frame loop.  (Not memset(q, 0, ...): the compiler folds malloc + memset-to-zero into
+    // calloc, whose pages are only mapped when they are written -- 200 page faults per 820 KB bitstream, 0.35 ms of every
+    // frame's entropy thread, seen with PCC_PIPELINE_TRACE as the time between "coder loop" and "stored".  Streaming
+    // stores for the copy itself were tried as well: slower, the coder loops on the other hardware threads suffer.)
+    for (size_t k = 0; k < bytes; k += 4096) static_cast<volatile uint8_t*>(q)[k] = 1;
     free(arena);
     arena = q;
     arena_cap = bytes;
@@ -150,8 +154,14 @@ struct pcc_pipeline {
     seen = generation;
     return true;
   }
-  void job_done() {
+  double t_last_thread = 0;  // (trace) when the last thread left the job, and which one it was (GPU-stage threads first)
+  int last_thread = -1;
+  void job_done(int who = -1) {
     std::lock_guard<std::mutex> lk(mu);
+    if (tracing) {
+      const double t = us_since(job_t0);
+      if (t > t_last_thread) { t_last_thread = t; last_thread = who; }
+    }
     if (--busy == 0) cv_done.notify_all();
   }
 
@@ -161,7 +171,7 @@ struct pcc_pipeline {
       // A frame that comes from host memory spends most of its time waiting for its turn on the PCIe link (and, if
       // its memory is pageable, in the page-locking call): more threads keep the link busy.  With the frames in HBM
       // the extra frames in flight only get in each other's way on the GPU.
-      if (!job.host_input && index >= n_gpu_device) { job_done(); continue; }
+      if (!job.host_input && index >= n_gpu_device) { job_done(index); continue; }
       double tl = 0, tf = 0, cl = 0, cf = 0;
       for (;;) {
         Ready r;
@@ -230,7 +240,7 @@ struct pcc_pipeline {
         cpu_launch += cl; cpu_finish += cf;
       }
       cv_ready.notify_all();
-      job_done();
+      job_done(index);
     }
   }
 
@@ -372,6 +382,7 @@ struct pcc_pipeline {
             }
           }
           note_error(r[i].ctx, rc[i]);
+          if (tracing) trace[r[i].frame].stored = us_since(job_t0);
           ++done;
         }
         {
@@ -390,7 +401,7 @@ struct pcc_pipeline {
         for (int i = 0; i < 4; ++i) host_us[i] += hu[i];
         frames_done += done;
       }
-      job_done();
+      job_done(1000 + index);
     }
   }
 };
@@ -536,6 +547,7 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
       static const bool want = [] { const char* e = getenv("PCC_PIPELINE_TRACE"); return e && e[0] == '1'; }();
       p->tracing = want && mode == 0 && n_frames <= 64;
       if (p->tracing) p->trace.assign(n_frames, pcc_pipeline::FrameTrace());
+      p->t_last_thread = 0;
       p->job_t0 = Clock::now();
     }
     p->results.assign(n_frames, pcc_bitstream());
@@ -559,11 +571,11 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->cv_done.wait(lk, [&] { return p->busy == 0; });
   }
   if (p->tracing) {
-    fprintf(stderr, "[pcc_pipeline] call of %zu frames done after %.0f us\n", n_frames, us_since(p->job_t0));
+    fprintf(stderr, "[pcc_pipeline] call of %zu frames done after %.0f us (the last thread, %d, left the job at %.0f us)\n", n_frames, us_since(p->job_t0), p->last_thread, p->t_last_thread);
     for (size_t f = 0; f < n_frames; ++f) {
       const pcc_pipeline::FrameTrace& t = p->trace[f];
-      fprintf(stderr, "  frame %2zu: launched %6.0f  left the GPU stage %6.0f  coder loop %6.0f .. %6.0f  (%d in the loop, entropy thread %d)\n", f, t.launched,
-              t.gpu_done, t.ent_start, t.ent_end, t.batch, t.thread);
+      fprintf(stderr, "  frame %2zu: launched %6.0f  left the GPU stage %6.0f  coder loop %6.0f .. %6.0f, stored %6.0f  (%d in the loop, entropy thread %d)\n", f, t.launched,
+              t.gpu_done, t.ent_start, t.ent_end, t.stored, t.batch, t.thread);
     }
   }
   // frame_ID_ is only incremented for frames that are not dropped (impl.hpp:133 vs :206-212): renumber the
