@@ -180,13 +180,18 @@ def main():
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
     trace("warm-up done")
     sync_all()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
     t_call = time.perf_counter()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    trace("timed region: the call %.3f ms, the synchronisation behind it %.3f ms" % (1e3 * (t_call - t0), 1e3 * (t1 - t_call)))
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    trace("timed region: the call %.3f ms, the synchronisation behind it %.3f ms; CPU user %.1f ms, system %.1f ms, %d minor page faults, "
+          "%d + %d context switches" % (1e3 * (t_call - t0), 1e3 * (t1 - t_call), 1e3 * (ru1.ru_utime - ru0.ru_utime), 1e3 * (ru1.ru_stime - ru0.ru_stime),
+                                       ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
     trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
     ktimes, profiled = pipe.kernel_times()
