@@ -28,6 +28,8 @@ the last kernel of a frame without any events in between.
 import argparse
 import json
 import os
+import resource   # (at the top on purpose: a module imported -- a shared object loaded -- while the pipeline's threads exist
+                  #  costs the run a quarter of its throughput, see main())
 import sys
 import time
 
@@ -180,7 +182,10 @@ def main():
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
     trace("warm-up done")
     sync_all()
-    import resource
+    # Nothing may be imported from here to the end of the timed region.  Measured: `import resource` at this point -- the
+    # dlopen of a small extension module -- took the 1024-frame run from 8 500 to 6 300 Mpoints/s.  glibc 2.35 sends every
+    # access to a thread-local variable of a dlopen-ed library (the HIP runtime and libpcc_hip.so are loaded that way by
+    # ctypes / torch) through the slow path of __tls_get_addr once a later dlopen has bumped the TLS generation counter.
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
