@@ -318,6 +318,11 @@ def test_pair_sort_mode_matches_packed_mode(pkg, oracle, monkeypatch):
         xyz = np.repeat(xyz, 2, axis=0)[rng.permutation(140000)]
         for kw in (dict(octree_bits=9, color_coding_type=1), dict(octree_bits=7, color_coding_type=0, keep_centroid=1)):
             assert_matches_oracle(pkg, oracle, c, cloud(pkg, xyz), **kw)
+        # the same beyond 96 sort tiles, where sort pass and leaf scan run in their 512-thread shape (two workgroups per CU)
+        xyz = rng.uniform(0.1, 0.9, (210000, 3)).astype(np.float32)
+        xyz[rng.integers(0, 210000, 500)] = np.nan
+        xyz = np.repeat(xyz, 2, axis=0)[rng.permutation(420000)]
+        assert_matches_oracle(pkg, oracle, c, cloud(pkg, xyz), octree_bits=9, color_coding_type=1, keep_centroid=1)
     finally:
         c.close()
 
@@ -335,6 +340,19 @@ def test_cpp_shim_example_runs(pkg):
     assert "decoded voxels" in r.stdout
     # decodePointCloud consumes exactly one frame per call, from seekable and from forward-only streams
     assert "3 frames decoded one by one" in r.stdout
+
+
+def test_cpp_pipeline_bench_runs(pkg):
+    """The sequence interface of the C ABI from a C++ caller (pcc_pipeline_encode / _encode_host, no Python around it)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cwi-pcl-codec_amd", "shim", "examples", "pipeline_bench")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe)], check=True)
+    r = subprocess.run([exe, "60000", "48", "8", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("frames in HBM") == 3 and r.stdout.count("frames in host memory") == 2
 
 
 def test_next_frame_may_be_launched_before_the_entropy_stage(pkg, oracle):
