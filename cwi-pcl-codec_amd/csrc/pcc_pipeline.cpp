@@ -3,9 +3,10 @@
 //   GPU-stage threads   take a free context and the next frame, enqueue the kernels, sleep until the
 //                       occupancy stream / JPEG rows have landed in the context's pinned buffers, and hand
 //                       the context to the ready queue;
-//   entropy threads     take one or (preferably) two ready contexts and run the serial host stage (static
-//                       range coder, JPEG stitching); two frames share one loop (pcc_entropy_encode2), which
-//                       costs about the time of one.  Then the contexts go back to the free list.
+//   entropy threads     take a batch of ready contexts -- up to four; how many follows what is left of the call, see
+//                       batch_wanted() -- and run the serial host stage (static range coder, JPEG stitching) for all of
+//                       them in one loop (pcc_entropy_encode_many), which costs little more than one frame alone.  Then
+//                       the contexts go back to the free list.
 // So the GPU always has a few frames in flight, and every core that the host stage can get codes symbols.
 //
 // The reference encodes the frames of a sequence one after the other on one thread (eval.hpp:818-835).
