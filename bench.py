@@ -60,17 +60,18 @@ def parse():
 
 # must-move bytes of each kernel per launch, as a function of the frame ("Kernels")
 def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
-    pay = 4 if with_color else 0           # the colour word rides through the sort as payload
+    # no centroids in the bench workloads: the sort key is [code | colour] or the code alone, 8 bytes, no payload array
+    col = 4 if with_color else 0
     if name == "k_boxes_events":
         return 16 * n                      # x,y,z(,w) of every point (the replaying workgroup reads a chunk or two again)
     if name == "k_make_keys":
-        return (16 + pay) * n + (8 + pay) * n   # read xyz (+ colour word), write key (+ payload)
+        return (16 + col) * n + 8 * n      # read xyz (+ colour word), write key
     if name == "k_sort_pass":
-        return 2 * (8 + pay) * n           # read key + payload, write key + payload
+        return 2 * 8 * n                   # read keys, write keys
     if name == "k_leaf_scan":
         return 8 * n + 17 * L + B          # read keys; write start, code, base, t per leaf; zero the DFS stream
-    if name == "k_leaf_tile":              # leaf records, colour words; bgr, image rows, simplified cloud, DFS stream
-        return 17 * L + pay * n + (3 * L + image_bytes if with_color else 0) + 16 * L + B
+    if name == "k_leaf_tile":              # leaf records, keys (their colour bits); bgr, image rows, simplified cloud, DFS stream
+        return 17 * L + (8 * n + 3 * L + image_bytes if with_color else 0) + 16 * L + B
     if name == "k_jpeg_rows":              # image rows in; 1.5 int16 coefficients per pixel = 3 bytes per pixel out
         return 2 * image_bytes if with_color else 0
     return 0

@@ -542,6 +542,8 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
+    // '2': keep the point index in the key although nothing needs it (the packed [code | index] + colour payload sort)
+    a.need_index = (a.lp.do_centroid || stop_after_leaf_scan || (fp && fp[0] == '2')) ? 1 : 0;
   }
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;

@@ -7,9 +7,10 @@
 //   points      N x stride B   caller's pcl::PointXYZRGB array (x,y,z at 0, colour word at rgb_off)
 //   chunk_box   ceil(N/2048) x 32 B   per-chunk AABB + first finite index + finite count
 //   state       1 x FrameState  epochs of the adaptive bounding box, sort geometry, L, B
-//   keys[2]     N x u64         packed (morton | index) sort keys, ping-pong; ~0 marks a non-finite point
-//   idx[2]      N x u32         sort payload: the point's colour word (so that no random gather is needed after
-//                               the sort), or the point index in pairs mode (code + index bits > 64)
+//   keys[2]     N x u64         sort keys, ping-pong; ~0 marks a non-finite point.  [morton | colour] or the morton code
+//                               alone when nobody needs the point index (no centroids), else [morton | index]
+//   idx[2]      N x u32         sort payload, only with an index in the key: the point's colour word (so that no random
+//                               gather is needed after the sort), or the point index in pairs mode (code + index bits > 64)
 //   hist_rows   ceil(N/4096) x kMaxPasses x 512 x u32   per-tile digit counts of every pass (from k_make_keys)
 //   digit_tot   kMaxPasses x 512 x u32                  column sums of hist_rows
 //   status      kMaxPasses x (tiles + tiles/16) x 512 x u32   look-back words of the sort passes: per tile, per group of 16 tiles
@@ -76,6 +77,7 @@ struct FrameState {
   int32_t packed;                    // 1: [code|index] in one u64;  0: u64 code keys + u32 index payload
   int32_t payload;                   // what the u32 payload of the sort carries: 0 nothing, 1 point index (pairs
                                      // mode), 2 the point's colour word (packed mode with colour: no gather later)
+  int32_t colour_in_key;             // 1: the low 24 key bits (ibits = 24) are the point's colour, no payload, no index
   int32_t npasses;                   // radix passes actually needed (>= 1)
   int32_t pass_bits[kMaxPasses];     // digit width of each pass
   int32_t pass_shift[kMaxPasses];    // bit position of each digit inside the code (add ibits for the packed key)

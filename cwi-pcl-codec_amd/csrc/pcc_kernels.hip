@@ -272,7 +272,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int passes_launched, int do_color, FixedBox box,
+                                                         int force_pairs, int need_index, int passes_launched, int do_color, FixedBox box,
                                                          FrameState* __restrict__ st, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       if (threadIdx.x == 0) {
         st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
         st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0;
+        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0;
         st->passes_launched = passes_launched;
       }
       return;
@@ -560,9 +560,14 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       vb = max(vb, nb);
     }
     int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
-    // code + index in one u64 when they fit (8 B/key/pass); otherwise u64 code keys with a u32
-    // index payload (12 B/key/pass).  The stable sort makes both orders identical.
-    const int packed = (3 * vb + ibits <= 64 && !force_pairs) ? 1 : 0;
+    // Nothing downstream needs the point index unless centroids are coded or the caller wants the sorted points
+    // themselves (macroblock trees): the sort is stable, so equal codes keep their input order without it.  Then the
+    // key is the code alone, or [code | the point's 24 colour bits] -- 8 B per key and pass, no payload array.
+    // Otherwise code + index in one u64 when they fit (+ the colour word as a u32 payload: 12 B); otherwise u64 code
+    // keys with a u32 index payload (12 B).  All of them give the same order.
+    const bool bare = !need_index && !force_pairs && (!do_color || 3 * vb + 24 <= 63);
+    const int packed = (bare || (3 * vb + ibits <= 64 && !force_pairs)) ? 1 : 0;
+    if (bare) ibits = do_color ? 24 : 0;
     if (!packed) ibits = 0;
     // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
     const int vbits = 3 * vb;
@@ -589,7 +594,8 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->vbits = vbits;
       st->ibits = ibits;
       st->packed = packed;
-      st->payload = packed ? (do_color ? 2 : 0) : 1;
+      st->payload = bare ? 0 : (packed ? (do_color ? 2 : 0) : 1);
+      st->colour_in_key = (bare && do_color) ? 1 : 0;
       st->npasses = err != kErrNone ? 0 : np;
       st->error = err;
     }
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
   const int vb = st->vbits_axis, ibits = st->ibits;
   const bool packed_mode = st->packed != 0;
   const int payload = st->payload;
+  const bool colour_in_key = st->colour_in_key != 0;
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
   const uint32_t base = blockIdx.x * kSortTile;
   const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
@@ -654,7 +661,9 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
 #pragma unroll
       for (int p = 0; p < kMaxPasses; ++p)
         if (p < np) atomicAdd(&s_h[p][(uint32_t)(code >> pshift[p]) & pmask[p]], 1u);
-      key = packed_mode ? ((code << ibits) | (uint64_t)i) : code;
+      // low bits: the point index, or (nobody needs the index) the point's colour, or nothing
+      const uint64_t low = colour_in_key ? (uint64_t)(load_rgba(pv, i) & 0xffffffu) : (ibits ? (uint64_t)i : 0ull);
+      key = packed_mode ? ((code << ibits) | low) : code;
     }
     if (payload == 1) idx[i] = i;
     else if (payload == 2) idx[i] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
@@ -1134,11 +1143,13 @@ struct IndexOf {
 };
 
 // `colour_pay`: the sorted colour words themselves (payload 2), else they are gathered through the point index
+// (`colour_keys`: the colour sits in the low 24 bits of the sorted keys)
 __device__ __forceinline__ void leaf_colour(const PointView& pv, const IndexOf& index_of, const uint32_t* __restrict__ colour_pay,
+                                            const uint64_t* __restrict__ colour_keys,
                                             uint32_t s, uint32_t e, uint32_t red, uint32_t& b, uint32_t& g, uint32_t& r) {
   uint32_t s0 = 0, s1 = 0, s2 = 0;
   for (uint32_t i = s; i < e; ++i) {
-    const uint32_t w = colour_pay ? colour_pay[i] : load_rgba(pv, index_of(i));
+    const uint32_t w = colour_keys ? (uint32_t)colour_keys[i] : (colour_pay ? colour_pay[i] : load_rgba(pv, index_of(i)));
     s0 += w & 0xffu; s1 += (w >> 8) & 0xffu; s2 += (w >> 16) & 0xffu;
   }
   const uint32_t cnt = e - s;
@@ -1250,6 +1261,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   index_of.idx = st->payload == 1 ? pay_sorted : nullptr;
   index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
   const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
+  const uint64_t* colour_keys = st->colour_in_key ? keys : nullptr;
 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
   if (threadIdx.x < kMaxDepth + 2) s_slotbits[threadIdx.x] = 0ull;
@@ -1282,13 +1294,13 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   const uint32_t run1 = nl ? leaf_start[pos0 + nl] : 0u;
   const uint64_t code0 = (nl && pos0) ? leaf_code[pos0] : 0ull;
   for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
-  const bool staged = colour_pay != nullptr && lp.do_color;
+  const bool staged = (colour_pay != nullptr || colour_keys != nullptr) && lp.do_color;
   const uint32_t ncol = staged ? min(run1 - run0, (uint32_t)kColourStage) : 0u;
   uint32_t colreg[kColourStage / kFinThreads];
 #pragma unroll
   for (int q = 0; q < kColourStage / kFinThreads; ++q) {
     const uint32_t k = threadIdx.x + (uint32_t)q * kFinThreads;
-    colreg[q] = k < ncol ? colour_pay[run0 + k] : 0u;
+    colreg[q] = k < ncol ? (colour_keys ? (uint32_t)colour_keys[run0 + k] : colour_pay[run0 + k]) : 0u;
   }
 #pragma unroll
   for (int r = 0; r < kFinRounds; ++r) {
@@ -1363,7 +1375,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   }
   if (threadIdx.x == 0 && lp.write_image && nl < npos) {  // padding pixels repeat the last voxel's colour (jpegcc.h:203-213)
     uint32_t b, g, r;
-    leaf_colour(pv, index_of, colour_pay, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
+    leaf_colour(pv, index_of, colour_pay, colour_keys, leaf_start[L - 1], leaf_start[L], lp.color_reduction, b, g, r);
     s_pad = b | (g << 8) | (r << 16);
   }
   __syncthreads();
@@ -1397,7 +1409,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
         if (cnt > 1) { s0 /= cnt; s1 /= cnt; s2 /= cnt; }
         cb = (s0 >> lp.color_reduction) & 0xffu; cg = (s1 >> lp.color_reduction) & 0xffu; cr = (s2 >> lp.color_reduction) & 0xffu;
       } else {
-        leaf_colour(pv, index_of, colour_pay, ls[r], le[r], lp.color_reduction, cb, cg, cr);
+        leaf_colour(pv, index_of, colour_pay, colour_keys, ls[r], le[r], lp.color_reduction, cb, cg, cr);
       }
       s_bgr[3 * lj] = (uint8_t)cb; s_bgr[3 * lj + 1] = (uint8_t)cg; s_bgr[3 * lj + 2] = (uint8_t)cr;
       if (lp.write_image) {
@@ -2045,7 +2057,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
+                     a.res, a.force_pairs, a.need_index, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
   PCC_STAMP("k_make_keys");

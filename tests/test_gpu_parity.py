@@ -327,6 +327,26 @@ def test_pair_sort_mode_matches_packed_mode(pkg, oracle, monkeypatch):
         c.close()
 
 
+def test_indexed_keys_match_bare_keys(pkg, oracle, monkeypatch):
+    """Without centroids nothing reads the point index of a sorted element, so the sort keys are [code | colour] or the
+    code alone (8 B per key and pass); PCC_FORCE_PAIRS=2 keeps the [code | index] key + colour payload sort that frames
+    with centroids use, on frames that would not need it.  Both ways give the oracle's bytes."""
+    rng = np.random.default_rng(78)
+    xyz = rng.uniform(0.1, 0.9, (150000, 3)).astype(np.float32)
+    xyz[rng.integers(0, 150000, 300)] = np.nan
+    xyz = np.repeat(xyz, 2, axis=0)[rng.permutation(300000)]
+    cases = (dict(octree_bits=9, color_coding_type=1), dict(octree_bits=8, color_coding_type=0), dict(octree_bits=10, color_coding_type=2),
+             dict(octree_bits=9, color_bits=0), dict(octree_bits=11, color_coding_type=0, color_bits=5))
+    for mode in ("0", "2"):
+        monkeypatch.setenv("PCC_FORCE_PAIRS", mode)
+        c = pkg.binding.Context(0)
+        try:
+            for kw in cases:
+                assert_matches_oracle(pkg, oracle, c, cloud(pkg, xyz), **kw)
+        finally:
+            c.close()
+
+
 def test_cpp_shim_example_runs(pkg):
     """The reference-style C++ caller built against the drop-in header (g++ only) runs end to end."""
     import os

@@ -1,16 +1,11 @@
 #!/bin/bash
-# Round-2 probe: GPU tests, single-stream latency for cfg2 / cfg4, in-kernel phase stamps (ktime build).
-# Usage (through gpurun): bash tools/r02_probe.sh <tag> [notest]
+# quick probe: parity subset, single-stream latency (cfg2, cfg4), saturated throughput
 TAG=${1:-probe}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-if [ "$2" != "notest" ]; then
-  python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
-  tail -3 $OUT/pytest_gpu.log
-fi
-python tools/gpu_latency.py cfg2 30 > $OUT/lat_cfg2.txt 2>&1; cat $OUT/lat_cfg2.txt
-python tools/gpu_latency.py cfg4 10 > $OUT/lat_cfg4.txt 2>&1; cat $OUT/lat_cfg4.txt
-if [ -f cwi-pcl-codec_amd/libpcc_hip_ktime.so ]; then
-  PCC_LIB=$PWD/cwi-pcl-codec_amd/libpcc_hip_ktime.so python tools/ktime.py > $OUT/ktime.txt 2>&1; cat $OUT/ktime.txt
-fi
+python -m pytest tests/test_gpu_parity.py tests/test_codec_golden.py tests/test_delta_gpu.py -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -5 $OUT/pytest_gpu.log
+python tools/gpu_latency.py cfg2 20 > $OUT/latency_cfg2.txt 2>&1; grep -v "^   (" $OUT/latency_cfg2.txt | tail -14
+python tools/gpu_latency.py cfg4 8 > $OUT/latency_cfg4.txt 2>&1; grep -v "^   (" $OUT/latency_cfg4.txt | tail -12
+python tools/gpu_throughput.py cfg2 1 4 8 10 12 > $OUT/throughput.txt 2>&1; cat $OUT/throughput.txt
