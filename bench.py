@@ -148,6 +148,13 @@ def main():
     workers = args.workers or default_workers(world)
 
     # ---- frames of this rank, resident in HBM before the clock starts ----
+    if world > 1 and "PCC_PIPELINE_PIN_SPAN" not in os.environ:
+        # the pipeline gives its entropy threads groups of physical cores of their own; the ranks of one host share the
+        # host's cores, so every rank takes its own range (a core has two hardware threads: half the allowed CPUs)
+        cores = max(1, len(os.sched_getaffinity(0)) // 2)
+        span = max(1, cores // world)
+        os.environ["PCC_PIPELINE_PIN_SPAN"] = str(span)
+        os.environ["PCC_PIPELINE_PIN_OFFSET"] = str(int(os.environ.get("LOCAL_RANK", "0")) * span)
     pipe = b.Pipeline(local_rank, workers)
     ctx0 = pipe.context(0)
     for w in range(pipe.n_contexts):

@@ -9,6 +9,7 @@
 #include "pcc_host_codec.h"
 
 #include <float.h>
+#include <immintrin.h>
 #include <math.h>
 #include <string.h>
 
@@ -152,6 +153,55 @@ struct RcStream {
 #define PCC_RC_STORE(S, st)                                                                         \
   (st)->low = low##S; (st)->range = range##S; (st)->pos = (size_t)(p##S - (st)->payload());
 
+// The same symbol with a shorter chain of dependent operations, for loops of one or two streams (whose speed is the
+// latency of that chain, not the number of instructions: a lone frame, the last frames of a call).  What the next
+// symbol needs first is r = range / total AFTER the renormalisation, and the renormalisation is a shift by 8 k bits
+// whose k comes out of a five-operation chain (add, xor, count leading zeros, mask).  floor(magic * (range << 8k) >> 64)
+// is the 128-bit product magic * range shifted left by 8k (no bit is lost: magic < 2^56, range << 8k < 2^32), so the
+// multiply starts as soon as the new range exists, beside the chain that finds k, and r is two shifts and an OR
+// behind k: 10 cycles per symbol instead of 13 (multiply, then k, then shift, then the 64 x 64 multiply).
+// State between symbols: low, range and r = range / total.
+#ifndef PCC_RC_VARIANT
+#define PCC_RC_VARIANT 1
+#endif
+#if PCC_RC_VARIANT == 2  // two shifts and an OR, kept apart (a double shift by CL is microcoded on some cores)
+#define PCC_RC_TAIL(phi, plo, sh, r) { uint64_t tail_ = (plo) >> (63u - (sh)); __asm__("" : "+r"(tail_)); r = (uint32_t)(((phi) << (sh)) | tail_); }
+#else                    // the compiler makes one double shift (shld) of it
+#define PCC_RC_TAIL(phi, plo, sh, r) r = (uint32_t)(((phi) << (sh)) | ((plo) >> (63u - (sh))));
+#endif
+#define PCC_RC_STEP_FAST(S)                                                                         \
+  {                                                                                                 \
+    const uint64_t fw = sb[S].fw[in##S[i]];                                                         \
+    low##S += (uint32_t)fw * r##S;                                                                  \
+    range##S = (uint32_t)(fw >> 32) * r##S;                                                         \
+    const unsigned __int128 prod = (unsigned __int128)sb[S].magic * range##S;                       \
+    const uint64_t phi = (uint64_t)(prod >> 64), plo = (uint64_t)prod >> 1;                         \
+    const uint32_t x = low##S ^ (low##S + range##S);                                                \
+    const unsigned sh = (unsigned)_lzcnt_u32(x | 1u) & 0x38u; /* 8 * settled bytes */               \
+    const uint32_t be = __builtin_bswap32(low##S);                                                  \
+    memcpy(p##S, &be, 4);                                                                           \
+    p##S += sh >> 3;                                                                                \
+    low##S = (uint32_t)((uint64_t)low##S << sh);                                                    \
+    range##S = (uint32_t)((uint64_t)range##S << sh);                                                \
+    PCC_RC_TAIL(phi, plo, sh, r##S)                                                                 \
+    if (__builtin_expect(range##S < kBottom, 0)) {                                                  \
+      range##S = (0u - low##S) & (kBottom - 1);                                                     \
+      for (;;) {                                                                                    \
+        *p##S++ = (uint8_t)(low##S >> 24);                                                          \
+        range##S <<= 8;                                                                             \
+        low##S <<= 8;                                                                               \
+        if ((low##S ^ (low##S + range##S)) >= kTop) {                                               \
+          if (range##S >= kBottom) break;                                                           \
+          range##S = (0u - low##S) & (kBottom - 1);                                                 \
+        }                                                                                           \
+      }                                                                                             \
+      r##S = (uint32_t)(((unsigned __int128)sb[S].magic * range##S) >> 64);                         \
+    }                                                                                               \
+  }
+#define PCC_RC_LOAD_FAST(S, st)                                                                     \
+  PCC_RC_LOAD(S, st)                                                                                \
+  uint32_t r##S = (uint32_t)(((unsigned __int128)(st)->magic * range##S) >> 64);
+
 constexpr size_t kRcBlock = 256;                      // symbols between two capacity checks
 constexpr size_t kRcBlockBytes = 4 * kRcBlock + 16;   // a symbol emits at most 4 bytes (+ store slack)
 
@@ -164,8 +214,13 @@ void rc_run1(RcStream* sb, size_t i0, size_t i1) {
   for (size_t b = i0; b < i1; b += kRcBlock) {
     const size_t e = std::min(b + kRcBlock, i1);
     sb[0].ensure(kRcBlockBytes);
+#if PCC_RC_VARIANT == 0
     PCC_RC_LOAD(0, &sb[0])
     for (size_t i = b; i < e; ++i) PCC_RC_STEP(0)
+#else
+    PCC_RC_LOAD_FAST(0, &sb[0])
+    for (size_t i = b; i < e; ++i) PCC_RC_STEP_FAST(0)
+#endif
     PCC_RC_STORE(0, &sb[0])
   }
 }
@@ -173,8 +228,13 @@ void rc_run2(RcStream* sb, size_t i0, size_t i1) {
   for (size_t b = i0; b < i1; b += kRcBlock) {
     const size_t e = std::min(b + kRcBlock, i1);
     sb[0].ensure(kRcBlockBytes); sb[1].ensure(kRcBlockBytes);
+#if PCC_RC_VARIANT == 0
     PCC_RC_LOAD(0, &sb[0]) PCC_RC_LOAD(1, &sb[1])
     for (size_t i = b; i < e; ++i) { PCC_RC_STEP(0) PCC_RC_STEP(1) }
+#else
+    PCC_RC_LOAD_FAST(0, &sb[0]) PCC_RC_LOAD_FAST(1, &sb[1])
+    for (size_t i = b; i < e; ++i) { PCC_RC_STEP_FAST(0) PCC_RC_STEP_FAST(1) }
+#endif
     PCC_RC_STORE(0, &sb[0]) PCC_RC_STORE(1, &sb[1])
   }
 }

@@ -88,7 +88,10 @@ struct pcc_pipeline {
   // frames in the larger batches; a long call runs in fours and tapers off at its end.  (Callers hold `mu`.)
   size_t batch_wanted() const {
     const size_t left = job.n_frames > taken ? job.n_frames - taken : 0;
-    static const double spread = [] { const char* e = getenv("PCC_PIPELINE_SPREAD"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 2.0; }();
+    // (with the entropy threads on cores of their own -- see pcc_pipeline_create -- the last frames of a call are best
+    // spread wider: 20 frames on 16 threads as five pairs and ten singles, 4.6 ms against 5.0 ms)
+    static const double forced = [] { const char* e = getenv("PCC_PIPELINE_SPREAD"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.0; }();
+    const double spread = forced > 0.0 ? forced : (left <= 2 * (size_t)std::max(n_entropy, 1) ? 1.4 : 2.0);
     const size_t per = (size_t)(((double)left * spread + (double)n_entropy - 1.0) / (double)std::max(n_entropy, 1));
     return std::min<size_t>(std::max<size_t>(per, 1), (size_t)batch);
   }
@@ -408,6 +411,9 @@ struct pcc_pipeline {
 };
 
 // one logical CPU per physical core, out of the CPUs this process may run on
+// set by pcc_pipeline_create_multi around the creation of each of its pipelines: which range of the allowed cores is whose
+static thread_local int pin_offset_hint = 0, pin_span_hint = 0;
+
 static std::vector<int> one_cpu_per_core() {
   std::vector<int> out;
   cpu_set_t allowed;
@@ -469,20 +475,33 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_on_gpu = !strcmp(e, "gpu");
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p, w] { p->entropy_thread(w); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
-  // threads of one core run at about half speed each.  PCC_PIPELINE_PIN=cores gives every entropy thread a physical
-  // core of its own (first hardware thread of the k-th allowed core, starting at core PCC_PIPELINE_PIN_OFFSET).
-  if (const char* e = getenv("PCC_PIPELINE_PIN")) {
-    if (!strcmp(e, "cores")) {
-      const std::vector<int> cores = one_cpu_per_core();
-      int off = 0;
-      if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) off = atoi(o);
-      if (!cores.empty())
-        for (int w = 0; w < p->n_entropy; ++w) {
-          cpu_set_t set;
-          CPU_ZERO(&set);
-          CPU_SET(cores[(size_t)(off + w) % cores.size()], &set);
-          (void)pthread_setaffinity_np(p->threads[(size_t)p->n_gpu + w].native_handle(), sizeof(set), &set);
-        }
+  // threads of one core run at about half speed each, and the scheduler does put them there (20 frames on 16 threads:
+  // 4.8-7.4 ms from call to call; 256 frames: 34.6 ms).  So every entropy thread gets a GROUP of physical cores of its
+  // own (up to eight; first hardware thread of each): the threads of this pipeline never share a core, and the scheduler
+  // can still step aside when somebody else's work sits on one of them -- a thread pinned to ONE core that another
+  // tenant of the host uses takes twice as long (13-25 ms outliers of a 5 ms call).  Measured (tools/pin_probe.sh):
+  // 20 frames 6.1 -> 4.6 ms, 64 frames 12.1 -> 10.2 ms, 256 frames 34.6 -> 28.9 ms, 1 024 frames unchanged.
+  //   PCC_PIPELINE_PIN = groups (default when the process may use at least two cores per entropy thread) | cores (one
+  //   core per thread) | none;  PCC_PIPELINE_PIN_OFFSET = first core (in the list of allowed cores) of this pipeline,
+  //   PCC_PIPELINE_PIN_SPAN = how many cores it may use: several pipelines / ranks on one host take different ranges.
+  {
+    const std::vector<int> cores = one_cpu_per_core();
+    const char* e = getenv("PCC_PIPELINE_PIN");
+    size_t span = cores.size();
+    if (const char* o = getenv("PCC_PIPELINE_PIN_SPAN")) span = std::min<size_t>(cores.size(), (size_t)std::max(atoi(o), 1));
+    if (pin_span_hint > 0) span = std::min<size_t>(span, (size_t)pin_span_hint);
+    int mode = (span >= 2 * (size_t)p->n_entropy) ? 2 : 0;  // 0 none, 1 cores, 2 groups
+    if (e) mode = !strcmp(e, "cores") ? 1 : (!strcmp(e, "groups") ? 2 : 0);
+    size_t off = pin_offset_hint > 0 ? (size_t)pin_offset_hint : 0;
+    if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) off = (size_t)std::max(atoi(o), 0);
+    if (mode && !cores.empty()) {
+      const size_t per = mode == 2 ? std::min<size_t>(8, std::max<size_t>(1, span / (size_t)std::max(p->n_entropy, 1))) : 1;
+      for (int w = 0; w < p->n_entropy; ++w) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        for (size_t k = 0; k < per; ++k) CPU_SET(cores[(off + ((size_t)w * per + k) % span) % cores.size()], &set);
+        (void)pthread_setaffinity_np(p->threads[(size_t)p->n_gpu + w].native_handle(), sizeof(set), &set);
+      }
     }
   }
   return p;
@@ -663,8 +682,12 @@ struct pcc_multi_pipeline {
 pcc_multi_pipeline* pcc_pipeline_create_multi(const int* devices, int n_devices, int n_workers_per_device) {
   if (!devices || n_devices < 1) return nullptr;
   pcc_multi_pipeline* m = new pcc_multi_pipeline();
+  const int n_cores = (int)one_cpu_per_core().size();
   for (int d = 0; d < n_devices; ++d) {
+    pin_span_hint = std::max(n_cores / n_devices, 1);  // every pipeline's entropy threads on a range of cores of its own
+    pin_offset_hint = d * pin_span_hint;
     pcc_pipeline* p = pcc_pipeline_create(devices[d], n_workers_per_device);
+    pin_span_hint = pin_offset_hint = 0;
     if (!p) {  // a device that does not exist: nothing is silently left out
       for (pcc_pipeline* q : m->pipes) pcc_pipeline_destroy(q);
       delete m;
