@@ -77,6 +77,17 @@ def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
     return 0
 
 
+def cgroup_throttled():
+    """(nr_throttled, throttled_usec) of this job's cgroup: the CPU quota (cpu.max) stalls threads until the next 100 ms
+    period when it runs out -- on a CPU whose local slice is used up, others go on -- which shows up as a 5 ms call
+    taking 15 ms.  None where the file is not there."""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d["nr_throttled"]), int(d["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def default_workers(world):
     """Entropy threads per GPU: the CPUs this process may really use (cgroup quota, affinity), shared by the ranks."""
     cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
@@ -194,6 +205,7 @@ def main():
     # dlopen of a small extension module -- took the 1024-frame run from 8 500 to 6 300 Mpoints/s.  glibc 2.35 sends every
     # access to a thread-local variable of a dlopen-ed library (the HIP runtime and libpcc_hip.so are loaded that way by
     # ctypes / torch) through the slow path of __tls_get_addr once a later dlopen has bumped the TLS generation counter.
+    thr0 = cgroup_throttled()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     res = pipe.encode(seq, [n_points] * args.steps, params, copy=False)
@@ -202,6 +214,10 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    thr1 = cgroup_throttled()
+    throttled_ms = None if thr0 is None or thr1 is None else round((thr1[1] - thr0[1]) / 1e3, 3)
+    trace("cgroup CPU quota: throttled %s times for %s ms inside the timed region" % (
+        "?" if thr0 is None or thr1 is None else thr1[0] - thr0[0], throttled_ms))
     trace("timed region: the call %.3f ms, the synchronisation behind it %.3f ms; CPU user %.1f ms, system %.1f ms, %d minor page faults, "
           "%d + %d context switches" % (1e3 * (t_call - t0), 1e3 * (t1 - t_call), 1e3 * (ru1.ru_utime - ru0.ru_utime), 1e3 * (ru1.ru_stime - ru0.ru_stime),
                                        ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
@@ -392,6 +408,7 @@ def main():
             "kernels_ms_per_frame": {k: round(v, 5) for k, v in sorted(span_frame_ms.items(), key=lambda kv: -kv[1])},
             "host_input": host_input,
             "host_cpus_for_this_rank": default_workers(world),
+            "cgroup_throttled_ms_in_timed_region": throttled_ms,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
