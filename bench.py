@@ -80,10 +80,15 @@ def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
 def cgroup_throttled():
     """(nr_throttled, throttled_usec) of this job's cgroup: the CPU quota (cpu.max) stalls threads until the next 100 ms
     period when it runs out -- on a CPU whose local slice is used up, others go on -- which shows up as a 5 ms call
-    taking 15 ms.  None where the file is not there."""
+    taking 15 ms.  None where the file is not there.  (Plain os.open / os.read: this runs right next to the timed region,
+    where nothing may be imported -- see the note there -- and Python's text layer imports on first use.)"""
     try:
-        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
-        return int(d["nr_throttled"]), int(d["throttled_usec"])
+        fd = os.open("/sys/fs/cgroup/cpu.stat", os.O_RDONLY)
+        try:
+            d = dict(l.split() for l in os.read(fd, 4096).split(b"\n") if l)
+        finally:
+            os.close(fd)
+        return int(d[b"nr_throttled"]), int(d[b"throttled_usec"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -102,6 +107,7 @@ def default_workers(world):
 
 def main():
     args = parse()
+    cgroup_throttled()  # first use here, long before the pipeline's threads exist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,7 +201,7 @@ def main():
     # HIP events between the kernels of ONE context: live kernel durations from inside the timed region
     # without taxing every stream (the free list is a stack: its top context takes part in every round)
     # (only in long runs: a profiled frame creates its events on first use, which a 20-frame region would mostly consist of)
-    prof_ctxs = [pipe.context(pipe.n_contexts - 1 - k) for k in range(min(4, pipe.n_contexts))] if args.steps >= 256 else []
+    prof_ctxs = [pipe.context(pipe.n_contexts - 1 - k) for k in range(min(4, pipe.n_contexts))] if (args.steps >= 256 and not os.environ.get("PCC_BENCH_NO_KERNEL_EVENTS")) else []
     for c in prof_ctxs:
         c.set_profiling(True)
     seq = [dev_frames[s % n_distinct] for s in range(args.steps)]
@@ -205,6 +211,16 @@ def main():
     # dlopen of a small extension module -- took the 1024-frame run from 8 500 to 6 300 Mpoints/s.  glibc 2.35 sends every
     # access to a thread-local variable of a dlopen-ed library (the HIP runtime and libpcc_hip.so are loaded that way by
     # ctypes / torch) through the slow path of __tls_get_addr once a later dlopen has bumped the TLS generation counter.
+    # The warm-up ends with one untimed call of the timed call's own shape.  The first long call of a process is slower than
+    # every later one (1 024 frames: 148 ms, then 101-106 ms; 3 000-11 000 page faults against 56): contexts that the short
+    # warm-up call never reached -- the free list is a stack, a short call uses its top -- make their host-side buffers
+    # inside it.  (PCC_BENCH_SHAPE_WARMUP=0 leaves it out, =N repeats it.)
+    for rep in range(int(os.environ.get("PCC_BENCH_SHAPE_WARMUP", "1"))):
+        tx = time.perf_counter()
+        pipe.encode(seq, [n_points] * args.steps, params, copy=False)
+        trace("warm-up call %d of the timed call's shape: %.3f ms" % (rep, 1e3 * (time.perf_counter() - tx)))
+        pipe.reserve(args.steps, max(r[0] for r in wres), n_points)  # what a caller does before a sequence (see pcc_reserve)
+    sync_all()
     thr0 = cgroup_throttled()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
@@ -409,6 +425,7 @@ def main():
             "host_input": host_input,
             "host_cpus_for_this_rank": default_workers(world),
             "cgroup_throttled_ms_in_timed_region": throttled_ms,
+            "warmup_frames_run": warm + args.steps * int(os.environ.get("PCC_BENCH_SHAPE_WARMUP", "1")),
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

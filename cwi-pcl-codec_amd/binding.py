@@ -30,6 +30,7 @@ EXPORTS = [
     "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
     "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
     "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
+    "pcc_stream_create", "pcc_stream_destroy", "pcc_use_stream",
     "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra", "pcc_decode_intra_gpu", "pcc_get_decode_times",
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_host_times",
     "pcc_set_profiling",
@@ -146,6 +147,11 @@ def load_library():
     lib.pcc_upload_lane_create.argtypes = [i32]
     lib.pcc_upload_lane_destroy.argtypes = [vp]
     lib.pcc_upload_lane_destroy.restype = None
+    lib.pcc_stream_create.restype = vp
+    lib.pcc_stream_create.argtypes = [i32]
+    lib.pcc_stream_destroy.argtypes = [vp]
+    lib.pcc_stream_destroy.restype = None
+    lib.pcc_use_stream.argtypes = [vp, vp]
     lib.pcc_host_alloc.restype = vp
     lib.pcc_host_alloc.argtypes = [sz]
     lib.pcc_host_free.argtypes = [vp]

@@ -74,7 +74,8 @@ struct PinnedBuf {  // grow-only page-locked host allocation (D2H landing zone)
 
 struct pcc_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // where this context's GPU work goes: its own stream, or a borrowed one (pcc_use_stream)
+  hipStream_t own_stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_wait = nullptr;  // blocking-sync event: a host thread that waits for the GPU sleeps instead of
                                  // spinning, so its core is free for the entropy stage of another frame
@@ -348,6 +349,11 @@ void unlock_host_range(const void* p) {
 // One stream that carries the host-to-device copies of a GPU, one after the other: copies issued side by side on
 // several streams share the link and finish later in total (51 GB/s with eight in flight against 56 GB/s one at a
 // time, tools/ubench/h2d.cpp), and a frame's kernels should start when ITS points are there, not when everybody's are.
+struct pcc_stream {
+  int device = 0;
+  hipStream_t stream = nullptr;
+};
+
 struct pcc_upload_lane {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -368,7 +374,7 @@ pcc_ctx* pcc_create(int device) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || ((c->stream = c->own_stream), false) ||
       hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming) != hipSuccess) {
@@ -414,7 +420,7 @@ void pcc_destroy(pcc_ctx* c) {
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
   if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -604,6 +610,32 @@ void pcc_upload_lane_destroy(pcc_upload_lane* l) {
   (void)hipStreamSynchronize(l->stream);
   (void)hipStreamDestroy(l->stream);
   delete l;
+}
+
+pcc_stream* pcc_stream_create(int device) {
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  pcc_stream* st = new pcc_stream();
+  st->device = device;
+  if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete st;
+    return nullptr;
+  }
+  return st;
+}
+void pcc_stream_destroy(pcc_stream* st) {
+  if (!st) return;
+  (void)hipSetDevice(st->device);
+  (void)hipStreamSynchronize(st->stream);
+  (void)hipStreamDestroy(st->stream);
+  delete st;
+}
+int pcc_use_stream(pcc_ctx* ctx, pcc_stream* st) {
+  if (!ctx) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  if (ctx->launched) return fail(ctx, PCC_ERR_STATE, "pcc_use_stream: a frame is in flight on this context");
+  if (st && st->device != ctx->device) return fail(ctx, PCC_ERR_ARG, "pcc_use_stream: the stream belongs to another device");
+  ctx->stream = st ? st->stream : ctx->own_stream;
+  return PCC_OK;
 }
 
 void* pcc_host_alloc(size_t bytes) {

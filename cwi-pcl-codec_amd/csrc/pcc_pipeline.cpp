@@ -66,6 +66,7 @@ struct pcc_pipeline {
   int n_entropy = 0, n_gpu = 0;
   int n_gpu_device = 0;  // of the n_gpu GPU-stage threads, how many take part when the frames already sit in HBM
   pcc_upload_lane* lane = nullptr;  // host-to-device copies of host-input jobs, one after the other
+  std::vector<pcc_stream*> gpu_streams;  // one per GPU-stage thread, created one after the other: see pcc_use_stream in pcc_codec.h
   // Opt-in (pcc_pipeline_set_option "entropy_on_gpu"): the range coders run on the GPU, one wave per stream, in batches of
   // `gpu_batch` frames per entropy thread -- for hosts with fewer cores than the GPU stage can feed.
   bool entropy_on_gpu = false;
@@ -190,6 +191,7 @@ struct pcc_pipeline {
         }
         r.prm = job.params;
         r.prm.frame_id = job.params.frame_id + (uint32_t)r.frame;  // frame_ID_ by sequence index
+        if ((size_t)index < gpu_streams.size() && gpu_streams[(size_t)index]) (void)pcc_use_stream(r.ctx, gpu_streams[(size_t)index]);
         Clock::time_point t0 = Clock::now();
         if (tracing) trace[r.frame].launched = us_since(job_t0);
         double c0 = thread_cpu_us();
@@ -444,12 +446,14 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   // frames in flight on the GPU: six saturate it to within a few per cent (tools/gpu_throughput.py: 4 streams 6 600, 8 streams
   // 7 750, 12 streams 8 070 frames/s); with the entropy stage no longer the bottleneck the last per cent count
   // (tools/sweep_gpu_threads.sh: 7 000 frames/s end to end with 6 threads, 7 400-7 500 with 10 or 12)
-  p->n_gpu_device = n_workers < 10 ? n_workers : 10;
+  // Twelve since the streams are balanced over the runtime's four hardware queues (three each; ten were 3 3 2 2, and the
+  // ten contexts that happened to be in flight out of 92 anything): tools/queue_balance.py, 10 400 -> 11 200 frames/s.
+  p->n_gpu_device = n_workers < 12 ? n_workers : 12;
   if (const char* e = getenv("PCC_PIPELINE_GPU_THREADS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) p->n_gpu_device = v;
   }
-  p->n_gpu = std::max(p->n_gpu_device, std::min(n_workers, 10));
+  p->n_gpu = std::max(p->n_gpu_device, std::min(n_workers, 12));
   if (const char* e = getenv("PCC_PIPELINE_UPLOAD_THREADS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) p->n_gpu = std::max(p->n_gpu_device, v);
@@ -470,6 +474,10 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     p->ctxs.push_back(c);
   }
   p->lane = pcc_upload_lane_create(device);
+  // one stream per GPU-stage thread, created back to back (the runtime hands out its hardware queues round robin)
+  // (PCC_PIPELINE_OWN_STREAMS=1: every context keeps its own stream, as before)
+  if (!(getenv("PCC_PIPELINE_OWN_STREAMS") && getenv("PCC_PIPELINE_OWN_STREAMS")[0] == '1'))
+    for (int w = 0; w < p->n_gpu; ++w) p->gpu_streams.push_back(pcc_stream_create(device));
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
   p->batches.assign((size_t)p->n_entropy, nullptr);
   if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_on_gpu = !strcmp(e, "gpu");
@@ -518,6 +526,7 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   for (pcc_ctx* c : p->ctxs) pcc_destroy(c);
   for (pcc_entropy_batch* b : p->batches) pcc_entropy_batch_destroy(b);
   pcc_upload_lane_destroy(p->lane);
+  for (pcc_stream* st : p->gpu_streams) pcc_stream_destroy(st);
   free(p->arena);
   delete p;
 }

@@ -160,6 +160,18 @@ pcc_upload_lane *pcc_upload_lane_create(int device);
 void pcc_upload_lane_destroy(pcc_upload_lane *lane);
 int pcc_hotpath_launch_host(pcc_ctx *ctx, pcc_upload_lane *lane, const void *host_points, size_t n, size_t stride,
                             size_t rgb_offset, const pcc_params *params);
+/* A context's GPU work runs on a stream of its own unless it borrows one.  Why a caller would care: the HIP runtime
+ * spreads the streams of a process over four hardware queues, round robin in the order the streams are created, and
+ * the frames in flight overlap best when every queue carries the same number of them (cfg2, saturated GPU stage: 12
+ * streams as 3 3 3 3: 11 200 frames/s, 10 streams as 3 3 2 2: 10 400, 12 as 4 4 4 0: 10 000; tools/queue_balance.py).
+ * With more contexts than frames in flight -- a context is held until its host stage is over -- the streams that
+ * happen to be busy are not balanced; pcc_pipeline therefore creates one stream per GPU-stage thread, one after the
+ * other, and lends it to whichever context the thread is driving.  Only between frames (no launch in flight on the
+ * context); NULL gives the context its own stream back. */
+typedef struct pcc_stream pcc_stream;
+pcc_stream *pcc_stream_create(int device);
+void pcc_stream_destroy(pcc_stream *stream);
+int pcc_use_stream(pcc_ctx *ctx, pcc_stream *stream);
 /* page-locked host memory for callers that fill their frames themselves (capture, file readers) */
 void *pcc_host_alloc(size_t bytes);
 void pcc_host_free(void *p);

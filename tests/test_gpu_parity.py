@@ -587,6 +587,35 @@ def test_host_frames_through_one_context(pkg, oracle):
         lib.pcc_upload_lane_destroy(lane)
 
 
+def test_contexts_on_borrowed_streams(pkg, oracle):
+    """pcc_use_stream: two contexts take turns on one borrowed stream (what the pipeline's GPU-stage threads do), go
+    back to their own, and a context with a frame in flight refuses to change streams."""
+    b = pkg.binding
+    lib = b.load_library()
+    ca, cb = b.Context(0), b.Context(0)
+    st = lib.pcc_stream_create(0)
+    assert st
+    try:
+        kw = dict(octree_bits=9, jpeg_quality=85)
+        prm = b.make_params(frame_id=1, **kw)
+        clouds = [pkg.synthetic.sphere_shell(90_000, 0xB0 + k) for k in range(2)]
+        want = [oracle.encode_intra(p, oracle.make_params(frame_id=1, **kw)).bitstream for p in clouds]
+        dev = [ca.upload(clouds[0]), cb.upload(clouds[1])]
+        for borrowed in (st, None, st):
+            for c in (ca, cb):
+                assert lib.pcc_use_stream(c.h, borrowed) == 0
+            ca.hotpath_launch(dev[0], len(clouds[0]), prm)
+            assert lib.pcc_use_stream(ca.h, None) == -6          # PCC_ERR_STATE: a frame is in flight
+            cb.hotpath_launch(dev[1], len(clouds[1]), prm)       # queued behind ca's frame on the shared stream
+            for c, w in ((cb, want[1]), (ca, want[0])):
+                hot = c.hotpath_finish(copy=False)
+                stream, _ = c.entropy_encode(hot.raw, prm)
+                assert stream == w
+    finally:
+        ca.close(); cb.close()
+        lib.pcc_stream_destroy(st)
+
+
 # ---------------- the decoder with its data-parallel half on the GPU ----------------
 
 @pytest.mark.parametrize("kw", [

@@ -3,6 +3,9 @@
 lengths, repeated.  PCC_PIPELINE_BATCH caps the frames per coder loop.   python tools/short_calls.py [n ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("SHORT_CALLS_WITH_TORCH"):  # does the process behave differently with torch (its threads, its HIP context) loaded?
+    import torch
+    torch.cuda.set_device(0); torch.cuda.synchronize()
 import __graft_entry__ as G
 pkg = G.load_package(); B = pkg.binding
 ns = [int(x) for x in sys.argv[1:]] or [20, 64, 256]
