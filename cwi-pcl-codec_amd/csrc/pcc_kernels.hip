@@ -611,7 +611,11 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
 constexpr uint64_t kInvalidKey = ~0ull;
 
 
-__global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
+// (1024 threads x 4 points; 512 x 8 was tried for the sake of frames in flight -- a smaller workgroup finds room on a
+// busy CU sooner, which took k_digit_totals from 22 to 14 us under load -- but here it lost both ways: 15.4 -> 18.9 us
+// alone, 38.6 -> 41.9 us under load)
+constexpr int kKeyThreads = kSortThreads, kKeyItems = kSortTile / kKeyThreads;
+__global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
                                                             uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows, unsigned long long* span) {
   const KSpan kspan(span);
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
   const int np = st->npasses;
-  for (int k = threadIdx.x; k < np * kMaxBins; k += kSortThreads) (&s_h[0][0])[k] = 0u;
+  for (int k = threadIdx.x; k < np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
   __syncthreads();
   const int vb = st->vbits_axis, ibits = st->ibits;
   const bool packed_mode = st->packed != 0;
@@ -634,8 +638,8 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
 #pragma unroll
   for (int p = 0; p < kMaxPasses; ++p) { pshift[p] = st->pass_shift[p]; pmask[p] = (1u << st->pass_bits[p]) - 1u; }
 #pragma unroll
-  for (int k = 0; k < kSortItems; ++k) {
-    const uint32_t i = base + k * kSortThreads + threadIdx.x;
+  for (int k = 0; k < kKeyItems; ++k) {
+    const uint32_t i = base + k * kKeyThreads + threadIdx.x;
     if (i >= n) break;
     float x, y, z;
     load_xyz(pv, i, x, y, z);
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
   }
   __syncthreads();
   uint32_t* row = hist_rows + (size_t)blockIdx.x * kMaxPasses * kMaxBins;
-  for (int k = threadIdx.x; k < np * kMaxBins; k += kSortThreads) row[k] = (&s_h[0][0])[k];
+  for (int k = threadIdx.x; k < np * kMaxBins; k += kKeyThreads) row[k] = (&s_h[0][0])[k];
 }
 
 // column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
@@ -679,11 +683,17 @@ __global__ __launch_bounds__(kSortThreads) void k_make_keys(PointView pv, uint32
 // hundred workgroups however many tiles there are, and a thread walks rows / 64 of them.
 // For pass 0 the input order of the sort is the tile order of k_make_keys, so the same kernel also
 // writes the exclusive prefix over the tiles (tile_prefix0[tile][digit]): pass 0 needs no look-back.
-constexpr uint32_t kDtCols = 16, kDtGroups = 1024 / kDtCols;
-__global__ __launch_bounds__(1024) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
+// (256 threads per workgroup for frames of up to 512 tiles: a 1024-thread workgroup needs sixteen free wave slots on ONE
+// CU at the same moment, and with the kernels of three other frames on the GPU it waits for them: 22 us under load
+// against 5.5 us alone; the narrow shape 14 us against 7 us)
+// (for frames of many tiles the wide shape stays: a thread of the narrow one would walk rows / 16 of them)
+constexpr uint32_t kDtCols = 16;
+template <uint32_t kDtThreads>
+__global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
                                                        const uint32_t* __restrict__ hist_rows,
                                                        uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0, unsigned long long* span) {
   const KSpan kspan(span);
+  constexpr uint32_t kDtGroups = kDtThreads / kDtCols;
   __shared__ uint32_t s_part[kDtGroups][kDtCols];
   const uint32_t c = threadIdx.x % kDtCols;
   const uint32_t col = blockIdx.x * kDtCols + c;
@@ -2021,7 +2031,7 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
     out += line;
   };
   one("k_boxes_events", (const void*)k_boxes_events, kBlock);
-  one("k_make_keys", (const void*)k_make_keys, kSortThreads);
+  one("k_make_keys", (const void*)k_make_keys, kKeyThreads);
   one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems>, kSortThreads);
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
   one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems>, kSortThreads);
@@ -2059,9 +2069,12 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
                      a.res, a.force_pairs, a.need_index, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
-  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
+  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
   PCC_STAMP("k_make_keys");
-  hipLaunchKernelGGL(k_digit_totals, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+  if (s_tiles <= 512)
+    hipLaunchKernelGGL(k_digit_totals<256>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(256), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+  else
+    hipLaunchKernelGGL(k_digit_totals<1024>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
   PCC_STAMP("k_digit_totals");
   // Few tiles (every tile has a CU to itself): 16 waves share a tile's latency-bound steps.  Many tiles: 8 waves with
   // twice the keys per thread need 62 KB of LDS instead of 87 KB, so two tiles share a CU and one loads or waits for
