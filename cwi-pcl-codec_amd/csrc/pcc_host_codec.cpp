@@ -159,7 +159,9 @@ struct RcStream {
 // whose k comes out of a five-operation chain (add, xor, count leading zeros, mask).  floor(magic * (range << 8k) >> 64)
 // is the 128-bit product magic * range shifted left by 8k (no bit is lost: magic < 2^56, range << 8k < 2^32), so the
 // multiply starts as soon as the new range exists, beside the chain that finds k, and r is two shifts and an OR
-// behind k: 10 cycles per symbol instead of 13 (multiply, then k, then shift, then the 64 x 64 multiply).
+// behind k: 10 cycles per symbol instead of 13 (multiply, then k, then shift, then the 64 x 64 multiply).  The upper end
+// of the new interval, low + (start + size) * r, is a third multiply next to start * r and size * r instead of an add
+// behind them.
 // State between symbols: low, range and r = range / total.
 #ifndef PCC_RC_VARIANT
 #define PCC_RC_VARIANT 1
@@ -169,14 +171,19 @@ struct RcStream {
 #else                    // the compiler makes one double shift (shld) of it
 #define PCC_RC_TAIL(phi, plo, sh, r) r = (uint32_t)(((phi) << (sh)) | ((plo) >> (63u - (sh))));
 #endif
-#define PCC_RC_STEP_FAST(S)                                                                         \
+#define PCC_RC_STEP_FAST(S) PCC_RC_STEP_FAST_(S, low##S + range##S)
+// (a lone stream only -- in a loop of two the extra multiply costs more than the shorter chain gains: 1.42 -> 1.51 ms per frame)
+#define PCC_RC_STEP_FAST3(S) PCC_RC_STEP_FAST_(S, top3_)
+#define PCC_RC_STEP_FAST_(S, TOP)                                                                         \
   {                                                                                                 \
     const uint64_t fw = sb[S].fw[in##S[i]];                                                         \
+    const uint32_t top3_ = low##S + ((uint32_t)fw + (uint32_t)(fw >> 32)) * r##S; /* low + range of the new interval by a multiply of its own, beside the other two (dead code unless TOP names it) */ \
     low##S += (uint32_t)fw * r##S;                                                                  \
     range##S = (uint32_t)(fw >> 32) * r##S;                                                         \
     const unsigned __int128 prod = (unsigned __int128)sb[S].magic * range##S;                       \
     const uint64_t phi = (uint64_t)(prod >> 64), plo = (uint64_t)prod >> 1;                         \
-    const uint32_t x = low##S ^ (low##S + range##S);                                                \
+    (void)top3_;                                                                                    \
+    const uint32_t x = low##S ^ (TOP);                                                              \
     const unsigned sh = (unsigned)_lzcnt_u32(x | 1u) & 0x38u; /* 8 * settled bytes */               \
     const uint32_t be = __builtin_bswap32(low##S);                                                  \
     memcpy(p##S, &be, 4);                                                                           \
@@ -219,7 +226,7 @@ void rc_run1(RcStream* sb, size_t i0, size_t i1) {
     for (size_t i = b; i < e; ++i) PCC_RC_STEP(0)
 #else
     PCC_RC_LOAD_FAST(0, &sb[0])
-    for (size_t i = b; i < e; ++i) PCC_RC_STEP_FAST(0)
+    for (size_t i = b; i < e; ++i) PCC_RC_STEP_FAST3(0)
 #endif
     PCC_RC_STORE(0, &sb[0])
   }
