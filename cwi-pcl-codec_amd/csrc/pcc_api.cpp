@@ -550,6 +550,8 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
     // '2': keep the point index in the key although nothing needs it (the packed [code | index] + colour payload sort)
     a.need_index = (a.lp.do_centroid || stop_after_leaf_scan || (fp && fp[0] == '2')) ? 1 : 0;
+    const char* nr = getenv("PCC_NO_CELL_RANKS");  // test hook: the full varying Morton code is sorted
+    a.no_cell_ranks = (nr && nr[0] == '1') ? 1 : 0;
   }
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
@@ -610,6 +612,16 @@ void pcc_upload_lane_destroy(pcc_upload_lane* l) {
   (void)hipStreamSynchronize(l->stream);
   (void)hipStreamDestroy(l->stream);
   delete l;
+}
+
+// developer aid (not part of include/pcc_codec.h): the sort geometry of the last frame whose state came back --
+// {sort passes, code bits that were sorted, varying Morton bits, key bits per axis below the cell ranks, bytes per key and pass}
+int pcc_debug_sort_plan(pcc_ctx* ctx, int32_t out[5]) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  const FrameState& st = *ctx->h_state.p;
+  out[0] = st.npasses; out[1] = st.code_bits; out[2] = st.vbits; out[3] = st.code_low_bits; out[4] = st.payload ? 12 : 8;
+  return PCC_OK;
 }
 
 pcc_stream* pcc_stream_create(int device) {

@@ -78,6 +78,16 @@ struct FrameState {
   int32_t payload;                   // what the u32 payload of the sort carries: 0 nothing, 1 point index (pairs
                                      // mode), 2 the point's colour word (packed mode with colour: no gather later)
   int32_t colour_in_key;             // 1: the low 24 key bits (ibits = 24) are the point's colour, no payload, no index
+  // cell ranks: the code that is SORTED may be shorter than the 3 * vbits_axis varying Morton bits.  A cloud that
+  // straddles a high power-of-two boundary of its box varies in key bits far above its extent (a 1024-voxel capture in a
+  // box of 8192: 13 bits per axis, 39 code bits, five sort passes), but touches only a few cells of side 2^code_low_bits
+  // up there: the high part of the code is replaced by the cell's rank in Morton order (order preserving), which
+  // k_leaf_scan turns back into the Morton bits (cell_abs) before anything downstream sees a code.
+  int32_t code_low_bits;             // m: key bits per axis that go into the sorted code verbatim (= vbits_axis: no ranks)
+  int32_t code_bits;                 // 3 * m + bits of a rank: what the sort passes cover
+  uint32_t cell_base[3], cell_dim[3];  // the cells the cloud's box touches: first cell per axis (key >> m), cells per axis
+  uint8_t cell_rank[64];             // cell (dz + dim_z * (dy + dim_y * dx)) -> rank
+  uint64_t cell_abs[64];             // rank -> Morton code of the cell's varying high key bits
   int32_t npasses;                   // radix passes actually needed (>= 1)
   int32_t pass_bits[kMaxPasses];     // digit width of each pass
   int32_t pass_shift[kMaxPasses];    // bit position of each digit inside the code (add ibits for the packed key)

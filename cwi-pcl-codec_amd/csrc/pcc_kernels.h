@@ -63,6 +63,7 @@ struct HotPathArgs {
   LeafParams lp;
   int max_passes;  // sort passes to enqueue (the device decides how many do work; more needed => kErrPasses)
   int force_pairs; // testing: use the (key, index) pair sort even when the packed key would fit
+  int no_cell_ranks;  // testing: sort the full varying Morton code even where cell ranks would save a pass
   int need_index;  // somebody reads the point index of the sorted elements (centroids, macroblock trees): keep it in the key
   FixedBox box;    // defineBoundingBox before addPointsFromInputCloud
   int stop_after_leaf_scan;  // macroblock trees: only the sorted points and the leaf (= block) arrays are wanted

@@ -272,7 +272,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int need_index, int passes_launched, int do_color, FixedBox box,
+                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int do_color, FixedBox box,
                                                          FrameState* __restrict__ st, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction
@@ -471,6 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
         st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
         st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0;
+        st->code_low_bits = 0; st->code_bits = 0;
         st->passes_launched = passes_launched;
       }
       return;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (depth > kMaxDepth && err == kErrNone) err = kErrDepth;
     // varying key bits from the global AABB under the final origin, +-1 voxel of slack
     int vb = 0;
-    unsigned kmin[3];
+    unsigned kmin[3], kmax[3];
     const unsigned klim = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u);
     for (int a = 0; a < 3; ++a) {
       float gmin = FLT_MAX, gmax = -FLT_MAX;
@@ -554,10 +555,43 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       unsigned kh = hi > 0.0 ? (unsigned)hi : 0u;
       kl = kl > 0 ? kl - 1 : 0;
       kh = kh < klim ? kh + 1 : klim;
-      kmin[a] = kl;
+      kmin[a] = kl; kmax[a] = kh;
       const unsigned x = kl ^ kh;
       const int nb = x ? 32 - __clz((int)x) : 0;
       vb = max(vb, nb);
+    }
+    // ---- cell ranks (FrameState::code_low_bits): the shortest sorted code over the low-bit counts m that leave at most
+    //      64 cells; fewer passes first, then fewer cells
+    auto passes_for = [](int bits) { return bits <= kMaxDigitBits ? 1 : (bits + kMaxDigitBits - 1) / kMaxDigitBits; };
+    int cm = vb, cbits = 3 * vb;
+    unsigned cdim[3] = {1u, 1u, 1u};
+    for (int m = vb - 1; m >= 0 && vb < 32; --m) {
+      unsigned d[3];
+      unsigned long long nc = 1;
+      for (int a = 0; a < 3; ++a) { d[a] = (kmax[a] >> m) - (kmin[a] >> m) + 1u; nc *= d[a]; }
+      if (nc > 64ull) break;
+      const int rb = nc > 1ull ? 32 - __clz((int)(nc - 1ull)) : 0;
+      const int bits = 3 * m + rb;
+      if (passes_for(bits) < passes_for(cbits)) { cm = m; cbits = bits; for (int a = 0; a < 3; ++a) cdim[a] = d[a]; }
+    }
+    if (no_cell_ranks) { cm = vb; cbits = 3 * vb; cdim[0] = cdim[1] = cdim[2] = 1u; }
+    {
+      const unsigned nc = cdim[0] * cdim[1] * cdim[2];
+      const int i = lane_id();
+      const unsigned hm = (vb - cm) >= 32 ? 0xffffffffu : ((1u << (vb - cm)) - 1u);  // the varying part of a cell coordinate
+      uint64_t mort = ~0ull;
+      if ((unsigned)i < nc) {
+        const unsigned dz = (unsigned)i % cdim[2], dy = ((unsigned)i / cdim[2]) % cdim[1], dx = (unsigned)i / (cdim[2] * cdim[1]);
+        mort = morton3(((kmin[0] >> cm) + dx) & hm, ((kmin[1] >> cm) + dy) & hm, ((kmin[2] >> cm) + dz) & hm);
+      }
+      unsigned rank = 0;
+      for (int j = 0; j < 64; ++j) {
+        const uint64_t other = __shfl(mort, j);
+        rank += (other < mort) ? 1u : 0u;
+      }
+      if ((unsigned)i < nc) { st->cell_rank[i] = (uint8_t)rank; st->cell_abs[rank] = mort; }
+      if (i < 3) { st->cell_base[i] = kmin[i] >> cm; st->cell_dim[i] = cdim[i]; }
+      if (i == 0) { st->code_low_bits = cm; st->code_bits = cbits; }
     }
     int ibits = 32 - __clz((int)n);  // bit length of n: index < 2^ibits - 1
     // Nothing downstream needs the point index unless centroids are coded or the caller wants the sorted points
@@ -565,12 +599,12 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     // key is the code alone, or [code | the point's 24 colour bits] -- 8 B per key and pass, no payload array.
     // Otherwise code + index in one u64 when they fit (+ the colour word as a u32 payload: 12 B); otherwise u64 code
     // keys with a u32 index payload (12 B).  All of them give the same order.
-    const bool bare = !need_index && !force_pairs && (!do_color || 3 * vb + 24 <= 63);
-    const int packed = (bare || (3 * vb + ibits <= 64 && !force_pairs)) ? 1 : 0;
+    const bool bare = !need_index && !force_pairs && (!do_color || cbits + 24 <= 63);
+    const int packed = (bare || (cbits + ibits <= 64 && !force_pairs)) ? 1 : 0;
     if (bare) ibits = do_color ? 24 : 0;
     if (!packed) ibits = 0;
     // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
-    const int vbits = 3 * vb;
+    const int vbits = cbits;  // what is sorted
     int np = (vbits + kMaxDigitBits - 1) / kMaxDigitBits;
     if (np < 1) np = 1;
     if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
@@ -591,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (p == 8) {
       for (int a = 0; a < 3; ++a) st->prefix[a] = vb >= 32 ? 0u : ((kmin[a] >> vb) << vb);
       st->vbits_axis = vb;
-      st->vbits = vbits;
+      st->vbits = 3 * vb;
       st->ibits = ibits;
       st->packed = packed;
       st->payload = bare ? 0 : (packed ? (do_color ? 2 : 0) : 1);
@@ -629,6 +663,11 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   const bool packed_mode = st->packed != 0;
   const int payload = st->payload;
   const bool colour_in_key = st->colour_in_key != 0;
+  const int cm = st->code_low_bits;
+  const bool ranked = cm < vb;  // the high key bits go into the code as the rank of their cell (FrameState::code_low_bits)
+  const unsigned cbase[3] = {st->cell_base[0], st->cell_base[1], st->cell_base[2]};
+  const unsigned cdim[3] = {st->cell_dim[0], st->cell_dim[1], st->cell_dim[2]};
+  const unsigned lm = cm >= 32 ? 0xffffffffu : ((1u << cm) - 1u);
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
   const uint32_t base = blockIdx.x * kSortTile;
   const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
@@ -660,8 +699,17 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
         kk[a] = (unsigned)d + st->ep_shift[e][a];
         ok &= vb >= 32 || ((kk[a] >> vb) == (st->prefix[a] >> vb));
       }
+      uint64_t code;
+      if (!ranked) {
+        code = morton3(kk[0] & m, kk[1] & m, kk[2] & m);
+      } else {
+        unsigned d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { d[a] = (kk[a] >> cm) - cbase[a]; ok &= d[a] < cdim[a]; }
+        const unsigned cell = ok ? d[2] + cdim[2] * (d[1] + cdim[1] * d[0]) : 0u;
+        code = ((uint64_t)st->cell_rank[cell] << (3 * cm)) | morton3(kk[0] & lm, kk[1] & lm, kk[2] & lm);
+      }
       if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
-      const uint64_t code = morton3(kk[0] & m, kk[1] & m, kk[2] & m);
 #pragma unroll
       for (int p = 0; p < kMaxPasses; ++p)
         if (p < np) atomicAdd(&s_h[p][(uint32_t)(code >> pshift[p]) & pmask[p]], 1u);
@@ -1029,6 +1077,17 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const int ibits = st->ibits, depth = st->depth;
   const int lane = lane_id(), wave = wave_id();
+  // sorted codes whose high part is a cell rank (FrameState::code_low_bits) become Morton codes again here: nothing
+  // downstream of this kernel sees a rank
+  __shared__ uint64_t s_cell_abs[64];
+  const int cm3 = 3 * st->code_low_bits;
+  const bool ranked = st->code_low_bits < st->vbits_axis;
+  if (ranked) {
+    if (threadIdx.x < 64) s_cell_abs[threadIdx.x] = st->cell_abs[threadIdx.x];
+    __syncthreads();
+  }
+  const uint64_t lowmask = (1ull << cm3) - 1ull;
+  auto unrank = [&](uint64_t c) { return ranked ? ((s_cell_abs[(c >> cm3) & 63u] << cm3) | (c & lowmask)) : c; };
   // Every wave owns 512 consecutive sorted keys, read as 8 rows of 64 (coalesced); element (r, lane)
   // is key wbase + 64 r + lane, so scan order is row-major inside the wave, then wave-major.
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
@@ -1036,9 +1095,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-    code[r] = i < nfin ? (keys[i] >> ibits) : 0ull;
+    code[r] = i < nfin ? unrank(keys[i] >> ibits) : 0ull;
   }
-  uint64_t carry = (lane == 0 && wbase > 0 && wbase < nfin) ? (keys[wbase - 1] >> ibits) : 0ull;  // key before the segment
+  uint64_t carry = (lane == 0 && wbase > 0 && wbase < nfin) ? unrank(keys[wbase - 1] >> ibits) : 0ull;  // key before the segment
   uint64_t wave_tot = 0;
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
@@ -2067,7 +2126,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, a.need_index, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
+                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
   PCC_STAMP("k_make_keys");

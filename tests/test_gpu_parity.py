@@ -347,6 +347,36 @@ def test_indexed_keys_match_bare_keys(pkg, oracle, monkeypatch):
             c.close()
 
 
+def test_cell_ranks_save_a_sort_pass_and_change_nothing(pkg, oracle, monkeypatch):
+    """A capture-like cloud (1024-voxel lattice) that straddles a high power-of-two boundary of its adaptive box varies in
+    13 key bits per axis: 39 code bits, five sort passes.  The sorted code carries the rank of the 2^m-cell instead of the
+    high bits (FrameState::code_low_bits): four passes, the same bytes.  PCC_NO_CELL_RANKS=1 sorts the full code."""
+    import ctypes as C
+    b = pkg.binding
+    lib = b.load_library()
+    lib.pcc_debug_sort_plan.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    pts = pkg.synthetic.make_frame("cfg3v", n=200_000)
+    rng = np.random.default_rng(5)
+    clouds = [pts, cloud(pkg, (rng.uniform(0.0, 1.0, (60_000, 3)) * 0.23 + 0.38).astype(np.float32))]
+    plans = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PCC_NO_CELL_RANKS", mode)
+        c = b.Context(0)
+        try:
+            for k, p in enumerate(clouds):
+                for kw in (dict(octree_bits=10, color_coding_type=1), dict(octree_bits=10, color_coding_type=0, keep_centroid=1), dict(octree_bits=11, color_bits=0)):
+                    assert_matches_oracle(pkg, oracle, c, p, **kw)
+                    plan = (C.c_int32 * 5)()
+                    assert lib.pcc_debug_sort_plan(c.h, plan) == 0
+                    plans.setdefault(mode, []).append(list(plan))
+        finally:
+            c.close()
+    for ranked, plain in zip(plans["0"], plans["1"]):
+        assert plain[1] == plain[2] and ranked[2] == plain[2]      # the plain plan sorts every varying bit
+        assert ranked[0] <= plain[0] and ranked[1] <= plain[1]
+    assert any(r[0] < p[0] for r, p in zip(plans["0"], plans["1"]))  # and at least the capture-like cloud saves a pass
+
+
 def test_cpp_shim_example_runs(pkg):
     """The reference-style C++ caller built against the drop-in header (g++ only) runs end to end."""
     import os
