@@ -585,11 +585,11 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         mort = morton3(((kmin[0] >> cm) + dx) & hm, ((kmin[1] >> cm) + dy) & hm, ((kmin[2] >> cm) + dz) & hm);
       }
       unsigned rank = 0;
-      for (int j = 0; j < 64; ++j) {
-        const uint64_t other = __shfl(mort, j);
+      for (unsigned j = 0; j < nc && nc > 1u; ++j) {  // (one cell: no ranks, nobody reads the tables)
+        const uint64_t other = __shfl(mort, (int)j);
         rank += (other < mort) ? 1u : 0u;
       }
-      if ((unsigned)i < nc) { st->cell_rank[i] = (uint8_t)rank; st->cell_abs[rank] = mort; }
+      if ((unsigned)i < nc && nc > 1u) { st->cell_rank[i] = (uint8_t)rank; st->cell_abs[rank] = mort; }
       if (i < 3) { st->cell_base[i] = kmin[i] >> cm; st->cell_dim[i] = cdim[i]; }
       if (i == 0) { st->code_low_bits = cm; st->code_bits = cbits; }
     }
