@@ -332,7 +332,7 @@ def main():
             "path_sum_of_kernel_spans_ms": round(sum_spans, 5),
             "path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
             "path_frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-            "frames_in_flight_in_timed_region": int(min(pipe.workers, 10)),
+            "frames_in_flight_in_timed_region": int(os.environ.get("PCC_PIPELINE_GPU_THREADS") or min(pipe.workers, 12)),
             "kernel_avg_ms_sharing_the_gpu": round(shared.get(dominant, 0.0), 5) if shared else None,
         }
 
