@@ -1301,8 +1301,12 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   const uint32_t L = st->n_leaves;
   if (L == 0 || st->error != kErrNone) return;  // after an error upstream the leaf arrays are not to be trusted
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
-  const uint32_t br = blockIdx.x;              // block row: image rows [8 br, 8 br + 8)
-  if (8u * br >= H) return;
+  // Block row: image rows [8 br, 8 br + 8).  Workgroups go to the XCDs round robin (workgroup b to XCD b % 8), and a
+  // block row looks at the leaf records just before its own (parent search): every XCD takes one contiguous range of
+  // the block rows in use, so that those records are in its own L2 already instead of being fetched a second time.
+  const uint32_t rows_used = (H + 7u) / 8u, rows_per_xcd = (rows_used + 7u) / 8u;
+  const uint32_t br = lp.linear_rows ? blockIdx.x : (blockIdx.x & 7u) * rows_per_xcd + (blockIdx.x >> 3);
+  if ((!lp.linear_rows && (blockIdx.x >> 3) >= rows_per_xcd) || 8u * br >= H) return;
   const uint32_t full = H / 8u, hl = H % 8u;
   const uint32_t pos0 = 2048u * br, npos = br < full ? 2048u : 256u * hl;  // leaf positions [pos0, pos0 + npos) fill this block row (br <= full here)
   const uint32_t nl = min(npos, L - pos0);                  // real leaves among them (pos0 <= L always)
@@ -2161,7 +2165,10 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
-  hipLaunchKernelGGL(k_leaf_tile, dim3((max_h + 7u) / 8u), dim3(kFinThreads), 0, stream, a.pv, a.res, a.lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
+  static const bool linear_rows = [] { const char* e = getenv("PCC_LEAF_ROWS"); return e && !strcmp(e, "linear"); }();
+  LeafParams lp = a.lp;
+  lp.linear_rows = linear_rows ? 1u : 0u;
+  hipLaunchKernelGGL(k_leaf_tile, dim3(((max_h + 7u) / 8u + 7u) / 8u * 8u), dim3(kFinThreads), 0, stream, a.pv, a.res, lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
                      a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
                      reinterpret_cast<float4*>(a.simplified), span("k_leaf_tile"));
   PCC_STAMP("k_leaf_tile");
