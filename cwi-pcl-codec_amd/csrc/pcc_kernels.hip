@@ -80,48 +80,71 @@ __device__ __forceinline__ uint64_t morton3(uint32_t kx, uint32_t ky, uint32_t k
   return (split3(kx) << 2) | (split3(ky) << 1) | split3(kz);
 }
 
-__device__ __forceinline__ float wave_min_f(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+// ---- wave-wide reductions and scans through DPP: lanes read each other's registers inside the VALU (a __shfl is a
+//      ds_bpermute, an LDS round trip of a hundred cycles or more per step, six steps per reduction; these run in the
+//      latency-bound stretches of every kernel: digit scans of the sort pass, the replay workgroup of k_boxes_events).
+//      All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t identity, uint32_t v) {  // lanes without a source keep `identity`
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive scan over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2 into
+// rows 1 and 3 (row_bcast:15), then lane 31 into the upper half (row_bcast:31)
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, uint32_t id, Op op) {
+  v = op(v, dpp_mov<0x111, 0xf>(id, v));
+  v = op(v, dpp_mov<0x112, 0xf>(id, v));
+  v = op(v, dpp_mov<0x114, 0xf>(id, v));
+  v = op(v, dpp_mov<0x118, 0xf>(id, v));
+  v = op(v, dpp_mov<0x142, 0xa>(id, v));
+  v = op(v, dpp_mov<0x143, 0xc>(id, v));
   return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
+  const uint32_t lo = dpp_mov<CTRL, ROW_MASK>(0u, (uint32_t)v), hi = dpp_mov<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+  return v + (((uint64_t)hi << 32) | lo);
+}
+// lane `l` of v for everybody, l uniform: v_readlane (a __shfl with a uniform index is still a ds_bpermute)
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float lane_of(float v, int l) { return __uint_as_float(lane_of(__float_as_uint(v), l)); }
+__device__ __forceinline__ uint64_t lane_of(uint64_t v, int l) { return ((uint64_t)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l); }
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint64_t lane63(uint64_t v) { return ((uint64_t)lane63((uint32_t)(v >> 32)) << 32) | lane63((uint32_t)v); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  return wave_scan_u32(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+}
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+  v = dpp_add_u64<0x111, 0xf>(v);
+  v = dpp_add_u64<0x112, 0xf>(v);
+  v = dpp_add_u64<0x114, 0xf>(v);
+  v = dpp_add_u64<0x118, 0xf>(v);
+  v = dpp_add_u64<0x142, 0xa>(v);
+  v = dpp_add_u64<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_incl_scan_u32(v); }
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v) { return wave_incl_scan_u64(v); }
+__device__ __forceinline__ float wave_min_f(float v) {
+  const uint32_t r = wave_scan_u32(__float_as_uint(v), __float_as_uint(FLT_MAX),
+                                   [](uint32_t a, uint32_t b) { return __float_as_uint(fminf(__uint_as_float(a), __uint_as_float(b))); });
+  return __uint_as_float(lane63(r));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  const uint32_t r = wave_scan_u32(__float_as_uint(v), __float_as_uint(-FLT_MAX),
+                                   [](uint32_t a, uint32_t b) { return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b))); });
+  return __uint_as_float(lane63(r));
 }
 __device__ __forceinline__ int wave_min_i(int v) {
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
+  return (int)lane63(wave_scan_u32((uint32_t)v, 0x7fffffffu, [](uint32_t a, uint32_t b) { return (uint32_t)min((int)a, (int)b); }));
 }
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-// inclusive scan inside a wave
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
-  const int lane = lane_id();
-  for (int o = 1; o < 64; o <<= 1) {
-    uint64_t u = __shfl_up(v, o);
-    if (lane >= o) v += u;
-  }
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  const int lane = lane_id();
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t u = __shfl_up(v, o);
-    if (lane >= o) v += u;
-  }
-  return v;
-}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return lane63(wave_incl_scan_u64(v)); }
 // block-wide exclusive scan of one value per thread (NW wave64 per workgroup); `total` = block sum
 template <int NW, typename T>
 __device__ __forceinline__ T block_excl_scan(T v, T* s_wave /*[NW]*/, T& total) {
-  T incl = v;
+  const T incl = wave_incl_scan(v);
   const int lane = lane_id();
-  for (int o = 1; o < 64; o <<= 1) {
-    const T u = __shfl_up(incl, o);
-    if (lane >= o) incl += u;
-  }
   if (lane == 63) s_wave[wave_id()] = incl;
   __syncthreads();
   T off = 0, tot = 0;
@@ -206,17 +229,22 @@ __device__ __forceinline__ void publish_box(uint64_t* dst, const ChunkBox& b, ui
 #pragma unroll
   for (int k = 0; k < kBoxWords; ++k) publish_u64(dst + k, ((uint64_t)seq << 32) | v[k]);
 }
-__device__ __forceinline__ bool fetch_box(const uint64_t* src, uint32_t seq, ChunkBox& b) {
+__device__ __forceinline__ bool decode_box(const uint64_t* w, uint32_t seq, ChunkBox& b) {
   uint32_t v[kBoxWords];
   bool all = true;
 #pragma unroll
   for (int k = 0; k < kBoxWords; ++k) {
-    const uint64_t w = poll_u64(src + k);
-    all &= (uint32_t)(w >> 32) == seq;
-    v[k] = (uint32_t)w;
+    all &= (uint32_t)(w[k] >> 32) == seq;
+    v[k] = (uint32_t)w[k];
   }
   __builtin_memcpy(&b, v, sizeof(b));
   return all;
+}
+__device__ __forceinline__ bool fetch_box(const uint64_t* src, uint32_t seq, ChunkBox& b) {
+  uint64_t w[kBoxWords];
+#pragma unroll
+  for (int k = 0; k < kBoxWords; ++k) w[k] = poll_u64(src + k);
+  return decode_box(w, seq, b);
 }
 
 __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n, uint32_t c, uint32_t n_chunks, uint64_t* __restrict__ boxes,
@@ -360,7 +388,33 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     i0 = index;
     cur = box.enabled ? index : index + 1;  // a given box has to be checked against the first point too
   };
-  // all growth events of the loaded chunk from `cur` on (adoptBoundingBoxToPoint, bounding_box_defined_ branch)
+  // adoptBoundingBoxToPoint, bounding_box_defined_ branch: the box doubles towards the point until it holds it
+  // (uniform: every calling thread replays it in its own registers; thread 0 records the events)
+  auto grow_to = [&](float fx, float fy, float fz, int index) {
+    const double p[3] = {(double)fx, (double)fy, (double)fz};
+    for (;;) {
+      bool up[3], any = false;
+      for (int a = 0; a < 3; ++a) { up[a] = p[a] >= mx[a]; any |= (p[a] < mn[a]) | up[a]; }
+      if (!any) break;
+      if (nev >= kMaxEpochs || depth >= 31) { err = kErrEpochs; break; }
+      double side = __dmul_rn((double)(1u << depth), res);
+      int lowered = 0;
+      for (int a = 0; a < 3; ++a)
+        if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
+      if (threadIdx.x == 0) {
+        ev_depth_before[nev] = depth;
+        ev_index[nev] = index;
+        ev_lowered[nev] = lowered;
+        for (int a = 0; a < 3; ++a) ev_mn[nev][a] = mn[a];
+      }
+      ++depth;
+      side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
+      for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
+      ++nev;
+    }
+    float_bounds();
+  };
+  // all growth events of the loaded chunk from `cur` on
 #ifdef PCC_KTIME
   int dbg_round = 0;
 #endif
@@ -381,33 +435,44 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         cur = (loaded + 1) * kTile;
         return;
       }
-      const double p[3] = {(double)s_p[0][emin], (double)s_p[1][emin], (double)s_p[2][emin]};
-      for (;;) {
-        bool up[3], any = false;
-        for (int a = 0; a < 3; ++a) { up[a] = p[a] >= mx[a]; any |= (p[a] < mn[a]) | up[a]; }
-        if (!any) break;
-        if (nev >= kMaxEpochs || depth >= 31) { err = kErrEpochs; break; }
-        double side = __dmul_rn((double)(1u << depth), res);
-        int lowered = 0;
-        for (int a = 0; a < 3; ++a)
-          if (!up[a]) { mn[a] = __dsub_rn(mn[a], side); lowered |= 1 << a; }
-        if (threadIdx.x == 0) {
-          ev_depth_before[nev] = depth;
-          ev_index[nev] = loaded * kTile + emin;
-          ev_lowered[nev] = lowered;
-          for (int a = 0; a < 3; ++a) ev_mn[nev][a] = mn[a];
-        }
-        ++depth;
-        side = __dsub_rn(__dmul_rn((double)(1u << depth), res), eps);
-        for (int a = 0; a < 3; ++a) mx[a] = __dadd_rn(mn[a], side);
-        ++nev;
-      }
-      float_bounds();
+      grow_to(s_p[0][emin], s_p[1][emin], s_p[2][emin], loaded * kTile + emin);
       cur = loaded * kTile + emin + 1;
     }
   };
+  // The same for 64 consecutive elements of the loaded chunk, by wave 0 alone: a lane holds one point, the first
+  // violating lane comes from a ballot and its coordinates from a broadcast -- no LDS round, no barrier per event.
+  // With points in random order the box reaches its final size within the first few dozen points, so this takes
+  // the events that used to cost one block-wide round each.  The other waves pick the state up from LDS.
+  __shared__ double s_state_d[6];
+  __shared__ int s_state_i[4];
+  auto replay_first_lanes = [&]() {
+    const int e0 = max(cur - loaded * kTile, 0);
+    if (wave_id() == 0) {
+      const int e = e0 + lane_id();
+      float x = __builtin_nanf(""), y = x, z = x;
+      if (e < kTile) { x = s_p[0][e]; y = s_p[1][e]; z = s_p[2][e]; }
+      int from = 0;  // lanes below `from` are behind the replay
+      while (err == kErrNone) {
+        const uint64_t viol = __ballot(lane_id() >= from && violates(x, y, z));
+        if (viol == 0ull) break;
+        const int l = __ffsll((long long)viol) - 1;
+        grow_to(lane_of(x, l), lane_of(y, l), lane_of(z, l), loaded * kTile + e0 + l);
+        from = l + 1;
+      }
+      if (lane_id() == 0) {
+        for (int a = 0; a < 3; ++a) { s_state_d[a] = mn[a]; s_state_d[3 + a] = mx[a]; }
+        s_state_i[0] = depth; s_state_i[1] = nev; s_state_i[2] = err;
+      }
+    }
+    __syncthreads();
+    for (int a = 0; a < 3; ++a) { mn[a] = s_state_d[a]; mx[a] = s_state_d[3 + a]; }
+    depth = s_state_i[0]; nev = s_state_i[1]; err = s_state_i[2];
+    float_bounds();
+    cur = loaded * kTile + min(e0 + 64, kTile);
+  };
 
   // ---- early: chunk 0, while the other workgroups read the cloud ----
+  uint64_t pre_w[kBoxWords] = {0, 0, 0, 0, 0, 0, 0, 0};  // (sequence numbers start at 1: all zero = not there)
   load_chunk(0);
   {
     int ce = 0x7fffffff;
@@ -421,6 +486,15 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     PCC_KTR(6, 1);
     if (f != 0x7fffffff) {
       first_box(s_p[0][f], s_p[1][f], s_p[2][f], f);
+      PCC_KTR(8, 5);
+      replay_first_lanes();
+      PCC_KTR(8, 6);
+      // the first chunk box of every thread is requested now and looked at after the block-wide rounds below: by then
+      // the streaming workgroups have usually published, and the sweep starts with its first round trip behind it
+      if (threadIdx.x < n_chunks) {
+#pragma unroll
+        for (int k = 0; k < kBoxWords; ++k) pre_w[k] = poll_u64(boxes + (size_t)threadIdx.x * kBoxWords + k);
+      }
       replay_loaded_chunk();
     }
   }
@@ -442,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     for (;;) {
       while (c < n_chunks) {
         ChunkBox b;
-        if (!fetch_box(boxes + (size_t)c * kBoxWords, seq, b)) break;
+        if (!(c == threadIdx.x && spins == 0 && decode_box(pre_w, seq, b)) && !fetch_box(boxes + (size_t)c * kBoxWords, seq, b)) break;
         if (b.n_finite > 0) {
           first = min(first, b.first_finite);
           nfin += (unsigned)b.n_finite;
@@ -523,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     for (int a = 0; a < 3; ++a) {
       const uint32_t add = (live && (ev_lowered[k] & (1 << a))) ? (1u << ev_depth_before[k]) : 0u;
       const uint32_t incl = wave_incl_scan_u32(add);
-      later[a] = __shfl(incl, 63) - incl;  // growths after event k
+      later[a] = lane63(incl) - incl;  // growths after event k
     }
     if (last_of_run) {
       st->ep_index[w] = ev_index[k];
@@ -586,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       }
       unsigned rank = 0;
       for (unsigned j = 0; j < nc && nc > 1u; ++j) {  // (one cell: no ranks, nobody reads the tables)
-        const uint64_t other = __shfl(mort, (int)j);
+        const uint64_t other = lane_of(mort, (int)j);
         rank += (other < mort) ? 1u : 0u;
       }
       if ((unsigned)i < nc && nc > 1u) { st->cell_rank[i] = (uint8_t)rank; st->cell_abs[rank] = mort; }
@@ -874,7 +948,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
     // values, and 64 lanes ORing into one LDS word would serialise), the others through LDS
     const uint64_t vm = __ballot(valid);
     const int first = vm ? __ffsll((long long)vm) - 1 : 0;
-    const uint32_t d0 = __shfl(d, first);
+    const uint32_t d0 = lane_of(d, first);
     const uint64_t same = __ballot(valid && d == d0);
     const bool via_lds = valid && d != d0;
     if (via_lds) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
@@ -1105,9 +1179,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
     uint64_t prev = __shfl_up(code[r], 1);
     if (lane == 0) prev = carry;
     ht[r] = i < nfin ? head_t(code[r], prev, i == 0, depth) : 0ull;
-    carry = __shfl(code[r], 63);  // lane 0 of the next row compares against the end of this one
+    carry = lane63(code[r]);  // lane 0 of the next row compares against the end of this one
     inc[r] = wave_incl_scan_u64(ht[r]) + wave_tot;
-    wave_tot = __shfl(inc[r], 63);
+    wave_tot = lane63(inc[r]);
   }
   if (lane == 63) s_w[wave] = wave_tot;
   __syncthreads();
@@ -1810,7 +1884,7 @@ __global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(FrameState* st, cons
   if (wave == 0) {  // exclusive scan of the 96 block lengths
     const uint32_t l0 = s_blen[lane], l1 = lane < 32 ? s_blen[64 + lane] : 0u;
     const uint32_t i0 = wave_incl_scan_u32(l0);
-    const uint32_t t0 = __shfl(i0, 63);
+    const uint32_t t0 = lane63(i0);
     const uint32_t i1 = wave_incl_scan_u32(l1);
     s_boff[lane] = i0 - l0;
     if (lane < 32) s_boff[64 + lane] = t0 + i1 - l1;
