@@ -109,6 +109,11 @@ __device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
 __device__ __forceinline__ uint32_t lane_of(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ float lane_of(float v, int l) { return __uint_as_float(lane_of(__float_as_uint(v), l)); }
 __device__ __forceinline__ uint64_t lane_of(uint64_t v, int l) { return ((uint64_t)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l); }
+// the value of the lane below (wave_shr:1); lane 0 keeps its own `first`
+__device__ __forceinline__ uint64_t wave_shr1(uint64_t v, uint64_t first) {
+  const uint32_t lo = dpp_mov<0x138, 0xf>((uint32_t)first, (uint32_t)v), hi = dpp_mov<0x138, 0xf>((uint32_t)(first >> 32), (uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ uint64_t lane63(uint64_t v) { return ((uint64_t)lane63((uint32_t)(v >> 32)) << 32) | lane63((uint32_t)v); }
 
@@ -1176,8 +1181,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-    uint64_t prev = __shfl_up(code[r], 1);
-    if (lane == 0) prev = carry;
+    const uint64_t prev = wave_shr1(code[r], carry);  // the key of the lane before; lane 0: the end of the row before
     ht[r] = i < nfin ? head_t(code[r], prev, i == 0, depth) : 0ull;
     carry = lane63(code[r]);  // lane 0 of the next row compares against the end of this one
     inc[r] = wave_incl_scan_u64(ht[r]) + wave_tot;
