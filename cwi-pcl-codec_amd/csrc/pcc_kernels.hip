@@ -829,8 +829,20 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
   const uint32_t g = threadIdx.x / kDtCols;
   const uint32_t per = (n_rows + kDtGroups - 1u) / kDtGroups;
   const uint32_t r0 = min(g * per, n_rows), r1 = min(r0 + per, n_rows);
+  // The narrow shape serves frames of up to 512 tiles: a thread's rows (at most 32) are requested together and stay in
+  // registers for the prefixes of pass 0 below, instead of a walk with a load per step and a second walk over the same rows.
+  constexpr uint32_t kHeld = kDtThreads == 256 ? 32u : 1u;
+  const bool held = kDtThreads == 256 && per <= kHeld;
+  uint32_t mine[kHeld];
   uint32_t acc = 0;
-  for (uint32_t r = r0; r < r1; ++r) acc += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
+  if (held) {
+#pragma unroll
+    for (uint32_t k = 0; k < kHeld; ++k) mine[k] = (r0 + k < r1) ? hist_rows[(size_t)(r0 + k) * kMaxPasses * kMaxBins + col] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kHeld; ++k) acc += mine[k];
+  } else {
+    for (uint32_t r = r0; r < r1; ++r) acc += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
+  }
   s_part[g][c] = acc;
   __syncthreads();
   uint32_t before = 0, all = 0;
@@ -840,7 +852,14 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
     all += v;
   }
   if (g == 0) digit_tot[col] = all;
-  if (pass == 0) {
+  if (pass == 0 && held) {
+    uint32_t run = before;
+#pragma unroll
+    for (uint32_t k = 0; k < kHeld; ++k) {
+      if (r0 + k < r1) tile_prefix0[(size_t)(r0 + k) * kMaxBins + col] = run;
+      run += mine[k];
+    }
+  } else if (pass == 0) {
     uint32_t run = before;
     for (uint32_t r = r0; r < r1; ++r) {
       tile_prefix0[(size_t)r * kMaxBins + col] = run;
