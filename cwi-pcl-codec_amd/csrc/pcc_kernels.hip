@@ -1760,6 +1760,11 @@ __global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(FrameState* st, cons
     const uint32_t* src = reinterpret_cast<const uint32_t*>(image + (size_t)16u * m * 768u);
     for (uint32_t k = threadIdx.x; k < ndw; k += kJpegThreads) reinterpret_cast<uint32_t*>(s_img)[k] = src[k];
   }
+  if (jpeg_tiles) {  // what stage C needs from global memory travels together with the image rows
+    for (int k = threadIdx.x; k < kJpegTileWords; k += kJpegThreads) s_hbits[k] = 0u;
+    for (int k = threadIdx.x; k < 24; k += kJpegThreads) s_hdc[k] = (&huff->dc[0][0])[k];
+    for (int k = threadIdx.x; k < 512; k += kJpegThreads) s_hac[k] = (&huff->ac[0][0])[k];
+  }
   __syncthreads();
   PCC_KTR(7, 4);
 
@@ -1844,10 +1849,6 @@ __global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(FrameState* st, cons
   // ---- C: Huffman coding of the 96 blocks (jchuff.c encode_one_block), one wave per block, lane = zigzag
   // index.  The row's bit string is assembled in LDS; the DC codes of the first Y, Cb and Cr block depend on
   // the MCU row before and are left to the host, which stitches the rows together.
-  for (int k = threadIdx.x; k < kJpegTileWords; k += kJpegThreads) s_hbits[k] = 0u;
-  for (int k = threadIdx.x; k < 24; k += kJpegThreads) s_hdc[k] = (&huff->dc[0][0])[k];
-  for (int k = threadIdx.x; k < 512; k += kJpegThreads) s_hac[k] = (&huff->ac[0][0])[k];
-  __syncthreads();
   constexpr int kBlocksPerWave = 96 / (kJpegThreads / 64);  // 6
   uint64_t hb[kBlocksPerWave];
   uint32_t hlen[kBlocksPerWave], ho[kBlocksPerWave];
