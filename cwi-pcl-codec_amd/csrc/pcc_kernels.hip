@@ -1500,7 +1500,14 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   // requested at the top of the kernel (s_probe); the last round takes a whole range of <= 256 leaves at once,
   // four per lane, together with their stream offsets, so that a level costs two dependent round trips.
   if (nl && pos0) {
-    for (int v = wave + 1; v <= D; v += kFinThreads / 64) {
+    // a leaf with t nodes of its own asks for the level-(t + 1) parent: levels beyond the tile's largest t + 1 are never
+    // looked at (2048 consecutive leaves rarely open a node more than five or six levels up, so one round of waves does it)
+    int vtop = 0;
+    {
+      const uint64_t any = __ballot(lane >= 1 && lane <= D && s_slotbits[lane] != 0ull);
+      vtop = any ? 64 - __clzll((long long)any) : 1;  // largest t in the tile, + 1
+    }
+    for (int v = wave + 1; v <= min(D, vtop); v += kFinThreads / 64) {
       const int sh = 3 * v;
       const uint64_t pcode = sh >= 64 ? 0ull : ((code0 >> sh) << sh);
       // invariant: the answer (first leaf with code >= pcode) lies in [lo, hi]; leaf hi has code >= pcode
