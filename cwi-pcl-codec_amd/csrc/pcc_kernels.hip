@@ -301,6 +301,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     b.n_finite = cc;
     publish_box(boxes + (size_t)c * kBoxWords, b, seq);
   }
+  PCC_KTR(6, 7);
 }
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,

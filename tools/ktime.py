@@ -47,5 +47,8 @@ print("k_leaf_tile A1 (median us since kernel start): first barrier, records lan
 x8 = t[8, 0, :8]
 x = t[6, 0, :7]
 print("k_boxes_events replay rounds (us since start, after each block-wide minimum):", np.round((x8 - x[0]) / 100.0, 2))
+nb = (len(pts) + 2047) // 2048 + 1
+pub = (t[6, 1:nb, 7] - x[0]) / 100.0
+print("k_boxes_events, streaming workgroups: box published (us since workgroup 0 started): min %.2f median %.2f max %.2f" % (pub.min(), np.median(pub), pub.max()))
 print("k_boxes_events, workgroup 0, stamps (us): start, first point found, chunk 0 replayed, chunk boxes all there, sweep done, events done, end:", np.round((x - x[0]) / 100.0, 2))
 ctx.close()
