@@ -45,7 +45,7 @@ EXPORTS = [
     "pcc_entropy_batch_create", "pcc_entropy_batch_destroy", "pcc_entropy_batch_size", "pcc_entropy_batch_capacity",
     "pcc_entropy_batch_add", "pcc_entropy_batch_flush", "pcc_entropy_batch_last_error",
     "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
-    "pcc_host_range_encode", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
+    "pcc_host_range_encode", "pcc_host_range_encode_many", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position", "pcc_normalize_group", "pcc_normalize_group_boxes", "pcc_restore_scaling",
 ]
 
@@ -227,6 +227,7 @@ def load_library():
     lib.pcc_host_rigid_decompress.argtypes = [vp, sz, vp]
     lib.pcc_host_range_encode.restype = sz
     lib.pcc_host_range_encode.argtypes = [vp, sz, vp, sz]
+    lib.pcc_host_range_encode_many.argtypes = [i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     lib.pcc_host_range_decode.restype = sz
     lib.pcc_host_range_decode.argtypes = [vp, sz, vp, sz]
     lib.pcc_host_jpeg_encode.restype = sz
@@ -750,6 +751,23 @@ def host_range_encode(data: bytes) -> bytes:
     out = np.zeros(len(src) * 2 + 2048, dtype=np.uint8)
     n = lib.pcc_host_range_encode(src.ctypes.data if len(src) else None, len(src), out.ctypes.data, len(out))
     return out[:n].tobytes()
+
+
+def host_range_encode_many(vectors) -> list:
+    """Up to four vectors coded in one loop (pcc_host_range_encode_many): the bytes of each are those of host_range_encode."""
+    lib = load_library()
+    k = len(vectors)
+    srcs = [np.frombuffer(v, dtype=np.uint8) for v in vectors]
+    outs = [np.zeros(len(s) * 2 + 2048, dtype=np.uint8) for s in srcs]
+    inp = (C.c_void_p * k)(*[s.ctypes.data if len(s) else None for s in srcs])
+    n = (C.c_size_t * k)(*[len(s) for s in srcs])
+    outp = (C.c_void_p * k)(*[o.ctypes.data for o in outs])
+    cap = (C.c_size_t * k)(*[len(o) for o in outs])
+    got = (C.c_size_t * k)()
+    rc = lib.pcc_host_range_encode_many(k, inp, n, outp, cap, got)
+    if rc != 0:
+        raise PccError(rc, "pcc_host_range_encode_many")
+    return [outs[i][:got[i]].tobytes() for i in range(k)]
 
 
 def host_range_decode(stream: bytes, n: int):

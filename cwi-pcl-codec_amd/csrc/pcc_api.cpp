@@ -1527,6 +1527,24 @@ size_t pcc_host_range_encode(const uint8_t* in, size_t n, uint8_t* out, size_t o
   memcpy(out, b.data(), b.size());
   return b.size();
 }
+int pcc_host_range_encode_many(int count, const uint8_t* const* in, const size_t* n, uint8_t* const* out, const size_t* out_cap,
+                               size_t* out_len) {
+  if (count < 1 || count > StaticRangeCoder::kMaxStreams || !in || !n || !out || !out_cap || !out_len) return PCC_ERR_ARG;
+  try {
+    Bytes b[StaticRangeCoder::kMaxStreams];
+    Bytes* dst[StaticRangeCoder::kMaxStreams];
+    size_t got[StaticRangeCoder::kMaxStreams];
+    for (int i = 0; i < count; ++i) dst[i] = &b[i];
+    StaticRangeCoder::encode_many(count, in, n, dst, got);
+    for (int i = 0; i < count; ++i) {
+      out_len[i] = b[i].size() <= out_cap[i] ? b[i].size() : 0;
+      if (out_len[i]) memcpy(out[i], b[i].data(), b[i].size());
+    }
+  } catch (const std::bad_alloc&) {
+    return PCC_ERR_HIP;  // out of memory
+  }
+  return PCC_OK;
+}
 size_t pcc_host_range_decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t n) {
   return StaticRangeCoder::decode(in, in_len, out, n);
 }

@@ -123,11 +123,15 @@ struct RcStream {
 #define PCC_RC_STEP(S)                                                                              \
   {                                                                                                 \
     const uint64_t fw = sb[S].fw[in##S[i]];                                                         \
-    range##S = (uint32_t)(((unsigned __int128)sb[S].magic * range##S) >> 64); /* range /= total */  \
-    low##S += (uint32_t)fw * range##S;                                                              \
-    range##S *= (uint32_t)(fw >> 32);                                                               \
+    const uint64_t r_ = (uint64_t)(((unsigned __int128)sb[S].magic * range##S) >> 64); /* range / total */ \
+    /* start * r and size * r in ONE 64-bit multiply: fw = start | size << 32, and start * r <= (start + size) * r <= range  \
+       < 2^32, so the low product does not carry into the high one (the loop of three or four streams is bound by the       \
+       multiplier, not by a chain of dependent operations) */                                       \
+    const uint64_t pr_ = fw * r_;                                                                   \
+    low##S += (uint32_t)pr_;                                                                        \
+    range##S = (uint32_t)(pr_ >> 32);                                                               \
     const uint32_t x = low##S ^ (low##S + range##S);                                                \
-    const unsigned k = (unsigned)__builtin_clz(x | 1u) >> 3;                                        \
+    const unsigned k = (unsigned)_lzcnt_u32(x) >> 3; /* x != 0: range > 0 */                           \
     const uint32_t be = __builtin_bswap32(low##S);                                                  \
     memcpy(p##S, &be, 4);                                                                           \
     p##S += k;                                                                                      \
@@ -184,7 +188,7 @@ struct RcStream {
     const uint64_t phi = (uint64_t)(prod >> 64), plo = (uint64_t)prod >> 1;                         \
     (void)top3_;                                                                                    \
     const uint32_t x = low##S ^ (TOP);                                                              \
-    const unsigned sh = (unsigned)_lzcnt_u32(x | 1u) & 0x38u; /* 8 * settled bytes */               \
+    const unsigned sh = (unsigned)_lzcnt_u32(x) & 0x38u; /* 8 * settled bytes; x != 0: range > 0 */  \
     const uint32_t be = __builtin_bswap32(low##S);                                                  \
     memcpy(p##S, &be, 4);                                                                           \
     p##S += sh >> 3;                                                                                \

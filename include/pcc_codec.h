@@ -399,6 +399,12 @@ const char *pcc_entropy_batch_last_error(pcc_entropy_batch *b);
  * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */
 size_t pcc_host_range_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap);
 size_t pcc_host_range_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t n);
+/* The same coder for up to four independent vectors in ONE loop -- how the entropy stage codes the streams of the frames
+ * it holds (a lone coder is a chain of dependent operations and leaves most of a core idle).  Every out[i] gets exactly the
+ * bytes pcc_host_range_encode gives for in[i]; out_len[i] = encoded size, 0 if out_cap[i] is too small.  Returns PCC_OK,
+ * or PCC_ERR_ARG for count outside 1..4. */
+int pcc_host_range_encode_many(int count, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
+                               const size_t *out_cap, size_t *out_len);
 /* JPEGWriter::writeJPEG / JPEGReader::readJPEG (jpeg_io.hpp:211-330 / 90-192), RGB, 4:2:0 */
 size_t pcc_host_jpeg_encode(const uint8_t *rgb, int w, int h, int quality, uint8_t *out, size_t out_cap);
 int pcc_host_jpeg_decode(const uint8_t *jpg, size_t len, uint8_t *rgb, size_t rgb_cap, int *w, int *h);

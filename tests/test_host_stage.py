@@ -59,6 +59,33 @@ def test_range_coder_matches_oracle(pkg, oracle, n, kind):
     assert dec == data and used == len(enc)
 
 
+@pytest.mark.parametrize("lengths", [(5_000,), (70_000, 3), (0, 9_000), (12_345, 12_345, 700), (66_000, 1, 0, 40_000), (300, 200, 100, 70_001)])
+def test_range_coders_sharing_a_loop_match_oracle(pkg, oracle, lengths):
+    """The entropy stage codes up to four vectors in one loop (three and four: one multiply yields both the new low and
+    the new range; one and two: the short dependency chain); ragged lengths walk through every hand-over between the
+    loops.  Each vector must come out as the oracle codes it alone -- including a table that needs the 2^16 rescale and
+    vectors long enough for the rare range-underflow branch."""
+    rng = np.random.default_rng(sum(lengths) + len(lengths))
+    vectors = []
+    for k, n in enumerate(lengths):
+        if k % 2 == 0:  # occupancy-like: one to three bits set
+            bits = rng.integers(0, 8, (n, 3))
+            keep = rng.random((n, 3)) < np.array([1.0, 0.45, 0.15])
+            v = np.bitwise_or.reduce(np.where(keep, 1 << bits, 0), axis=1).astype(np.uint8)
+        else:
+            v = np.minimum(rng.geometric(0.08, n), 255).astype(np.uint8)
+        vectors.append(v.tobytes())
+    got = pkg.binding.host_range_encode_many(vectors)
+    for v, g in zip(vectors, got):
+        assert g == oracle.rc_encode(v)
+        assert g == pkg.binding.host_range_encode(v)
+
+
+def test_range_encode_many_refuses_bad_counts(pkg):
+    with pytest.raises(pkg.binding.PccError):
+        pkg.binding.host_range_encode_many([b"ab"] * 5)
+
+
 def test_jpeg_matches_libjpeg_turbo_golden(pkg):
     z = np.load(os.path.join(GOLDEN, "jpeg_golden.npz"))
     n = len([k for k in z.files if k.startswith("in_")])
