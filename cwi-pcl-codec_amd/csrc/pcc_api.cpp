@@ -147,7 +147,7 @@ struct pcc_ctx {
   int jpeg_on_gpu = 2;  // 0 host JPEG, 1 coefficients from the GPU, 2 Huffman-coded MCU rows from the GPU
   bool copy_image = true;
   std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
-  std::vector<pcc_point_xyzrgb> dec_points;  // decodePointCloud()
+  PointVec dec_points;  // decodePointCloud()
   // decodePointCloud with the data-parallel half on the GPU (pcc_decode_intra_gpu)
   FrameStreams dec_streams;
   LeafParents dec_parents;

@@ -15,6 +15,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 
 namespace pcc {
 
@@ -352,6 +355,31 @@ size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, 
     out[i] = (uint8_t)sym;
     low += freq[sym] * range;
     range *= freq[sym + 1] - freq[sym];
+    if (range == 0) return 0;  // a symbol of width zero: corrupt table or stream (PCL's loop would never end)
+    // PCL's loop takes one byte per turn while the top byte of the interval is settled; as in the encoder, the number of
+    // settled bytes is the number of leading zero BYTES of low ^ (low + range): they are taken in one step without a branch
+    // (the loop's trip count is as good as random, a mispredicted branch per symbol otherwise).  Near the end of the input,
+    // and when the range underflows with the top byte still open, the loop runs as PCL writes it.
+    if (__builtin_expect(pos + 4 <= in_len, 1)) {
+      const uint32_t x = low ^ (low + range);
+      const unsigned sh = (unsigned)_lzcnt_u32(x) & 0x38u;  // 8 * settled bytes (x != 0 because range != 0)
+      uint32_t next4;
+      memcpy(&next4, in + pos, 4);
+      next4 = __builtin_bswap32(next4);
+      code = (uint32_t)((((uint64_t)code << 32) | next4) >> (32u - sh));
+      low = (uint32_t)((uint64_t)low << sh);
+      range = (uint32_t)((uint64_t)range << sh);
+      pos += sh >> 3;
+      if (__builtin_expect(range >= kBottom, 1)) continue;
+      range = (0u - low) & (kBottom - 1);
+      {
+        const uint8_t b = pos < in_len ? in[pos] : 0;
+        ++pos;
+        code = (code << 8) | b;
+        range <<= 8;
+        low <<= 8;
+      }
+    }
     for (;;) {
       if ((low ^ (low + range)) >= kTop) {
         if (range >= kBottom) break;
@@ -1396,7 +1424,24 @@ struct Reader {
 };
 }  // namespace
 
-int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too) {
+namespace {
+// PCC_DECODE_TRACE=1: where the host decoder spends its time (stderr)
+struct DecodeTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  DecodeTrace() : on(getenv("PCC_DECODE_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pcc decode] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
+
+int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too,
+                         const std::function<void()>& after_occupancy) {
+  DecodeTrace tr;
   memset(&info, 0, sizeof(info));
   Reader r{stream, len, 0};
   if (!r.sync(kV2Id) || !r.sync(kV1Id)) return PCC_ERR_STREAM;
@@ -1450,6 +1495,10 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   size_t used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, occ.data(), occ.size());
   if (!used) return PCC_ERR_STREAM;
   r.pos += used;
+  tr.lap("occupancy range decoder");
+  fs.count = count;
+  fs.with_color = with_color != 0;
+  if (after_occupancy) after_occupancy();
   Bytes& cen = fs.cen;
   cen.clear();
   if (p.do_voxel_centroid) {
@@ -1471,17 +1520,30 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, payload.data(), payload.size());
     if (!used) return PCC_ERR_STREAM;
     r.pos += used;
+    tr.lap("colour range decoder");
     if (!colours_too && cct == 1) {
       // the caller takes the JPEG from fs.payload (the GPU decoder: inverse DCT, upsampling and un-snaking on the device)
     } else if (cct == 1) {  // decodeJPEGSnake (jpegcc.h:228-242)
       Bytes img;
       int w = 0, h = 0;
-      if (BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h) && w % 8 == 0) {
+      const bool jpeg_ok = BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h);
+      tr.lap("jpeg decoder");
+      if (jpeg_ok && w % 8 == 0) {
         col.resize(img.size());
         const uint64_t npix = (uint64_t)w * (uint64_t)h;  // < 2^32 (two 16-bit fields of the frame header)
-        for (uint64_t i = 0; i < npix; ++i) {
-          const uint32_t px = snake_position((uint32_t)i, (uint32_t)w, (uint32_t)h);
-          col[3 * i] = img[3 * px]; col[3 * i + 1] = img[3 * px + 1]; col[3 * i + 2] = img[3 * px + 2];
+        // the snake walks the image in runs of eight pixels of one row, forwards or backwards (snake.h:46-71; w is a
+        // multiple of 8): one position and one direction per run instead of a closed form with divisions per pixel
+        for (uint64_t i = 0; i < npix; i += 8) {
+          const uint32_t p0 = snake_position((uint32_t)i, (uint32_t)w, (uint32_t)h);
+          const uint32_t p1 = snake_position((uint32_t)i + 1u, (uint32_t)w, (uint32_t)h);
+          if (p1 == p0 + 1u) {
+            memcpy(&col[3 * i], &img[3 * (size_t)p0], 24);
+          } else {
+            for (uint32_t c = 0; c < 8; ++c) {
+              const size_t px = (size_t)p0 - c;
+              col[3 * (i + c)] = img[3 * px]; col[3 * (i + c) + 1] = img[3 * px + 1]; col[3 * (i + c) + 2] = img[3 * px + 2];
+            }
+          }
         }
       }
     } else if (cct == 2) {  // decodeJPEGLines (jpegcc.h:319-344)
@@ -1500,6 +1562,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
       col.swap(payload);
     }
   }
+  tr.lap("colours in voxel order");
   info.consumed = r.pos;
   fs.count = count;
   fs.with_color = with_color != 0;
@@ -1513,6 +1576,10 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
 int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents& lp) {
   lp.prefix.clear(); lp.bits.clear(); lp.first.clear();
   if (D == 0 || D > 21 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
+  {  // a level-(D-1) node holds at least one voxel and is one byte of the stream
+    const size_t most = (size_t)std::min<uint64_t>(count, occ.size());
+    lp.prefix.reserve(most); lp.bits.reserve(most); lp.first.reserve(most);
+  }
   uint8_t rem[24];
   int sp = 0;
   size_t op = 0;
@@ -1539,31 +1606,55 @@ int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents&
 }
 
 
-int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info) {
-  points.clear();
-  FrameStreams fs;
-  {
-    const int rc = decode_frame_streams(stream, len, info, fs, true);
-    if (rc != PCC_OK) return rc;
+namespace {
+// deserializeTreeCallback (impl.hpp:1584-1653), position part: centre of the voxel (impl.hpp:1630-1632) or, with a
+// centroid stream, lower corner + the decoded offset (ptv2.h:115-117)
+inline void voxel_position(pcc_point_xyzrgb& np, const uint32_t key[3], double res, const double* bbox, const uint8_t* cen3) {
+  float xyz[3];
+  for (int a = 0; a < 3; ++a) {
+    if (cen3) {
+      const double lc = (double)key[a] * res + bbox[a];
+      xyz[a] = (float)(lc + (float)cen3[a] * 0.001f);
+    } else {
+      xyz[a] = (float)(((double)key[a] + 0.5) * res + bbox[a]);
+    }
   }
-  const pcc_params& p = info.params;
-  const uint64_t count = fs.count;
-  const bool with_color = fs.with_color;
-  const uint32_t cct = fs.cct;
-  const double res = p.octree_resolution;
-  const Bytes &occ = fs.occ, &cen = fs.cen, &col = fs.col;
-  const uint64_t occ_n = occ.size();
-  // deserializeTree: pre-order walk with an explicit stack (Appendix B), leaves in Morton order
-  if (count > 8 * occ_n) return PCC_ERR_STREAM;  // a tree of occ_n branch nodes has at most eight leaves per node: corrupt header
-  points.resize((size_t)count);
-  const unsigned D = info.depth;
-  const unsigned shift = (cct == 0) ? (unsigned)(8 - p.color_bit_resolution) & 7u : 0u;
+  np.x = xyz[0]; np.y = xyz[1]; np.z = xyz[2]; np.w = 1.0f;
+  np.pad[0] = np.pad[1] = np.pad[2] = 0u;
+}
+
+// Positions of all voxels, leaves in Morton order.  Depth <= 21: the walk only visits branch nodes (walk_leaf_parents);
+// a parent's key comes out of its 3-bits-per-level path with three bit extractions and its voxels are its set bits in
+// ascending order.  Deeper trees (keys beyond 63 path bits): the plain pre-order walk with an explicit stack (Appendix B).
+int voxel_positions(const Bytes& occ, const Bytes& cen, bool centroids, unsigned D, double res, const double* bbox, PointVec& points) {
+  const size_t count = points.size();
+  if (D == 0 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
+  if (D <= 21) {
+    DecodeTrace wt;
+    LeafParents lp;
+    const int rc = walk_leaf_parents(occ, D, count, lp);
+    if (rc != PCC_OK) return rc;
+    wt.lap("  walk over the branch nodes");
+    const size_t np_ = lp.bits.size();
+    for (size_t i = 0; i < np_; ++i) {
+      const uint64_t path = lp.prefix[i];  // x-major triples, the level-(D-2) triple lowest
+      const uint32_t px = (uint32_t)_pext_u64(path, 0x4924924924924924ull), py = (uint32_t)_pext_u64(path, 0x2492492492492492ull),
+                     pz = (uint32_t)_pext_u64(path, 0x9249249249249249ull);
+      size_t leaf = lp.first[i];
+      for (unsigned bits = lp.bits[i]; bits; bits &= bits - 1u, ++leaf) {
+        const unsigned c = (unsigned)__builtin_ctz(bits);
+        const uint32_t key[3] = {(px << 1) | ((c >> 2) & 1u), (py << 1) | ((c >> 1) & 1u), (pz << 1) | (c & 1u)};
+        if (leaf >= count) return PCC_ERR_STREAM;
+        voxel_position(points[leaf], key, res, bbox, (centroids && 3 * leaf + 2 < cen.size()) ? &cen[3 * leaf] : nullptr);
+      }
+    }
+    return PCC_OK;
+  }
   size_t leaf = 0, op = 0;
   struct Frame { uint8_t bits; int8_t next; };
   Frame stack[40];
   uint32_t key[3] = {0, 0, 0};
   int sp = 0;
-  if (D == 0 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
   stack[0] = {occ[op++], 0};
   while (sp >= 0) {
     Frame& f = stack[sp];
@@ -1583,34 +1674,77 @@ int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb
       stack[++sp] = {occ[op++], 0};
       continue;
     }
-    // leaf: deserializeTreeCallback (impl.hpp:1584-1653)
-    if (leaf >= points.size()) return PCC_ERR_STREAM;
-    pcc_point_xyzrgb np;
-    memset(&np, 0, sizeof(np));
-    np.w = 1.0f;
-    float xyz[3];
-    for (int a = 0; a < 3; ++a) {
-      if (p.do_voxel_centroid && 3 * leaf + 2 < cen.size()) {
-        const double lc = (double)key[a] * res + info.bbox[a];
-        xyz[a] = (float)(lc + (float)cen[3 * leaf + a] * 0.001f);  // ptv2.h:115-117
-      } else {
-        xyz[a] = (float)(((double)key[a] + 0.5) * res + info.bbox[a]);  // impl.hpp:1630-1632
+    if (leaf >= count) return PCC_ERR_STREAM;
+    voxel_position(points[leaf], key, res, bbox, (centroids && 3 * leaf + 2 < cen.size()) ? &cen[3 * leaf] : nullptr);
+    ++leaf;
+    key[0] >>= 1; key[1] >>= 1; key[2] >>= 1;
+  }
+  return leaf == count ? PCC_OK : PCC_ERR_STREAM;
+}
+
+struct JoinOnExit {  // (an exception on the way -- a corrupt header asking for more memory than there is -- must not leave a thread behind)
+  std::thread& t;
+  ~JoinOnExit() { if (t.joinable()) t.join(); }
+};
+}  // namespace
+
+int decode_frame(const uint8_t* stream, size_t len, PointVec& points, pcc_cloud& info) {
+  points.clear();
+  FrameStreams fs;
+  // The three vectors sit one behind the other and a range-coded vector does not say how long it is, so they are decoded
+  // in order; but once the occupancy bytes are there, the walk over the tree (positions of all voxels) and the colour side
+  // (colour range decoder, JPEG, un-snaking) do not need each other: the walk runs on a second thread meanwhile.  With a
+  // centroid stream the positions need the second vector: then everything runs in order.
+  std::thread walker;
+  JoinOnExit joiner{walker};
+  int walk_rc = PCC_OK;
+  bool walked = false;
+  auto start_walk = [&]() {
+    static const bool serial = getenv("PCC_DECODE_SERIAL") != nullptr;  // developer knob: no second thread
+    if (serial || info.params.do_voxel_centroid || fs.count > 8 * (uint64_t)fs.occ.size()) return;
+    points.resize((size_t)fs.count);
+    walked = true;
+    walker = std::thread([&]() {
+      DecodeTrace wt;
+      try {
+        walk_rc = voxel_positions(fs.occ, fs.cen, false, info.depth, info.params.octree_resolution, info.bbox, points);
+      } catch (...) {
+        walk_rc = PCC_ERR_STREAM;
       }
-    }
-    np.x = xyz[0]; np.y = xyz[1]; np.z = xyz[2];
-    if (with_color) {
+      wt.lap("(second thread) tree walk");
+    });
+  };
+  const int rc = decode_frame_streams(stream, len, info, fs, true, start_walk);
+  if (walker.joinable()) walker.join();
+  DecodeTrace tr;
+  if (rc != PCC_OK) { points.clear(); return rc; }
+  const pcc_params& p = info.params;
+  const uint64_t count = fs.count;
+  // a tree of occ_n branch nodes has at most eight leaves per node: anything else is a corrupt header
+  if (count > 8 * (uint64_t)fs.occ.size()) { points.clear(); return PCC_ERR_STREAM; }
+  if (!walked) {
+    points.resize((size_t)count);
+    walk_rc = voxel_positions(fs.occ, fs.cen, p.do_voxel_centroid != 0, info.depth, p.octree_resolution, info.bbox, points);
+  }
+  if (walk_rc != PCC_OK) { points.clear(); return walk_rc; }
+  tr.lap("tree walk + positions (rest)");
+  // colour part of deserializeTreeCallback
+  const Bytes& col = fs.col;
+  const unsigned shift = (fs.cct == 0) ? (unsigned)(8 - p.color_bit_resolution) & 7u : 0u;
+  const size_t n = points.size();
+  if (fs.with_color) {
+    for (size_t leaf = 0; leaf < n; ++leaf) {
       uint32_t c0 = 0, c1 = 0, c2 = 0;
       if (3 * leaf + 2 < col.size()) { c0 = col[3 * leaf]; c1 = col[3 * leaf + 1]; c2 = col[3 * leaf + 2]; }
       c0 = (uint8_t)(c0 << shift); c1 = (uint8_t)(c1 << shift); c2 = (uint8_t)(c2 << shift);
-      np.rgba = c0 | (c1 << 8) | (c2 << 16);
-    } else {
-      np.rgba = 0x00FFFFFFu;  // ColorCoding::setDefaultColor
+      points[leaf].rgba = c0 | (c1 << 8) | (c2 << 16);
     }
-    points[leaf++] = np;
-    key[0] >>= 1; key[1] >>= 1; key[2] >>= 1;
+  } else {
+    for (size_t leaf = 0; leaf < n; ++leaf) points[leaf].rgba = 0x00FFFFFFu;  // ColorCoding::setDefaultColor
   }
-  info.n = leaf;
-  return leaf == (size_t)count ? PCC_OK : PCC_ERR_STREAM;
+  tr.lap("colours into the cloud");
+  info.n = n;
+  return PCC_OK;
 }
 
 }  // namespace pcc

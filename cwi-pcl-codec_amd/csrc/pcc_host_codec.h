@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <memory>
+#include <functional>
 #include <vector>
 
 #include "../../include/pcc_codec.h"
@@ -89,7 +90,9 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
                            uint64_t* const perf[], double* const times_us[]);
 
 // decodePointCloud (impl.hpp:224-310); returns PCC_OK or PCC_ERR_STREAM
-int decode_frame(const uint8_t* stream, size_t len, std::vector<pcc_point_xyzrgb>& points, pcc_cloud& info);
+// (the cloud is written voxel by voxel: no zero-fill of 32 bytes per voxel first)
+typedef std::vector<pcc_point_xyzrgb, NoInitAllocator<pcc_point_xyzrgb>> PointVec;
+int decode_frame(const uint8_t* stream, size_t len, PointVec& points, pcc_cloud& info);
 // pieces of the entropy stage for callers that run the range coders elsewhere (pcc_entropy_batch: on the GPU):
 // the 140-byte frame header (impl.hpp:1472-1486), and what the colour range coder gets (jpegcc.h:115-139)
 void frame_header_bytes(const pcc_hot_result& hot, const pcc_params& prm, Bytes& out);
@@ -104,7 +107,10 @@ struct FrameStreams {
   uint32_t cct = 0;
   Bytes occ, cen, col, payload;
 };
-int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too);
+// `after_occupancy` (may be empty) is called once the header is parsed and fs.occ holds the occupancy bytes, before the
+// other two vectors are decoded: the host decoder starts the walk over the tree on a second thread there.
+int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too,
+                         const std::function<void()>& after_occupancy = std::function<void()>());
 struct LeafParents {             // per node of level D-1, in stream order:
   std::vector<uint64_t> prefix;  //   its key, 3 bits per level, x-major triples
   std::vector<uint8_t> bits;     //   its occupancy byte = which of its eight voxels exist

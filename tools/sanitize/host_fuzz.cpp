@@ -117,7 +117,7 @@ static void frames() {
     entropy_encode_frame(hot, prm, out, perf, nullptr);
     CHECK(out.size() > 140);
     // the occupancy bytes are random, not a tree: the decoder has to cope with whatever it finds
-    std::vector<pcc_point_xyzrgb> pts;
+    PointVec pts;
     pcc_cloud info;
     (void)decode_frame(out.data(), out.size(), pts, info);
     for (int k = 0; k < 60; ++k) {
