@@ -894,10 +894,27 @@ void BaselineJpeg::encode_rgb(const uint8_t* rgb, int w, int h, int quality, Byt
 // decoder (libjpeg defaults: islow IDCT, fancy upsampling when downsampled_width > 2)
 // ---------------------------------------------------------------------------------------------
 namespace {
+// PCC_DECODE_TRACE=1: where the host decoder spends its time (stderr)
+struct DecodeTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  DecodeTrace() : on(getenv("PCC_DECODE_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pcc decode] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 struct HuffDec {
   int32_t maxcode[18] = {};
   int32_t valoff[17] = {};
   uint8_t vals[256] = {};
+  // the first kLook bits of the stream -> (code length << 8) | symbol, 0 if the code is longer than kLook bits.  Filled
+  // by running the length-by-length search below on every kLook-bit pattern, so a table that is not a proper prefix code
+  // (corrupt stream) decodes exactly as the search alone would.
+  static constexpr int kLook = 9;
+  uint16_t fast[1 << kLook] = {};
   bool ok = false;
   void build(const uint8_t bits[16], const uint8_t* v, int n) {
     memcpy(vals, v, (size_t)n);
@@ -914,19 +931,31 @@ struct HuffDec {
       code <<= 1;
     }
     maxcode[17] = 0x7fffffff;
+    for (uint32_t pat = 0; pat < (1u << kLook); ++pat) {
+      fast[pat] = 0;
+      int32_t c = 0;
+      for (int l = 1; l <= kLook; ++l) {
+        c = (c << 1) | (int32_t)((pat >> (kLook - l)) & 1u);
+        if (maxcode[l] >= 0 && c <= maxcode[l]) {
+          fast[pat] = (uint16_t)((l << 8) | vals[(c + valoff[l]) & 0xFF]);
+          break;
+        }
+      }
+    }
     ok = true;
   }
 };
-
+// The entropy-coded segment as a bit string: 0xFF 0x00 is a data byte 0xFF, any other 0xFF xx is a marker, behind which
+// (and behind the end of the data) the decoder reads zeros, as libjpeg does.  `pos` never moves past a marker.
 struct BitSource {
   const uint8_t* p;
   size_t len, pos;
-  uint32_t acc = 0;
+  uint64_t acc = 0;  // the low n bits are the next n bits of the string
   int n = 0;
   bool marker = false;
-  inline int bit() {
-    if (n == 0) {
-      uint8_t v = 0;
+  inline void refill() {  // afterwards n > 56
+    while (n <= 56) {
+      uint32_t v = 0;
       if (!marker && pos < len) {
         v = p[pos];
         if (v == 0xFF) {
@@ -936,23 +965,34 @@ struct BitSource {
           ++pos;
         }
       }
-      acc = v;
-      n = 8;
+      acc = (acc << 8) | v;
+      n += 8;
     }
-    --n;
-    return (acc >> n) & 1;
   }
   inline int bits(int k) {  // k <= 16 for any valid stream
-    uint32_t v = 0;
-    while (k-- > 0) v = (v << 1) | (uint32_t)bit();
-    return (int)(v & 0x7fffffffu);
+    if (k <= 0) return 0;
+    if (k > 31) k = 31;
+    if (n < k) refill();
+    n -= k;
+    return (int)((uint32_t)(acc >> n) & ((1u << k) - 1u));
   }
   inline int sym(const HuffDec& t) {
-    int32_t code = 0;
-    for (int l = 1; l <= 16; ++l) {
-      code = (code << 1) | bit();
-      if (t.maxcode[l] >= 0 && code <= t.maxcode[l]) return t.vals[(code + t.valoff[l]) & 0xFF];
+    if (n < 16) refill();
+    const uint32_t look = (uint32_t)(acc >> (n - 16)) & 0xFFFFu;  // the next 16 bits
+    const uint16_t e = t.fast[look >> (16 - HuffDec::kLook)];
+    if (e) {
+      n -= e >> 8;
+      return e & 0xFF;
     }
+    int32_t code = (int32_t)(look >> (16 - HuffDec::kLook));
+    for (int l = HuffDec::kLook + 1; l <= 16; ++l) {
+      code = (code << 1) | (int32_t)((look >> (16 - l)) & 1u);
+      if (t.maxcode[l] >= 0 && code <= t.maxcode[l]) {
+        n -= l;
+        return t.vals[(code + t.valoff[l]) & 0xFF];
+      }
+    }
+    n -= 16;  // no code of any length: sixteen bits are gone, the symbol is 0 (what the bit-by-bit search did)
     return 0;
   }
 };
@@ -990,14 +1030,29 @@ inline void idct_1d(const idct_t in[8], idct_t o[8]) {  // jidctint.c butterfly,
 }
 void idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t* dst, int stride) {
   idct_t ws[64], in[8], o[8];
+  // jidctint.c's short cuts, which give what the butterfly gives: a column (row) whose AC terms are all zero is its DC
+  // term times 8192 in every output, i.e. 4 * DC after the first descale and (DC + 16) >> 5 after the second.  Most
+  // columns of a quantised block are like that.
   for (int c = 0; c < 8; ++c) {
+    if ((coef[8 + c] | coef[16 + c] | coef[24 + c] | coef[32 + c] | coef[40 + c] | coef[48 + c] | coef[56 + c]) == 0) {
+      const idct_t dc = (idct_t)coef[c] * q[c] * 4;
+      for (int r = 0; r < 8; ++r) ws[8 * r + c] = dc;
+      continue;
+    }
     for (int r = 0; r < 8; ++r) in[r] = (idct_t)coef[8 * r + c] * q[8 * r + c];
     idct_1d(in, o);
     for (int r = 0; r < 8; ++r) ws[8 * r + c] = descale64(o[r], 13 - 2);
   }
   for (int r = 0; r < 8; ++r) {
-    idct_1d(ws + 8 * r, o);
-    for (int c = 0; c < 8; ++c) dst[(size_t)r * stride + c] = idct_clamp(descale64(o[c], 13 + 2 + 3));
+    const idct_t* w = ws + 8 * r;
+    uint8_t* d = dst + (size_t)r * stride;
+    if ((w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0) {
+      const uint8_t v = idct_clamp(descale64(w[0], 2 + 3));
+      for (int c = 0; c < 8; ++c) d[c] = v;
+      continue;
+    }
+    idct_1d(w, o);
+    for (int c = 0; c < 8; ++c) d[c] = idct_clamp(descale64(o[c], 13 + 2 + 3));
   }
 }
 }  // namespace
@@ -1085,6 +1140,7 @@ bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, i
     Y.resize((size_t)yw * mcus_y * 16); C0.resize((size_t)cpw * mcus_y * 8); C1.resize((size_t)cpw * mcus_y * 8);
   }
   uint8_t* C[2] = {C0.data(), C1.data()};
+  DecodeTrace jt;
   BitSource br{jpg, len, pos};
   int last_dc[3] = {0, 0, 0}, count = 0, next_rst = 0;
   int16_t blk_local[64];
@@ -1128,6 +1184,7 @@ bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, i
     }
   if (coefs_out) return true;
   Bytes& rgb = *rgb_out;
+  jt.lap("  jpeg: huffman + idct");
 
   // chroma upsampling (jdsample.c): triangle filter if downsampled_width > 2, else replication
   const int uw = cpw * 2;
@@ -1157,17 +1214,31 @@ bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, i
         *o++ = (uint8_t)((cur * 3 + prv + 8) >> 4);
         *o++ = (uint8_t)((cur * 4 + 7) >> 4);
       }
+  jt.lap("  jpeg: chroma upsampling");
   rgb.resize((size_t)w * h * 3);
+  // jdcolor.c: the chroma terms of every pixel come out of four 256-entry tables (as libjpeg builds them)
+  int32_t cr_r[256], cb_b[256], cb_g[256], cr_g[256];
+  for (int v = 0; v < 256; ++v) {
+    const int32_t x = v - 128;
+    cr_r[v] = (91881 * x + 32768) >> 16;
+    cb_b[v] = (116130 * x + 32768) >> 16;
+    cb_g[v] = -22554 * x + 32768;
+    cr_g[v] = -46802 * x;
+  }
   auto sat = [](int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
-  for (int r = 0; r < h; ++r)
-    for (int c = 0; c < w; ++c) {
-      const int y = Y[(size_t)r * yw + c];
-      const int32_t xb = U[0][(size_t)r * uw + c] - 128, xr = U[1][(size_t)r * uw + c] - 128;
-      uint8_t* o = rgb.data() + ((size_t)r * w + c) * 3;
-      o[0] = sat(y + ((91881 * xr + 32768) >> 16));
-      o[1] = sat(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16));
-      o[2] = sat(y + ((116130 * xb + 32768) >> 16));
+  for (int r = 0; r < h; ++r) {
+    const uint8_t* yr = Y.data() + (size_t)r * yw;
+    const uint8_t* ub = U[0] + (size_t)r * uw;
+    const uint8_t* ur = U[1] + (size_t)r * uw;
+    uint8_t* o = rgb.data() + (size_t)r * w * 3;
+    for (int c = 0; c < w; ++c, o += 3) {
+      const int y = yr[c];
+      o[0] = sat(y + cr_r[ur[c]]);
+      o[1] = sat(y + ((cb_g[ub[c]] + cr_g[ur[c]]) >> 16));
+      o[2] = sat(y + cb_b[ub[c]]);
     }
+  }
+  jt.lap("  jpeg: colour conversion");
   return true;
 }
 
@@ -1424,20 +1495,6 @@ struct Reader {
 };
 }  // namespace
 
-namespace {
-// PCC_DECODE_TRACE=1: where the host decoder spends its time (stderr)
-struct DecodeTrace {
-  bool on;
-  std::chrono::steady_clock::time_point t;
-  DecodeTrace() : on(getenv("PCC_DECODE_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
-  void lap(const char* what) {
-    if (!on) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[pcc decode] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-    t = now;
-  }
-};
-}  // namespace
 
 int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too,
                          const std::function<void()>& after_occupancy) {
