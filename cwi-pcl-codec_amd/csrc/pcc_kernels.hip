@@ -1954,7 +1954,7 @@ __global__ __launch_bounds__(kJpegThreads) void k_jpeg_rows(FrameState* st, cons
     uint32_t* rec = jpeg_tiles + (size_t)m * kJpegTileWords;
     for (uint32_t k = threadIdx.x; k < words; k += kJpegThreads) rec[k] = s_hbits[k];
   }
-  PCC_KTR(5, 6);
+  PCC_KTR(7, 5);
 }
 
 // ------------------------------------------------------------------------------------------

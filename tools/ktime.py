@@ -23,11 +23,13 @@ for ps in range(hot.depth * 3 // 9 + 1 if wl != "cfg2" else 4):
     x = t[ps, :ntiles, :8]
     t0 = x[:, 0].min()
     rel = (x - t0) / 100.0
-    print("pass %d: stamps (median us): start %.2f tile %.2f published %.2f closers-done %.2f ranked %.2f mates-read %.2f prev-group-ready %.2f lookback-done %.2f" % ((ps,) + tuple(np.median(rel, axis=0))))
-    print("        stamps (max us):", np.round(rel.max(axis=0), 2))
+    m = np.median(rel, axis=0)  # slots: 0 start, 1 tile id + digit totals, 4 ranked, 2 tile word published + digit starts, 3 group closers done, 6 group mates / group before there, 7 look-back done, 5 end
+    print("pass %d: stamps (median us): start %.2f, tile id + totals %.2f, ranked %.2f, published %.2f, closers done %.2f, mates / group before there %.2f, look-back done %.2f, end %.2f" %
+          (ps, m[0], m[1], m[4], m[2], m[3], m[6], m[7], m[5]))
+    print("        stamps (max us, slot order 0..7):", np.round(rel.max(axis=0), 2))
     d = x.astype(np.float64) / 100.0
-    print("        per workgroup (median us): ticket+totals %.2f  keys+histogram %.2f  ranking %.2f  look-back %.2f  reorder+write %.2f  whole %.2f" % (
-        np.median(d[:, 1] - d[:, 0]), np.median(d[:, 2] - d[:, 1]), np.median(d[:, 4] - d[:, 3]), np.median(d[:, 7] - d[:, 4]),
+    print("        per workgroup (median us): ticket+totals %.2f  keys+ranking %.2f  publish+digit starts %.2f  look-back (closers, waiting, reading) %.2f  write-out %.2f  whole %.2f" % (
+        np.median(d[:, 1] - d[:, 0]), np.median(d[:, 4] - d[:, 1]), np.median(d[:, 2] - d[:, 4]), np.median(d[:, 7] - d[:, 2]),
         np.median(d[:, 5] - d[:, 7]), np.median(d[:, 5] - d[:, 0])))
     order = np.argsort(d[:, 0])
     q = max(1, len(order) // 4)
@@ -39,7 +41,7 @@ gl = len(pts) // 2048 + 1   # k_leaf_tile: one workgroup per block row of 2048 l
 nlt = (gl + (gl + 1023) // 1024 - 1) // ((gl + 1023) // 1024)
 x = t[5, :nlt, :7]
 rel = (x - x[:, 0].min()) / 100.0
-print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end:", np.round(np.median(rel, axis=0), 2))
+print("k_leaf_tile stamps (median us): start, A1 done, r0 colour, r0 centre+simplified, r0 occupancy, A2 done (4 rounds), end (stores issued):", np.round(np.median(rel, axis=0), 2))
 print("            stamps (max us):", np.round(rel.max(axis=0), 2))
 x = t[7, :nlt, :4]
 rel = (x - t[5, :nlt, 0:1]) / 100.0
