@@ -328,18 +328,27 @@ size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, 
   const uint32_t total = freq[256];
   if (total == 0) return 0;
   // PCL finds the symbol of a cumulative count by an eight-step binary search; each step is an unpredictable branch,
-  // most of the decoder's time.  The encoder keeps the total below 2^16 (it halves the table otherwise), so a table
-  // count -> symbol of at most 64 K entries answers in one load; any other table (foreign or corrupt stream) takes the
-  // search.  The table must be non-decreasing for the two to agree: checked.
+  // most of the decoder's time.  The encoder keeps the total below 2^16 (it halves the table otherwise), so a table of
+  // 4096 entries -- the symbol that holds count 16 b, for every b -- followed by a walk up the cumulative table answers
+  // instead: symbols wider than 16 counts (all the frequent ones) need no step of the walk unless the count falls into the
+  // bucket of their first count, and table and cumulative counts stay in the first-level cache (a 64 K table of one
+  // entry per count does not: that load was a second-level hit on the path of every symbol).  Any other table (foreign or
+  // corrupt stream) takes the search.  The table must be non-decreasing for the two to agree: checked.
   bool monotone = true;
   for (int k = 0; k < 256; ++k) monotone &= freq[k] <= freq[k + 1];
-  std::vector<uint8_t> lut;
-  if (monotone && freq[0] == 0 && total <= 65536u && n >= 4096) {
-    lut.resize(total);
-    for (unsigned sy = 0; sy < 256; ++sy)
-      if (freq[sy + 1] > freq[sy]) memset(lut.data() + freq[sy], (int)sy, freq[sy + 1] - freq[sy]);
+  constexpr unsigned kBucketShift = 4;
+  uint8_t first_of_bucket[65536u >> kBucketShift];
+  bool have_table = false;
+  if (monotone && freq[0] == 0 && total <= 65536u && n >= 256) {
+    unsigned sy = 0;
+    for (uint32_t b = 0; (b << kBucketShift) < total; ++b) {
+      const uint32_t c = b << kBucketShift;
+      while (freq[sy + 1] <= c) ++sy;  // c < total = freq[256]: ends at sy <= 255
+      first_of_bucket[b] = (uint8_t)sy;
+    }
+    have_table = true;
   }
-  const uint8_t* const table = lut.empty() ? nullptr : lut.data();
+  const uint8_t* const table = have_table ? first_of_bucket : nullptr;
   const InvariantDiv32 by_total(total >= 2 ? total : 2);  // the same divisor for every symbol: a multiply instead of a divide
   for (size_t i = 0; i < n; ++i) {
     range = total >= 2 ? by_total.div(range) : range / total;
@@ -347,7 +356,8 @@ size_t StaticRangeCoder::decode(const uint8_t* in, size_t in_len, uint8_t* out, 
     const uint32_t count = (code - low) / range;
     unsigned sym = 0;
     if (table && count < total) {
-      sym = table[count];  // the largest symbol whose cumulative count does not exceed `count`, as the search finds it
+      sym = table[count >> kBucketShift];
+      while (freq[sym + 1] <= count) ++sym;  // the largest symbol whose cumulative count does not exceed `count`, as the search finds it
     } else {
       for (unsigned step = 128; step; step >>= 1)
         if (freq[sym + step] <= count) sym += step;
