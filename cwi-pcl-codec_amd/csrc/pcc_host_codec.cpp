@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <system_error>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -1770,16 +1771,20 @@ int decode_frame(const uint8_t* stream, size_t len, PointVec& points, pcc_cloud&
     static const bool serial = getenv("PCC_DECODE_SERIAL") != nullptr;  // developer knob: no second thread
     if (serial || info.params.do_voxel_centroid || fs.count > 8 * (uint64_t)fs.occ.size()) return;
     points.resize((size_t)fs.count);
-    walked = true;
-    walker = std::thread([&]() {
-      DecodeTrace wt;
-      try {
-        walk_rc = voxel_positions(fs.occ, fs.cen, false, info.depth, info.params.octree_resolution, info.bbox, points);
-      } catch (...) {
-        walk_rc = PCC_ERR_STREAM;
-      }
-      wt.lap("(second thread) tree walk");
-    });
+    try {
+      walker = std::thread([&]() {
+        DecodeTrace wt;
+        try {
+          walk_rc = voxel_positions(fs.occ, fs.cen, false, info.depth, info.params.octree_resolution, info.bbox, points);
+        } catch (...) {
+          walk_rc = PCC_ERR_STREAM;
+        }
+        wt.lap("(second thread) tree walk");
+      });
+      walked = true;
+    } catch (const std::system_error&) {
+      // no thread to be had (process limits): the walk runs on this thread after the colour side
+    }
   };
   const int rc = decode_frame_streams(stream, len, info, fs, true, start_walk);
   if (walker.joinable()) walker.join();
