@@ -146,6 +146,41 @@ def test_entropy_stage_and_decoder_match_oracle(pkg, oracle, mode, centroid):
     assert info["params"]["frame_id"] == 3 and info["params"]["color_coding_type"] == mode
 
 
+@pytest.mark.parametrize("octree_bits,mode,centroid", [(23, 1, 0), (22, 0, 1), (19, 3, 1), (9, 1, 0), (9, 3, 1)])
+def test_host_decoder_on_deep_and_larger_trees(pkg, oracle, octree_bits, mode, centroid):
+    """The host decoder walks branch nodes only and takes keys out of the 3-bits-per-level path while the path fits 63
+    bits (depth <= 21), and falls back to the pre-order walk with a stack beyond that; without a centroid stream the walk
+    runs on a second thread.  Both walks, both thread arrangements, against the oracle's decoder."""
+    n = 3000 if octree_bits > 21 else 60_000
+    pts = pkg.synthetic.sphere_shell(n, 0x99 + octree_bits)
+    r = oracle.encode_intra(pts, oracle.make_params(octree_bits=octree_bits, color_coding_type=mode, keep_centroid=centroid, jpeg_quality=70))
+    assert (r.depth > 21) == (octree_bits > 21) and r.depth <= 32
+    want = oracle.decode_intra(r.bitstream)
+    dec, info = pkg.binding.Context(None).decode_intra(r.bitstream)
+    assert info["depth"] == want.depth and info["consumed"] == want.consumed == len(r.bitstream)
+    assert dec.tobytes() == want.points.tobytes()
+
+
+def test_host_decoder_on_one_thread_gives_the_same_cloud(pkg, oracle, tmp_path):
+    """PCC_DECODE_SERIAL=1 (read once per process, hence the child process) keeps the walk on the calling thread."""
+    import subprocess, sys
+    pts = pkg.synthetic.sphere_shell(20_000, 0x5e)
+    r = oracle.encode_intra(pts, oracle.make_params(octree_bits=8, color_coding_type=1, jpeg_quality=85))
+    (tmp_path / "frame.bin").write_bytes(r.bitstream)
+    want = oracle.decode_intra(r.bitstream).points.tobytes()
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as G; b = G.load_package().binding; "
+            "pts, info = b.Context(None).decode_intra(open(%r, 'rb').read()); sys.stdout.buffer.write(pts.tobytes())"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "frame.bin")))
+    for serial in ("", "1"):
+        env = dict(os.environ)
+        env.pop("PCC_DECODE_SERIAL", None)
+        if serial:
+            env["PCC_DECODE_SERIAL"] = serial
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        assert out.stdout == want
+
+
 @pytest.mark.parametrize("modes", [(1, 1), (0, 2), (3, 1)])
 def test_two_frames_at_once_give_the_same_bytes(pkg, oracle, modes):
     """pcc_entropy_encode2 interleaves the range-coder loops of two frames: the bytes must not change
