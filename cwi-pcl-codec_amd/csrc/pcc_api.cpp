@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -696,23 +697,24 @@ int pcc_hotpath_launch_host(pcc_ctx* ctx, pcc_upload_lane* lane, const void* hos
 static int wait_frame_state(pcc_ctx* ctx) {
   { const int wrc = wait_stream(ctx, 0); if (wrc != PCC_OK) return wrc; }
   const FrameState& st = *ctx->h_state.p;
-  if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
-    // deeper tree than the frames before: run the frame again with every pass enqueued
-    ctx->args.max_passes = kMaxPasses;
-    const int rc = enqueue(ctx);
-    if (rc != PCC_OK) return rc;
-    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
-  }
-  if (st.error == kErrSpin) {
-    // A bounded poll ran out: a workgroup this frame waited for was held up for tens of milliseconds (another process
-    // on the GPU, a debugger).  Nothing is wrong with the frame: run it once more before giving up.
-    const int rc = enqueue(ctx);
-    if (rc != PCC_OK) return rc;
-    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
-    if (st.error == kErrSpin) {
-      return fail(ctx, PCC_ERR_HIP, "the GPU did not make progress on this frame (look-back poll timed out twice)");
+  // Two device errors mean "run the frame again": more sort passes needed than were enqueued (a deeper tree than the
+  // frames before: every pass is enqueued the second time), and a bounded poll that ran out (a workgroup this frame
+  // waited for was held up for tens of milliseconds -- another process on the GPU, a debugger; nothing is wrong with
+  // the frame).  Either can show up on the re-run the other one caused, hence a loop; a poll may time out once.
+  int spin_retries = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
+      ctx->args.max_passes = kMaxPasses;
+    } else if (st.error == kErrSpin && spin_retries == 0) {
+      ++spin_retries;
+    } else {
+      break;
     }
+    const int rc = enqueue(ctx);
+    if (rc != PCC_OK) return rc;
+    { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
   }
+  if (st.error == kErrSpin) return fail(ctx, PCC_ERR_HIP, "the GPU did not make progress on this frame (look-back poll timed out twice)");
   if (st.error != kErrNone) {
     char buf[160];
     snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
@@ -1139,7 +1141,7 @@ int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud*
   int rc;
   try {  // a corrupt header can ask for more memory than there is: that must not leave the C ABI as an exception
     rc = decode_frame(stream, len, ctx->dec_points, *out);
-  } catch (const std::bad_alloc&) {
+  } catch (const std::exception&) {  // bad_alloc, length_error, system_error: all of them mean "not a stream we can decode"
     ctx->dec_points.clear();
     rc = PCC_ERR_STREAM;
   }
@@ -1178,18 +1180,32 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     // the JPEG's Huffman decoding and the walk over the occupancy stream are both sequential, but not on each other:
     // they run side by side (a second thread for the time of the call)
     bool jpeg_ok = true, jpeg_oom = false;
-    std::thread jpeg_thread;
-    if (!host_only && jpeg)
-      jpeg_thread = std::thread([&] {
+    auto decode_jpeg = [&] {
+      try {
+        jpeg_ok = BaselineJpeg::decode_coefs(fs.payload.data(), fs.payload.size(), img_w, img_h, ctx->dec_coefs, (uint64_t)fs.count + 4096u);
+      } catch (const std::exception&) {  // (nothing may leave a thread's function)
+        jpeg_ok = false;
+        jpeg_oom = true;
+      }
+    };
+    {
+      // an exception on the way (the walk's vectors are sized from the untrusted stream) must not unwind past a
+      // joinable thread: that is std::terminate
+      struct JoinOnExit {
+        std::thread t;
+        ~JoinOnExit() { if (t.joinable()) t.join(); }
+      } helper;
+      bool inline_jpeg = false;
+      if (!host_only && jpeg) {
         try {
-          jpeg_ok = BaselineJpeg::decode_coefs(fs.payload.data(), fs.payload.size(), img_w, img_h, ctx->dec_coefs);
-        } catch (const std::bad_alloc&) {
-          jpeg_ok = false;
-          jpeg_oom = true;
+          helper.t = std::thread(decode_jpeg);
+        } catch (const std::system_error&) {  // no thread to be had: the JPEG is decoded here, after the walk
+          inline_jpeg = true;
         }
-      });
-    if (!host_only) rc = walk_leaf_parents(fs.occ, out->depth, fs.count, lp);
-    if (jpeg_thread.joinable()) jpeg_thread.join();
+      }
+      if (!host_only) rc = walk_leaf_parents(fs.occ, out->depth, fs.count, lp);
+      if (inline_jpeg) decode_jpeg();
+    }
     if (jpeg_oom) throw std::bad_alloc();
     if (!host_only && rc != PCC_OK) return fail(ctx, rc, "decode: occupancy stream does not describe the announced number of voxels");
     if (!host_only && jpeg && (!jpeg_ok || img_w % 8 != 0 || (size_t)img_w * (size_t)img_h < L)) host_only = true;
@@ -1262,6 +1278,8 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     return PCC_OK;
   } catch (const std::bad_alloc&) {
     return fail(ctx, PCC_ERR_STREAM, "decode: the stream asks for more memory than there is");
+  } catch (const std::exception& e) {  // nothing crosses the C ABI as an exception
+    return fail(ctx, PCC_ERR_STREAM, e.what());
   }
 }
 
@@ -1342,6 +1360,13 @@ int pcc_entropy_batch_add(pcc_entropy_batch* b, const pcc_hot_result* hot, const
   pcc_ctx* ctx = b->ctx;
   if (b->frames.size() >= b->max_frames) return fail(ctx, PCC_ERR_STATE, "the batch is full: flush it first");
   pcc_entropy_batch::Frame f;
+  // a frame that cannot be added leaves nothing behind in the arena
+  struct Rollback {
+    pcc_entropy_batch* b;
+    size_t used;
+    bool keep = false;
+    ~Rollback() { if (!keep) b->in_used = used; }
+  } rollback{b, b->in_used};
   frame_header_bytes(*hot, *prm, f.header);
   f.n_branches = hot->n_branches;
   f.n_leaves = hot->n_leaves;
@@ -1374,17 +1399,31 @@ int pcc_entropy_batch_add(pcc_entropy_batch* b, const pcc_hot_result* hot, const
     f.has_col = true;
   }
   b->frames.push_back(std::move(f));
+  rollback.keep = true;
   return (int)b->frames.size() - 1;
 }
+
+static int entropy_batch_flush_frames(pcc_entropy_batch* b, pcc_bitstream* out, size_t* n_out);
 
 int pcc_entropy_batch_flush(pcc_entropy_batch* b, pcc_bitstream* out, size_t out_capacity, size_t* n_out) {
   if (!b || (!out && out_capacity) || !n_out) return PCC_ERR_ARG;
   pcc_ctx* ctx = b->ctx;
   *n_out = 0;
   const size_t nf = b->frames.size();
-  if (out_capacity < nf) return fail(ctx, PCC_ERR_ARG, "room for fewer bitstreams than frames in the batch");
+  if (out_capacity < nf) return fail(ctx, PCC_ERR_ARG, "room for fewer bitstreams than frames in the batch");  // (the batch stays as it is)
   b->streams.assign(nf, Bytes());
   if (nf == 0) return PCC_OK;
+  const int rc = entropy_batch_flush_frames(b, out, n_out);
+  // whatever happened, the batch is empty afterwards: a failed flush loses its frames (the caller is told), it does not
+  // poison the flushes that follow
+  b->frames.clear();
+  b->in_used = 0;
+  return rc;
+}
+
+static int entropy_batch_flush_frames(pcc_entropy_batch* b, pcc_bitstream* out, size_t* n_out) {
+  pcc_ctx* ctx = b->ctx;
+  const size_t nf = b->frames.size();
   PCC_HIP(hipSetDevice(ctx->device));
   // jobs: the occupancy bytes (with their counts where the GPU stage delivered them), centroid bytes, colour payload
   std::vector<RcJob> jobs;
@@ -1462,8 +1501,6 @@ int pcc_entropy_batch_flush(pcc_entropy_batch* b, pcc_bitstream* out, size_t out
     out[i].len = s.size();
   }
   *n_out = nf;
-  b->frames.clear();
-  b->in_used = 0;
   return PCC_OK;
 }
 

@@ -1068,14 +1068,14 @@ void idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t* dst, int 
 }
 }  // namespace
 
-bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h) {
-  return decode_impl(jpg, len, &rgb, w, h, nullptr);
+bool BaselineJpeg::decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h, uint64_t max_pixels) {
+  return decode_impl(jpg, len, &rgb, w, h, nullptr, max_pixels);
 }
-bool BaselineJpeg::decode_coefs(const uint8_t* jpg, size_t len, int& w, int& h, JpegCoefs& out) {
-  return decode_impl(jpg, len, nullptr, w, h, &out);
+bool BaselineJpeg::decode_coefs(const uint8_t* jpg, size_t len, int& w, int& h, JpegCoefs& out, uint64_t max_pixels) {
+  return decode_impl(jpg, len, nullptr, w, h, &out, max_pixels);
 }
 
-bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, int& w, int& h, JpegCoefs* coefs_out) {
+bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, int& w, int& h, JpegCoefs* coefs_out, uint64_t max_pixels) {
   uint16_t qt[4][64] = {};
   HuffDec hd[2][4];
   int restart = 0;
@@ -1137,7 +1137,11 @@ bool BaselineJpeg::decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, i
     if (!hd[0][tdc[c]].ok || !hd[1][tac[c]].ok) return false;
   // An MCU of six blocks takes at least six bits of entropy data per block pair ... in any case more than one byte: a
   // header that promises more MCUs than the payload has bytes is corrupt (and would ask for gigabytes below)
-  if ((uint64_t)((w + 15) / 16) * (uint64_t)((h + 15) / 16) > (uint64_t)len) return false;
+  // (with one-bit codes for "size 0" and "end of block" an MCU is still twelve bits: 2 MCUs per 3 bytes at the very most)
+  if ((uint64_t)((w + 15) / 16) * (uint64_t)((h + 15) / 16) * 3u > 2u * (uint64_t)len) return false;
+  // a caller that knows how many pixels the image can have (a frame's voxel count) says so: 768 bytes of coefficients
+  // per MCU against a few bytes of payload is otherwise a 500-fold amplification a hostile frame header could ask for
+  if (max_pixels && (uint64_t)w * (uint64_t)h > max_pixels) return false;
 
   const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16;
   const int cw = (w + 1) / 2, chh = (h + 1) / 2;
@@ -1594,7 +1598,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
     } else if (cct == 1) {  // decodeJPEGSnake (jpegcc.h:228-242)
       Bytes img;
       int w = 0, h = 0;
-      const bool jpeg_ok = BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h);
+      const bool jpeg_ok = BaselineJpeg::decode_rgb(payload.data(), payload.size(), img, w, h, count + 4096u);  // 256 x (count / 256 + 1)
       tr.lap("jpeg decoder");
       if (jpeg_ok && w % 8 == 0) {
         col.resize(img.size());
@@ -1623,7 +1627,9 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
         if (!lr.get(sz) || lr.pos + sz > lr.len) break;
         Bytes img;
         int w = 0, h = 0;
-        if (BaselineJpeg::decode_rgb(lr.p + lr.pos, sz, img, w, h)) col.insert(col.end(), img.begin(), img.end());
+        // (a strip holds 2048 voxels, the last one up to 4095; the reference's own encoder writes a lone strip 2048 wide
+        // whatever the voxel count, jpegcc.h:256-275)
+        if (BaselineJpeg::decode_rgb(lr.p + lr.pos, sz, img, w, h, 4096u)) col.insert(col.end(), img.begin(), img.end());
         lr.pos += sz;
       }
     } else {
@@ -1644,6 +1650,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
 int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents& lp) {
   lp.prefix.clear(); lp.bits.clear(); lp.first.clear();
   if (D == 0 || D > 21 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
+  if (count >= (1ull << 32)) return PCC_ERR_STREAM;  // `first` counts voxels in 32 bits (and B < 2^32 bytes cannot hold more)
   {  // a level-(D-1) node holds at least one voxel and is one byte of the stream
     const size_t most = (size_t)std::min<uint64_t>(count, occ.size());
     lp.prefix.reserve(most); lp.bits.reserve(most); lp.first.reserve(most);

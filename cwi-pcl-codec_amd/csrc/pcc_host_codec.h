@@ -63,7 +63,7 @@ class BaselineJpeg {
   static void huffman_tables(uint32_t dc[2][12], uint32_t ac[2][256]);
   // The quantiser the GPU front end needs for `quality` (natural order; see pcc_kernels.h JpegQuant)
   static void quantiser(int quality, uint16_t half[2][64], uint32_t magic[2][64]);
-  static bool decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h);
+  static bool decode_rgb(const uint8_t* jpg, size_t len, Bytes& rgb, int& w, int& h, uint64_t max_pixels = 0);  // max_pixels: refuse larger images (0: no bound)
   // Entropy decoding only (the sequential part of a JPEG decoder): quantised coefficients, six blocks of 64 per MCU
   // (Y00 Y01 Y10 Y11 Cb Cr) in natural order, and the quantisation tables of the three components.
   struct JpegCoefs {
@@ -71,10 +71,10 @@ class BaselineJpeg {
     uint16_t q[3][64];
     int mcus_x = 0, mcus_y = 0;
   };
-  static bool decode_coefs(const uint8_t* jpg, size_t len, int& w, int& h, JpegCoefs& out);
+  static bool decode_coefs(const uint8_t* jpg, size_t len, int& w, int& h, JpegCoefs& out, uint64_t max_pixels = 0);
 
  private:
-  static bool decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, int& w, int& h, JpegCoefs* coefs_out);
+  static bool decode_impl(const uint8_t* jpg, size_t len, Bytes* rgb_out, int& w, int& h, JpegCoefs* coefs_out, uint64_t max_pixels);
 };
 
 // SnakeGridMapping (snake.h): position of linear element i in a w x h image (w multiple of 8)

@@ -185,6 +185,15 @@ __device__ __forceinline__ uint64_t poll_u64(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A place where the code relies on all 64 lanes of the wave having executed everything above it before any lane goes
+// on (the LDS operations of one wave are issued in program order): nothing on the GPU; a meeting point of the lanes in
+// the CPU executor of tests/emu, which runs the lanes of a wave one after the other between such points.
+#ifdef PCC_EMU
+#define PCC_WAVE_LOCKSTEP() emu::wave_barrier()
+#else
+#define PCC_WAVE_LOCKSTEP() do { } while (0)
+#endif
+
 #ifdef PCC_KTIME  // developer build only: phase time stamps of k_sort_pass (shader clock), read by tools/ktime.py
 __device__ unsigned long long g_ktime[(7 + 2) * 1024 * 8];
 #define PCC_KTR(row, slot)                                                                             \
@@ -977,9 +986,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
     const uint64_t same = __ballot(valid && d == d0);
     const bool via_lds = valid && d != d0;
     if (via_lds) atomicOr(reinterpret_cast<unsigned long long*>(&wmatch[d]), 1ull << lane);
+    PCC_WAVE_LOCKSTEP();
     const uint64_t peers = via_lds ? wmatch[d] : (valid ? same : 0ull);
     const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
     const uint32_t prior = s_cnt[wave][d];
+    PCC_WAVE_LOCKSTEP();
     if (valid && rank == 0) {
       if (via_lds) wmatch[d] = 0ull;
       s_cnt[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(peers));

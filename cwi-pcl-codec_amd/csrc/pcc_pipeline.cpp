@@ -415,6 +415,9 @@ struct pcc_pipeline {
 // one logical CPU per physical core, out of the CPUs this process may run on
 // set by pcc_pipeline_create_multi around the creation of each of its pipelines: which range of the allowed cores is whose
 static thread_local int pin_offset_hint = 0, pin_span_hint = 0;
+// cores handed to the entropy threads of earlier pipelines of this process: a pipeline created without a range of its own
+// (no hint, no PCC_PIPELINE_PIN_OFFSET) starts behind them, so two plain pcc_pipeline_create calls do not pin to the same cores
+static std::atomic<size_t> g_pin_cores_taken{0};
 
 static std::vector<int> one_cpu_per_core() {
   std::vector<int> out;
@@ -498,12 +501,26 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     size_t span = cores.size();
     if (const char* o = getenv("PCC_PIPELINE_PIN_SPAN")) span = std::min<size_t>(cores.size(), (size_t)std::max(atoi(o), 1));
     if (pin_span_hint > 0) span = std::min<size_t>(span, (size_t)pin_span_hint);
+    // one process per GPU on one host (torchrun: LOCAL_RANK of LOCAL_WORLD_SIZE): every rank takes its share of the
+    // allowed cores unless the caller gave a range
+    size_t rank_base = 0;
+    const bool ranged = pin_span_hint > 0 || getenv("PCC_PIPELINE_PIN_SPAN") || getenv("PCC_PIPELINE_PIN_OFFSET");
+    if (!ranged) {
+      const char* lr = getenv("LOCAL_RANK");
+      const char* lw = getenv("LOCAL_WORLD_SIZE");
+      const int nr = lw ? atoi(lw) : 1, r = lr ? atoi(lr) : 0;
+      if (nr > 1 && r >= 0 && r < nr) {
+        span = std::max<size_t>(cores.size() / (size_t)nr, 1);
+        rank_base = (size_t)r * span;
+      }
+    }
     int mode = (span >= 2 * (size_t)p->n_entropy) ? 2 : 0;  // 0 none, 1 cores, 2 groups
     if (e) mode = !strcmp(e, "cores") ? 1 : (!strcmp(e, "groups") ? 2 : 0);
+    const size_t per = mode == 2 ? std::min<size_t>(8, std::max<size_t>(1, span / (size_t)std::max(p->n_entropy, 1))) : 1;
     size_t off = pin_offset_hint > 0 ? (size_t)pin_offset_hint : 0;
     if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) off = (size_t)std::max(atoi(o), 0);
+    else if (pin_span_hint == 0 && mode) off = rank_base + g_pin_cores_taken.fetch_add((size_t)p->n_entropy * per) % span;
     if (mode && !cores.empty()) {
-      const size_t per = mode == 2 ? std::min<size_t>(8, std::max<size_t>(1, span / (size_t)std::max(p->n_entropy, 1))) : 1;
       for (int w = 0; w < p->n_entropy; ++w) {
         cpu_set_t set;
         CPU_ZERO(&set);

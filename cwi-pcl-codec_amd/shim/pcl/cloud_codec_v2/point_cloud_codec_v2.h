@@ -304,13 +304,17 @@ class OctreePointCloudCodecV2 {
       buf.insert(buf.end(), carry_.begin(), carry_.begin() + (std::ptrdiff_t)got);
       carry_.erase(carry_.begin(), carry_.begin() + (std::ptrdiff_t)got);
     }
-    if (got < n) {
+    // the rest comes off the stream in bounded pieces: `n` may derive from an untrusted header field, and a buffer is only
+    // ever grown by what the stream really delivered
+    while (got < n && in) {
+      const size_t piece = (n - got) < ((size_t)1 << 22) ? (n - got) : ((size_t)1 << 22);
       const size_t at = buf.size();
-      buf.resize(at + (n - got));
-      in.read(reinterpret_cast<char*>(buf.data() + at), (std::streamsize)(n - got));
+      buf.resize(at + piece);
+      in.read(reinterpret_cast<char*>(buf.data() + at), (std::streamsize)piece);
       const size_t r = (size_t)in.gcount();
       buf.resize(at + r);
       got += r;
+      if (r < piece) break;
     }
     return got;
   }
@@ -323,16 +327,17 @@ class OctreePointCloudCodecV2 {
     std::vector<uint8_t> one;
     while (matched < id_len) {  // syncToHeader: byte by byte until the identifier has gone by
       one.clear();
-      if (pull(in, one, 1) != 1) return false;
+      if (pull(in, one, 1) != 1) { carry_.clear(); carry_stream_ = nullptr; return false; }  // end of the stream
       const char ch = (char)one[0];
       matched = (ch == kId[matched]) ? matched + 1 : ((ch == kId[0]) ? 1 : 0);
     }
     buf.assign(kId, kId + id_len);
     // 20-byte base identifier, frame id, flags, then the voxel count at byte 55: the size of the frame follows it loosely
-    if (pull(in, buf, 140 - id_len) != 140 - id_len) return false;
+    if (pull(in, buf, 140 - id_len) != 140 - id_len) { carry_.clear(); carry_stream_ = nullptr; return false; }
     uint64_t voxels = 0;
     memcpy(&voxels, buf.data() + 55, sizeof(voxels));
-    size_t want = 8192 + (size_t)(voxels < (1ull << 32) ? voxels : (1ull << 32)) * 2;
+    // (the count only sizes the FIRST read, and only up to 4 MB: a corrupt header must not be able to ask for gigabytes)
+    size_t want = 8192 + (size_t)(voxels < (1ull << 21) ? voxels : (1ull << 21)) * 2;
     for (;;) {
       const size_t got = pull(in, buf, want);
       const int rc = pcc_decode_intra(ctx_, buf.data(), buf.size(), &out);
@@ -355,6 +360,8 @@ class OctreePointCloudCodecV2 {
       }
       if (got < want) {  // the stream has no more to give: truncated or corrupt frame (impl.hpp has no error path either)
         in.clear();
+        carry_.clear();  // nothing of this stream is kept: a later stream object at the same address starts clean
+        carry_stream_ = nullptr;
         return false;
       }
       want = buf.size();  // double what has been read

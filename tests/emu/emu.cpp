@@ -1,0 +1,464 @@
+// Runtime of the wave64 executor (see include/hip/hip_runtime.h): TEST INFRASTRUCTURE ONLY.
+//
+//   launch      -> the workgroups of the grid are handed out in blockIdx order to a pool of OS threads; the call returns
+//                  when the grid is through (streams are synchronous)
+//   workgroup   -> one OS thread; its LDS is that thread's thread-local storage
+//   lane        -> a fibre (own stack, hand-written x86-64 context switch); the lanes of a wave run one after the other
+//                  up to their next meeting point: a cross-lane operation, a barrier, a sleep, the end of the kernel
+//   cross-lane  -> executed by the wave's scheduler once every lane of the wave that can still get there has arrived
+//                  (lanes waiting at a barrier or finished are inactive, exactly the EXEC mask of the hardware)
+//   barrier     -> released when every lane of the workgroup has arrived or finished
+//   s_sleep     -> the OS thread yields: polls on other workgroups' words make progress because those workgroups run
+//                  on other threads of the pool (at least two)
+#include <hip/hip_runtime.h>
+
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+thread_local emu::Idx3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+namespace {
+
+// ------------------------------------------------------------------ context switch
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch,.-emu_switch
+)");
+
+enum State : int { kRunnable = 0, kCollective, kBarrier, kSleep, kDone };
+enum Kind : int { kBallot = 1, kDpp, kReadlane, kReadfirst, kShfl, kWaveBarrier, kSync, kSyncAnd, kSyncOr, kSyncCount };
+
+struct Lane {
+  void* sp;
+  int state;
+  int kind;
+  uint64_t a0, a1;  // operands
+  int c0, c1, c2, c3;  // constants of the operation (must agree over the wave)
+  uint64_t result;
+};
+
+constexpr size_t kStackBytes = 256 * 1024;
+constexpr int kMaxThreads = 1024;
+
+struct Worker {
+  char* stacks = nullptr;
+  Lane lanes[kMaxThreads];
+  void* sched_sp = nullptr;
+  int cur = -1;          // lane that is running
+  int nthreads = 0;
+  Launcher* job = nullptr;
+  const char* kname = "";
+  uint32_t block_linear = 0;
+};
+thread_local Worker* tl_worker = nullptr;
+
+[[noreturn]] void die(const char* what) {
+  Worker* w = tl_worker;
+  fprintf(stderr, "wave64 executor: %s (kernel %s, workgroup %u, lane %d)\n", what, w ? w->kname : "?", w ? w->block_linear : 0u, w ? w->cur : -1);
+  abort();
+}
+
+void lane_entry() {
+  Worker* w = tl_worker;
+  w->job->run_lane();
+  w = tl_worker;
+  Lane& l = w->lanes[w->cur];
+  l.state = kDone;
+  void* dummy;
+  emu_switch(&dummy, w->sched_sp);
+  die("a finished lane was resumed");
+}
+
+void prepare_lane(Worker* w, int i) {
+  char* top = w->stacks + (size_t)(i + 1) * kStackBytes;
+  uintptr_t sp = (uintptr_t)top & ~(uintptr_t)15;
+  // layout popped by emu_switch: r15 r14 r13 r12 rbx rbp, then the return address; after `ret` rsp % 16 must be 8
+  sp -= 8;  // alignment slot: entry sees rsp % 16 == 8
+  uint64_t* s = reinterpret_cast<uint64_t*>(sp);
+  *--s = (uint64_t)(uintptr_t)&lane_entry;
+  for (int k = 0; k < 6; ++k) *--s = 0;
+  w->lanes[i].sp = s;
+  w->lanes[i].state = kRunnable;
+  w->lanes[i].kind = 0;
+}
+
+// called on a lane's stack: hand control back to the scheduler of the workgroup
+inline uint64_t yield_lane(int state, int kind, uint64_t a0, uint64_t a1, int c0 = 0, int c1 = 0, int c2 = 0, int c3 = 0) {
+  Worker* w = tl_worker;
+  if (!w || w->cur < 0) die("device operation outside a kernel");
+  Lane& l = w->lanes[w->cur];
+  l.state = state; l.kind = kind; l.a0 = a0; l.a1 = a1; l.c0 = c0; l.c1 = c1; l.c2 = c2; l.c3 = c3;
+  emu_switch(&l.sp, w->sched_sp);
+  return tl_worker->lanes[tl_worker->cur].result;
+}
+
+// ------------------------------------------------------------------ cross-lane operations
+// source lane of a DPP control for destination lane i, or -1 (out of range)
+int dpp_source(int ctrl, int i) {
+  const int row = i & ~15, r = i & 15;
+  if (ctrl >= 0x000 && ctrl <= 0x0ff) return (i & ~3) | ((ctrl >> (2 * (i & 3))) & 3);  // quad_perm
+  if (ctrl >= 0x101 && ctrl <= 0x10f) { const int s = r + (ctrl & 15); return s < 16 ? row + s : -1; }   // row_shl
+  if (ctrl >= 0x111 && ctrl <= 0x11f) { const int s = r - (ctrl & 15); return s >= 0 ? row + s : -1; }   // row_shr
+  if (ctrl >= 0x121 && ctrl <= 0x12f) return row + ((r - (ctrl & 15)) & 15);                           // row_ror
+  switch (ctrl) {
+    case 0x130: return i + 1 < 64 ? i + 1 : -1;   // wave_shl:1
+    case 0x134: return (i + 1) & 63;              // wave_rol:1
+    case 0x138: return i - 1;                     // wave_shr:1 (lane 0: -1)
+    case 0x13c: return (i - 1) & 63;              // wave_ror:1
+    case 0x140: return row + (15 - r);            // row_mirror
+    case 0x141: return row + (r & 8) + (7 - (r & 7));  // row_half_mirror
+    case 0x142: return row >= 16 ? row - 1 : -1;  // row_bcast:15: lane 15 of the row before
+    case 0x143: return i >= 32 ? 31 : -1;         // row_bcast:31: lane 31 into the upper half
+  }
+  die("unknown DPP control");
+}
+
+void run_collective(Worker* w, int wave_first, uint64_t active) {
+  Lane* L = w->lanes + wave_first;
+  int first = __builtin_ctzll(active);
+  const int kind = L[first].kind;
+  for (int i = 0; i < 64; ++i)
+    if ((active >> i) & 1) {
+      if (L[i].kind != kind || L[i].c0 != L[first].c0 || L[i].c1 != L[first].c1 || L[i].c2 != L[first].c2 || L[i].c3 != L[first].c3) {
+        fprintf(stderr, "wave64 executor: lanes %d and %d of a wave are at different cross-lane operations (%d/%x vs %d/%x)\n", first, i, kind,
+                L[first].c0, L[i].kind, L[i].c0);
+        die("divergent cross-lane operation");
+      }
+    }
+  auto on = [&](int i) { return i >= 0 && i < 64 && ((active >> i) & 1); };
+  switch (kind) {
+    case kBallot: {
+      uint64_t m = 0;
+      for (int i = 0; i < 64; ++i) if (on(i) && L[i].a0) m |= 1ull << i;
+      for (int i = 0; i < 64; ++i) if (on(i)) L[i].result = m;
+      break;
+    }
+    case kDpp: {
+      const int ctrl = L[first].c0, row_mask = L[first].c1, bank_mask = L[first].c2, bound = L[first].c3;
+      for (int i = 0; i < 64; ++i) {
+        if (!on(i)) continue;
+        uint64_t r = L[i].a0;  // old
+        if (((row_mask >> (i >> 4)) & 1) && ((bank_mask >> ((i >> 2) & 3)) & 1)) {
+          const int s = dpp_source(ctrl, i);
+          if (on(s)) r = L[s].a1;
+          else if (bound) r = 0;
+        }
+        L[i].result = r;
+      }
+      break;
+    }
+    case kReadlane: {
+      const int s = L[first].c0;
+      if (s < 0 || s > 63) die("readlane: lane out of range");
+      // an inactive source lane's register is read as it is on the hardware; here the value is not known
+      if (!on(s)) die("readlane from a lane that is not active");
+      for (int i = 0; i < 64; ++i) if (on(i)) L[i].result = L[s].a0;
+      break;
+    }
+    case kReadfirst:
+      for (int i = 0; i < 64; ++i) if (on(i)) L[i].result = L[first].a0;
+      break;
+    case kShfl: {
+      const int width = L[first].c0, mode = L[first].c1;
+      if (width <= 0 || width > 64 || (width & (width - 1))) die("shuffle width");
+      for (int i = 0; i < 64; ++i) {
+        if (!on(i)) continue;
+        const int a = (int)(int64_t)L[i].a1, seg = i & ~(width - 1), r = i & (width - 1);
+        int s;
+        switch (mode) {
+          case 0: s = seg + (a & (width - 1)); break;
+          case 1: s = (r ^ a) < width ? seg + (r ^ a) : i; break;
+          case 2: s = r - a >= 0 ? seg + r - a : i; break;
+          default: s = r + a < width ? seg + r + a : i; break;
+        }
+        L[i].result = on(s) ? L[s].a0 : 0ull;  // ds_bpermute: a lane that is switched off contributes zero
+      }
+      break;
+    }
+    case kWaveBarrier: break;
+    default: die("unknown cross-lane operation");
+  }
+  for (int i = 0; i < 64; ++i) if (on(i)) L[i].state = kRunnable;
+}
+
+void run_workgroup(Worker* w) {
+  const int T = w->nthreads, nw = (T + 63) / 64;
+  for (int i = 0; i < T; ++i) prepare_lane(w, i);
+  for (;;) {
+    bool slept = false;
+    int n_done = 0, n_barrier = 0;
+    for (int wv = 0; wv < nw; ++wv) {
+      const int f = wv * 64, cnt = std::min(64, T - f);
+      for (;;) {
+        for (int i = 0; i < cnt; ++i) {
+          Lane& l = w->lanes[f + i];
+          if (l.state != kRunnable) continue;
+          w->cur = f + i;
+          threadIdx.x = (uint32_t)(f + i) % blockDim.x;
+          threadIdx.y = ((uint32_t)(f + i) / blockDim.x) % blockDim.y;
+          threadIdx.z = (uint32_t)(f + i) / (blockDim.x * blockDim.y);
+          emu_switch(&w->sched_sp, l.sp);
+        }
+        w->cur = -1;
+        uint64_t coll = 0;
+        bool sleepers = false;
+        for (int i = 0; i < cnt; ++i) {
+          const int s = w->lanes[f + i].state;
+          if (s == kCollective) coll |= 1ull << i;
+          else if (s == kSleep) sleepers = true;
+        }
+        if (sleepers) {  // come back to this wave after the others (and other workgroups) had their turn
+          for (int i = 0; i < cnt; ++i) if (w->lanes[f + i].state == kSleep) w->lanes[f + i].state = kRunnable;
+          slept = true;
+          break;
+        }
+        if (!coll) break;
+        run_collective(w, f, coll);
+      }
+    }
+    for (int i = 0; i < T; ++i) {
+      n_done += w->lanes[i].state == kDone;
+      n_barrier += w->lanes[i].state == kBarrier;
+    }
+    if (n_done == T) return;
+    if (n_done + n_barrier == T) {
+      int kind = 0, all = 1, any = 0, count = 0;
+      for (int i = 0; i < T; ++i) {
+        Lane& l = w->lanes[i];
+        if (l.state != kBarrier) continue;
+        if (kind == 0) kind = l.kind;
+        else if (kind != l.kind) die("the lanes of a workgroup wait at different kinds of barriers");
+        all &= l.a0 != 0; any |= l.a0 != 0; count += l.a0 != 0;
+      }
+      for (int i = 0; i < T; ++i) {
+        Lane& l = w->lanes[i];
+        if (l.state != kBarrier) continue;
+        l.result = kind == kSyncAnd ? all : kind == kSyncOr ? any : kind == kSyncCount ? count : 0;
+        l.state = kRunnable;
+      }
+      continue;
+    }
+    if (slept) { sched_yield(); continue; }
+    die("deadlock inside a workgroup: lanes wait for a cross-lane operation that the others cannot reach");
+  }
+}
+
+// ------------------------------------------------------------------ pool
+struct Pool {
+  std::mutex launch_mu;   // one launch at a time (host threads of the pipeline share the pool)
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  // the launch in flight
+  Launcher* job = nullptr;
+  const char* kname = "";
+  dim3 grid, block;
+  uint32_t total = 0;
+  std::atomic<uint32_t> next{0};
+  uint32_t finished = 0;
+  uint64_t generation = 0;
+  bool stop = false;
+  int nworkers = 0;
+
+  void worker_main() {
+    Worker* w = new Worker();
+    w->stacks = (char*)mmap(nullptr, kStackBytes * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (w->stacks == MAP_FAILED) { perror("mmap"); abort(); }
+    tl_worker = w;
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return stop || generation != seen; });
+        if (stop) break;
+        seen = generation;
+      }
+      uint32_t mine = 0;
+      for (;;) {
+        const uint32_t b = next.fetch_add(1u, std::memory_order_relaxed);
+        if (b >= total) break;
+        w->job = job; w->kname = kname; w->block_linear = b;
+        w->nthreads = (int)(block.x * block.y * block.z);
+        blockDim = {block.x, block.y, block.z};
+        gridDim = {grid.x, grid.y, grid.z};
+        blockIdx.x = b % grid.x; blockIdx.y = (b / grid.x) % grid.y; blockIdx.z = b / (grid.x * grid.y);
+        run_workgroup(w);
+        ++mine;
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        finished += mine + 1;  // + 1: this worker has left the launch
+        // (every worker adds one, so the launch is over at total + nworkers)
+      }
+      cv_done.notify_all();
+    }
+  }
+  void start() {
+    const char* e = getenv("PCC_EMU_WORKERS");
+    int n = e ? atoi(e) : (int)std::min<long>(8, sysconf(_SC_NPROCESSORS_ONLN));
+    nworkers = std::max(2, n);  // workgroup 0 of k_boxes_events waits for the others: they need a thread to run on
+    for (int i = 0; i < nworkers; ++i) threads.emplace_back([this] { worker_main(); });
+  }
+  void run(const char* name, dim3 g, dim3 b, Launcher& l) {
+    std::lock_guard<std::mutex> one(launch_mu);
+    if (threads.empty()) start();
+    const uint64_t nt = (uint64_t)b.x * b.y * b.z;
+    if (nt == 0 || nt > (uint64_t)kMaxThreads) { fprintf(stderr, "wave64 executor: %s: %llu threads per workgroup\n", name, (unsigned long long)nt); abort(); }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = &l; kname = name; grid = g; block = b;
+      total = g.x * g.y * g.z;
+      next.store(0);
+      finished = 0;
+      ++generation;
+    }
+    cv_work.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return finished == total + (uint32_t)nworkers; });
+    job = nullptr;
+  }
+};
+Pool& pool() {
+  static Pool* p = new Pool();  // never destroyed: the workers live as long as the process
+  return *p;
+}
+
+}  // namespace
+
+uint64_t ballot(int pred) { return yield_lane(kCollective, kBallot, (uint64_t)(pred != 0), 0); }
+int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  return (int)(uint32_t)yield_lane(kCollective, kDpp, (uint32_t)old, (uint32_t)src, ctrl, row_mask, bank_mask, bound_ctrl ? 1 : 0);
+}
+uint32_t readlane(uint32_t v, int lane) { return (uint32_t)yield_lane(kCollective, kReadlane, v, 0, lane); }
+uint32_t readfirstlane(uint32_t v) { return (uint32_t)yield_lane(kCollective, kReadfirst, v, 0); }
+uint64_t shfl64(uint64_t v, int a, int width, int mode) { return yield_lane(kCollective, kShfl, v, (uint64_t)(int64_t)a, width, mode); }
+void wave_barrier() { (void)yield_lane(kCollective, kWaveBarrier, 0, 0); }
+void syncthreads() { (void)yield_lane(kBarrier, kSync, 1, 0); }
+int syncthreads_and(int pred) { return (int)yield_lane(kBarrier, kSyncAnd, pred != 0, 0); }
+int syncthreads_or(int pred) { return (int)yield_lane(kBarrier, kSyncOr, pred != 0, 0); }
+int syncthreads_count(int pred) { return (int)yield_lane(kBarrier, kSyncCount, pred != 0, 0); }
+void sleep(int) { (void)yield_lane(kSleep, 0, 0, 0); }
+unsigned long long wall_clock() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec;  // "100 MHz" clock: see hipDeviceGetAttribute
+}
+void launch(void*, const char* name, dim3 grid, dim3 block, Launcher& l) {
+  if ((uint64_t)grid.x * grid.y * grid.z == 0) return;
+  pool().run(name, grid, block, l);
+}
+
+}  // namespace emu
+
+// -------------------------------------------------------------------- host API
+struct emuStream { int id; };
+struct emuEvent { unsigned long long t; };
+
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorNotReady ? "hipErrorNotReady" : "hipError (wave64 executor)"; }
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) {
+  const char* e = getenv("PCC_EMU_DEVICES");
+  *n = e ? atoi(e) : 1;
+  return hipSuccess;
+}
+static thread_local int tl_device = 0;
+hipError_t hipGetDevice(int* d) { *d = tl_device; return hipSuccess; }
+hipError_t hipSetDevice(int d) {
+  int n = 0;
+  hipGetDeviceCount(&n);
+  if (d < 0 || d >= n) return hipErrorInvalidDevice;
+  tl_device = d;
+  return hipSuccess;
+}
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  memset(p, 0, sizeof(*p));
+  snprintf(p->name, sizeof(p->name), "wave64 executor (CPU)");
+  snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
+  p->totalGlobalMem = (size_t)16 << 30;
+  p->multiProcessorCount = 256;
+  p->maxSharedMemoryPerMultiProcessor = 160 * 1024;
+  p->sharedMemPerBlock = 64 * 1024;
+  p->regsPerMultiprocessor = 128 * 1024;
+  p->maxThreadsPerMultiProcessor = 2048;
+  p->warpSize = 64;
+  p->clockRate = 2400000;
+  return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+  if (a == hipDeviceAttributeWallClockRate) { *v = 1000000; return hipSuccess; }  // kHz: wall_clock() counts nanoseconds
+  if (a == hipDeviceAttributeMultiprocessorCount) { *v = 256; return hipSuccess; }
+  return hipErrorInvalidValue;
+}
+hipError_t hipMalloc(void** p, size_t bytes) {
+  void* q = nullptr;
+  if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
+  // fresh device memory holds whatever was there before: poison it so that a kernel that relies on zeroes is caught
+  memset(q, 0xA5, bytes);
+  *p = q;
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+  void* q = nullptr;
+  if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
+  *p = q;
+  return hipSuccess;
+}
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void*) { return hipSuccess; }
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+  a->type = hipMemoryTypeUnregistered; a->device = 0; a->devicePointer = const_cast<void*>(p); a->hostPointer = const_cast<void*>(p);
+  return hipErrorInvalidValue;  // "not known to the runtime", what real HIP says of plain host memory
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) { memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemsetAsync(void* dst, int v, size_t bytes, hipStream_t) { memset(dst, v, bytes); return hipSuccess; }
+hipError_t hipMemset(void* dst, int v, size_t bytes) { memset(dst, v, bytes); return hipSuccess; }
+hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t bytes, size_t off, hipMemcpyKind) {
+  memcpy(dst, (const char*)sym + off, bytes);
+  return hipSuccess;
+}
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new emuStream{0}; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new emuStream{0}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent{0}; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emuEvent{0}; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu::wall_clock(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((double)(b->t - a->t) * 1e-6); return hipSuccess; }
