@@ -84,6 +84,7 @@ __device__ __forceinline__ uint64_t morton3(uint32_t kx, uint32_t ky, uint32_t k
 //      ds_bpermute, an LDS round trip of a hundred cycles or more per step, six steps per reduction; these run in the
 //      latency-bound stretches of every kernel: digit scans of the sort pass, the replay workgroup of k_boxes_events).
 //      All 64 lanes must be active.
+#ifndef PCC_WAVE_OPS_SHFL
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t identity, uint32_t v) {  // lanes without a source keep `identity`
   return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
@@ -117,16 +118,50 @@ __device__ __forceinline__ uint64_t wave_shr1(uint64_t v, uint64_t first) {
 __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ uint64_t lane63(uint64_t v) { return ((uint64_t)lane63((uint32_t)(v >> 32)) << 32) | lane63((uint32_t)v); }
 
+#else
+// -DPCC_WAVE_OPS_SHFL: the same helpers through __shfl (ds_bpermute), the form they had before the DPP rewrite -- a build
+// switch for bisecting (make shfl -> libpcc_hip_shfl.so; the parity tests run against either library through PCC_LIB)
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, uint32_t id, Op op) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl((int)v, lane - o);
+    v = op(v, lane >= o ? t : id);
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, int l) { return (uint32_t)__shfl((int)v, l); }
+__device__ __forceinline__ float lane_of(float v, int l) { return __shfl(v, l); }
+__device__ __forceinline__ uint64_t lane_of(uint64_t v, int l) { return ((uint64_t)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l); }
+__device__ __forceinline__ uint64_t wave_shr1(uint64_t v, uint64_t first) {
+  const int lane = lane_id();
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, lane - 1), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), lane - 1);
+  return lane ? (((uint64_t)hi << 32) | lo) : first;
+}
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return lane_of(v, 63); }
+__device__ __forceinline__ uint64_t lane63(uint64_t v) { return lane_of(v, 63); }
+#endif
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   return wave_scan_u32(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+#ifndef PCC_WAVE_OPS_SHFL
   v = dpp_add_u64<0x111, 0xf>(v);
   v = dpp_add_u64<0x112, 0xf>(v);
   v = dpp_add_u64<0x114, 0xf>(v);
   v = dpp_add_u64<0x118, 0xf>(v);
   v = dpp_add_u64<0x142, 0xa>(v);
   v = dpp_add_u64<0x143, 0xc>(v);
+#else
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, lane - o), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), lane - o);
+    if (lane >= o) v += ((uint64_t)hi << 32) | lo;
+  }
+#endif
   return v;
 }
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_incl_scan_u32(v); }
@@ -502,7 +537,11 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (f != 0x7fffffff) {
       first_box(s_p[0][f], s_p[1][f], s_p[2][f], f);
       PCC_KTR(8, 5);
+#ifndef PCC_WAVE_OPS_SHFL  // (the switch also restores the block-wide rounds for the first points: same commit as the DPP helpers)
       replay_first_lanes();
+#else
+      (void)replay_first_lanes;
+#endif
       PCC_KTR(8, 6);
       // the first chunk box of every thread is requested now and looked at after the block-wide rounds below: by then
       // the streaming workgroups have usually published, and the sweep starts with its first round trip behind it

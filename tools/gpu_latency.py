@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as G
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from frame_digests import check_frame
 
 pkg = G.load_package()
 b, syn = pkg.binding, pkg.synthetic
@@ -16,10 +18,16 @@ cfg = syn.CONFIGS[wl]
 p = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
                   jpeg_quality=cfg["jpeg_quality"], keep_centroid=cfg["keep_centroid"])
 ctx = b.Context(0)
-ctx.set_option("copy_image", 0)
 pts = syn.make_frame(wl)
 dev = ctx.upload(pts)
 n = len(pts)
+# parity line first: the frame that is about to be timed, with host copies and its bitstream, against the oracle's digests
+ctx.hotpath_launch(dev, n, p)
+_hot = ctx.hotpath_finish()
+_stream, _ = ctx.entropy_encode(_hot.raw, p)
+print("parity: %s frame 0 %s" % (wl, "matches the oracle's golden digests (bbox, occupancy, colours, bitstream)"
+                                  if check_frame(wl, 0, _hot, _stream) else "NOT CHECKED (no digest)"), flush=True)
+ctx.set_option("copy_image", 0)   # (the timed frames leave image and colours on the device)
 for prof in (0, 1, 2):   # 0 unprofiled, 1 HIP events between the launches + spans, 2 spans only (launches back to back)
     ctx.set_profiling(prof != 0)
     ctx.set_option("profile_events", 1 if prof == 1 else 0)
@@ -30,6 +38,7 @@ for prof in (0, 1, 2):   # 0 unprofiled, 1 HIP events between the launches + spa
         ctx.hotpath_launch(dev, n, p)
         hot = ctx.hotpath_finish(copy=False)
         w = time.perf_counter() - t
+        check_frame(wl, 0, hot)   # L, B, D and the bounding box of EVERY timed frame (no host copies in the timed loop)
         if k >= 3:
             ms.append(hot.gpu_ms); wall.append(w * 1e3)
             if prof:

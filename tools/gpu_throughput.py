@@ -6,6 +6,8 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as G
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from frame_digests import check_frame
 pkg = G.load_package(); b, syn = pkg.binding, pkg.synthetic
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 threads = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8, 16]
@@ -15,13 +17,18 @@ p = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], 
 pts = syn.make_frame(wl); n = len(pts)
 for T in threads:
     ctxs = [b.Context(0) for _ in range(T)]
-    for c in ctxs: c.set_option("copy_image", 0)
     dev = ctxs[0].upload(pts)
     K = 40 * T
+    for c in ctxs:   # parity line: every context's frame with host copies and bitstream against the oracle's digests
+        c.hotpath_launch(dev, n, p); h = c.hotpath_finish(); s, _ = c.entropy_encode(h.raw, p)
+        checked = check_frame(wl, 0, h, s)
+    print("parity: %s on %d contexts %s" % (wl, T, "matches the oracle's golden digests" if checked else "NOT CHECKED (no digest)"), flush=True)
+    for c in ctxs: c.set_option("copy_image", 0)
     def work(i):
         c = ctxs[i]
         for _ in range(K // T):
-            c.hotpath_launch(dev, n, p); c.hotpath_finish(copy=False)
+            c.hotpath_launch(dev, n, p)
+            check_frame(wl, 0, c.hotpath_finish(copy=False))   # L, B, D, bounding box of every timed frame
     with ThreadPoolExecutor(T) as ex:
         list(ex.map(work, range(T)))            # warm-up
         t = time.perf_counter(); list(ex.map(work, range(T))); dt = time.perf_counter() - t
