@@ -1,0 +1,77 @@
+"""The kernels' LOGIC on the CPU, for rounds in which no GPU can be reached.
+
+tests/emu is a wave64 executor: the product's own kernel and host sources compiled by g++ against a stand-in
+hip_runtime.h (workgroup = OS thread, lane = fibre, every cross-lane operation and barrier a meeting point of the lanes,
+LDS = thread-local storage, workgroups side by side on a thread pool so that look-back polls and tickets really wait for
+each other).  These tests run the `-m gpu` parity tests -- the same files, unchanged -- against that library in a child
+process (PCC_LIB), so what is compared with the oracle is every byte the GPU tests compare.
+
+What this is evidence of: the algorithm as written in the .hip sources, including the DPP scans as the ISA documents
+describe them.  What it is not: evidence about the hardware (timing, memory ordering on the real chip, register
+pressure) -- the `-m gpu` run on an MI355X stays the parity gate.  The product never loads this library: without a GPU
+`pcc_create` fails, as `test_product_library_has_no_cpu_fallback` checks.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+
+# linked against the real libpcc_hip.so (external executables) or in need of torch.cuda: not runnable on the executor
+NOT_ON_THE_EXECUTOR = [
+    "tests/test_bench_contract.py", "tests/test_evaluate_app.py", "tests/test_shim_boundary.py",
+    "tests/test_gpu_parity.py::test_cpp_shim_example_runs", "tests/test_gpu_parity.py::test_cpp_pipeline_bench_runs",
+]
+# minutes each on eight cores: only with PCC_EMU_FULL=1
+LONG = ["tests/test_delta_gpu.py::test_cfg5_at_its_stated_size",
+        "tests/test_gpu_parity.py::test_cfg4_reduced_parity_and_full_size_properties"]
+
+
+@pytest.fixture(scope="module")
+def emu_libs():
+    subprocess.run(["make", "-s", "-j8", "-C", EMU], check=True)
+    return os.path.join(EMU, "_build", "libpcc_emu.so"), os.path.join(EMU, "_build", "libpcc_emu_shfl.so")
+
+
+def run_gpu_tests(lib, targets, deselect=(), extra=()):
+    env = dict(os.environ, PCC_LIB=lib)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "1500"] + list(targets)
+    for d in deselect:
+        cmd += ["--deselect", d]
+    r = subprocess.run(cmd + list(extra), cwd=ROOT, env=env, capture_output=True, text=True)
+    tail = (r.stdout + r.stderr)[-3000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    return r.returncode, int(m.group(1)) if m else 0, tail
+
+
+def test_every_gpu_parity_test_passes_on_the_executor(emu_libs):
+    """All `-m gpu` tests of the repository (but the ones listed above), against the oracle, on the CPU executor."""
+    full = os.environ.get("PCC_EMU_FULL") == "1"
+    rc, passed, tail = run_gpu_tests(emu_libs[0], ["tests"], NOT_ON_THE_EXECUTOR + ([] if full else LONG))
+    assert rc == 0, tail
+    assert passed >= (168 if full else 166), tail
+
+
+def test_the_shfl_build_agrees(emu_libs):
+    """The bisecting build (-DPCC_WAVE_OPS_SHFL: wave scans and lane reads through __shfl, block-wide replay) gives the
+    same bytes: micro cases, every colour mode, the 48-case random sweep, cfg1."""
+    rc, passed, tail = run_gpu_tests(emu_libs[1], ["tests/test_gpu_parity.py"], NOT_ON_THE_EXECUTOR + LONG,
+                                     ["-k", "not cfg2 and not cfg3 and not pipeline and not headline and not short_calls"])
+    assert rc == 0, tail
+    assert passed >= 100, tail
+
+
+def test_product_library_has_no_cpu_fallback(pkg):
+    """The library the product loads (libpcc_hip.so) refuses to work without a HIP device; the executor is only ever
+    reached through an explicit PCC_LIB."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert "PCC_LIB" not in os.environ
+    assert os.path.basename(pkg.binding.LIB_PATH) == "libpcc_hip.so"
+    with pytest.raises(RuntimeError, match="no usable MI355X/HIP device"):
+        pkg.binding.Context(0)
