@@ -210,16 +210,38 @@ void run_collective(Worker* w, int wave_first, uint64_t active) {
   for (int i = 0; i < 64; ++i) if (on(i)) L[i].state = kRunnable;
 }
 
+// PCC_EMU_SHUFFLE=<seed>: the waves of a workgroup take their turns in a different pseudo-random order in every sweep, and
+// so do the lanes of a wave between two meeting points -- nothing a correct kernel can notice (the hardware promises no
+// order between waves, and between meeting points the lanes' effects are simultaneous), but a missing barrier or a
+// forgotten lockstep marker shows up as a parity failure instead of passing by the luck of "wave 0 first, lane 0 first".
+uint64_t shuffle_seed() {
+  static const uint64_t s = [] { const char* e = getenv("PCC_EMU_SHUFFLE"); return e ? (uint64_t)strtoull(e, nullptr, 0) * 2u + 1u : 0ull; }();
+  return s;
+}
+inline uint32_t next_rand(uint64_t& st) {
+  st = st * 6364136223846793005ull + 1442695040888963407ull;
+  return (uint32_t)(st >> 33);
+}
+
 void run_workgroup(Worker* w) {
   const int T = w->nthreads, nw = (T + 63) / 64;
   for (int i = 0; i < T; ++i) prepare_lane(w, i);
+  uint64_t rnd = shuffle_seed() ? shuffle_seed() ^ ((uint64_t)w->block_linear * 0x9E3779B97F4A7C15ull) : 0ull;
+  int wave_order[kMaxThreads / 64], lane_order[64];
+  for (int i = 0; i < nw; ++i) wave_order[i] = i;
+  for (int i = 0; i < 64; ++i) lane_order[i] = i;
   for (;;) {
     bool slept = false;
     int n_done = 0, n_barrier = 0;
-    for (int wv = 0; wv < nw; ++wv) {
+    if (rnd) for (int i = nw - 1; i > 0; --i) std::swap(wave_order[i], wave_order[next_rand(rnd) % (uint32_t)(i + 1)]);
+    for (int wi = 0; wi < nw; ++wi) {
+      const int wv = wave_order[wi];
       const int f = wv * 64, cnt = std::min(64, T - f);
       for (;;) {
-        for (int i = 0; i < cnt; ++i) {
+        if (rnd) for (int i = 63; i > 0; --i) std::swap(lane_order[i], lane_order[next_rand(rnd) % (uint32_t)(i + 1)]);
+        for (int li = 0; li < 64; ++li) {
+          const int i = lane_order[li];
+          if (i >= cnt) continue;
           Lane& l = w->lanes[f + i];
           if (l.state != kRunnable) continue;
           w->cur = f + i;
