@@ -67,7 +67,17 @@ static void encode_jpeg_snake(pcco_frame *f, int quality) {
   pcco_buf_free(&in);
 }
 
-/* C3: encodeJPEGLines (jpegcc.h:244-317) + JPEGLineData::serialize (:72-83) */
+/* C3: encodeJPEGLines (jpegcc.h:244-317) + JPEGLineData::serialize (:72-83)
+ *
+ * KNOWN DIVERGENCE from the reference, frames with fewer than 2048 voxels only: the reference sets im_in.width = 2048
+ * (jpegcc.h:256) and never narrows it in the `num_lines == 0` branch (jpegcc.h:261-275), so writeJPEG (jpeg_io.hpp:259,
+ * 302-309) codes a 2048-pixel strip and reads 3 * (2048 - L) bytes past the end of the 3 L-byte buffer: the tail of
+ * that strip -- and through the shared 8x8 / 16x16 blocks the last few real pixels -- is undefined (it can also fault).
+ * Nobody can reproduce undefined bytes; this restatement (and the product) codes the L x 1 strip the function evidently
+ * means, which decodeJPEGLines (jpegcc.h:319-344) reads back the same way (it appends every decoded pixel and the
+ * voxels take the first L).  The converse -- a 2048-wide strip from a real reference encoder -- is accepted by both
+ * decoders: tests/test_host_stage.py::test_host_decoder_accepts_the_2048_wide_strip_a_reference_encoder_writes.
+ * For L >= 2048 the reference narrows the last strip (jpegcc.h:305) and the bytes are defined and matched. */
 static void encode_jpeg_lines(pcco_frame *f, int quality) {
   long pixel_count = (long)f->bgr.len / 3;
   int num_lines = (int)(pixel_count / 2048);

@@ -168,3 +168,23 @@ def encode_geometry(points, res):
     return dict(bbox=np.concatenate([mn, mx]), depth=depth, leaf_keys=demorton(leaf_codes, depth),
                 leaf_counts=counts, occupancy=occ, bgr=bgr.reshape(-1), n_events=len(events),
                 sorted_idx=sidx, starts=starts)
+
+
+def reference_style_lines_stream(oracle, pts, L_expected=None, tail_value=0x5A, **kw):
+    """A colour-coding-type-2 frame as the REFERENCE's own encoder writes it when the frame has fewer than 2048 voxels:
+    jpegcc.h:256-275 leaves `im_in.width = 2048` in the `num_lines == 0` branch, so writeJPEG (jpeg_io.hpp:259,302-309)
+    codes a 2048-pixel strip whose first L pixels are the voxels' colours and whose tail is whatever lies behind the
+    3 L-byte buffer (undefined; a fixed byte here).  Returns (stream, strip as decoded by the oracle's JPEG decoder)."""
+    import struct
+    want = oracle.encode_intra(pts, oracle.make_params(color_coding_type=2, **kw))
+    L = want.n_leaves
+    assert L < 2048 and (L_expected is None or L == L_expected)
+    own_payload = want.color_payload
+    tail_len = 8 + len(oracle.rc_encode(own_payload))          # u64 length + range-coded payload close the frame
+    prefix = want.bitstream[:-tail_len]
+    strip = np.full((1, 2048, 3), tail_value, dtype=np.uint8)
+    strip[0, :L, :] = want.bgr.reshape(L, 3)
+    jpg = oracle.jpeg_encode(strip, kw.get("jpeg_quality", 85))
+    payload = struct.pack("<II", 1, len(jpg)) + jpg                 # JPEGLineData::serialize: line count, size, bytes
+    stream = prefix + struct.pack("<Q", len(payload)) + oracle.rc_encode(payload)
+    return stream, oracle.jpeg_decode(jpg)[0], want

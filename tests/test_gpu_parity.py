@@ -679,6 +679,20 @@ def test_gpu_decode_equals_the_oracles_decoder(pkg, oracle, ctx, kw):
         ctx.decode_intra(b"no frame here", on_gpu=True)
 
 
+def test_gpu_decode_accepts_the_2048_wide_strip_a_reference_encoder_writes(pkg, oracle, ctx):
+    """Colour coding type 2, fewer than 2048 voxels, as the reference's own encoder writes it (one strip 2048 wide, the
+    tail an over-read: jpegcc.h:256-275): pcc_decode_intra_gpu and pcc_decode_intra use the first L pixels like
+    decodeJPEGLines does (jpegcc.h:319-344)."""
+    for n, seed in ((40, 1), (600, 2), (1500, 3)):
+        pts = pkg.synthetic.sphere_shell(n, 0x11E5 + seed)
+        stream, strip, want = sortform.reference_style_lines_stream(oracle, pts, octree_bits=6, jpeg_quality=75, frame_id=2)
+        ref = oracle.decode_intra(stream).points
+        got, info = ctx.decode_intra(stream + b"next frame", on_gpu=True)
+        host, _ = ctx.decode_intra(stream)
+        assert info["consumed"] == len(stream) and len(got) == want.n_leaves
+        assert got.tobytes() == ref.tobytes() and host.tobytes() == ref.tobytes()
+
+
 def test_gpu_decode_of_the_headline_frame(pkg, oracle, ctx):
     """cfg2 (1 M points, 10-bit octree, JPEG snake): decoded cloud identical to the oracle's; the times of the two halves
     are reported by pcc_get_decode_times."""

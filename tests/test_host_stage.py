@@ -249,3 +249,21 @@ def test_normalize_group_matches_numpy(pkg):
     assert lib.pcc_restore_scaling(a.ctypes.data, len(a), mn.ctypes.data, mx.ctypes.data) == 0
     for ax in "xyz":
         assert np.abs(a[ax] - raw[ax]).max() < 1e-5
+
+
+def test_host_decoder_accepts_the_2048_wide_strip_a_reference_encoder_writes(pkg, oracle):
+    """Colour coding type 2 with fewer than 2048 voxels: the reference's encoder writes ONE strip 2048 pixels wide
+    (jpegcc.h:256-275, the width is never narrowed in the `num_lines == 0` branch; the pixels beyond the voxels are an
+    over-read).  decodeJPEGLines (jpegcc.h:319-344) appends every decoded pixel and the voxels take the first L: the
+    product's host decoder and the oracle's decoder must do the same with such a stream."""
+    import sortform
+    for n, seed in ((40, 1), (600, 2), (1500, 3)):
+        pts = pkg.synthetic.sphere_shell(n, 0x11E5 + seed)
+        stream, strip, want = sortform.reference_style_lines_stream(oracle, pts, octree_bits=6, jpeg_quality=75, frame_id=2)
+        L = want.n_leaves
+        ref = oracle.decode_intra(stream).points
+        got, info = pkg.binding.Context(None).decode_intra(stream + b"next frame")
+        assert info["consumed"] == len(stream) and len(got) == L
+        assert got.tobytes() == ref.tobytes()
+        own = oracle.decode_intra(want.bitstream).points       # the L x 1 strip this codec writes: same positions
+        assert np.array_equal(got["x"], own["x"]) and np.array_equal(got["y"], own["y"]) and np.array_equal(got["z"], own["z"])
