@@ -62,10 +62,11 @@ def parse():
 def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
     # no centroids in the bench workloads: the sort key is [code | colour] or the code alone, 8 bytes, no payload array
     col = 4 if with_color else 0
-    if name == "k_boxes_events":
-        return 16 * n                      # x,y,z(,w) of every point (the replaying workgroup reads a chunk or two again)
-    if name == "k_make_keys":
-        return (16 + col) * n + 8 * n      # read xyz (+ colour word), write key
+    fused = os.environ.get("PCC_FUSED_KEYS", "1") != "0" and (n + 2047) // 2048 <= 1024
+    if name == "k_boxes_events":           # fused mode: the streaming workgroups also write the keys (the cloud is read once)
+        return (16 + col) * n + 8 * n if fused else 16 * n   # x,y,z(,w) (+ colour word) of every point (+ key out)
+    if name == "k_make_keys":              # fused mode: only the chunk that holds the growth events is visited
+        return (16 + col + 8) * min(n, 2048) if fused else (16 + col) * n + 8 * n
     if name == "k_sort_pass":
         return 2 * 8 * n                   # read keys, write keys
     if name == "k_leaf_scan":

@@ -98,6 +98,7 @@ struct pcc_ctx {
   // HBM arena (see pcc_device.h for the layout)
   DevBuf<uint8_t> d_points;  // only for the host-input entry point
   DevBuf<uint64_t> d_boxes;   // eight self-describing words per chunk (k_boxes_events)
+  DevBuf<uint64_t> d_plan;    // fused mode: the sort plan and one word per chunk, self-describing as well
   uint32_t frame_seq = 0;     // sequence number of the last enqueued frame; stamps its chunk boxes
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
@@ -207,12 +208,16 @@ int reserve(pcc_ctx* ctx, size_t n) {
     PCC_HIP(ctx->d_boxes.ensure(8 * tiles));
     PCC_HIP(hipMemsetAsync(ctx->d_boxes.p, 0, ctx->d_boxes.cap * sizeof(uint64_t), ctx->stream));
   }
+  if (ctx->d_plan.cap < kPlanGranulesHost + tiles) {  // (the same: nothing in a fresh array may look like this frame's plan)
+    PCC_HIP(ctx->d_plan.ensure(kPlanGranulesHost + tiles));
+    PCC_HIP(hipMemsetAsync(ctx->d_plan.p, 0, ctx->d_plan.cap * sizeof(uint64_t), ctx->stream));
+  }
   PCC_HIP(ctx->d_state.ensure(1));
   PCC_HIP(ctx->d_keys_a.ensure(n));
   PCC_HIP(ctx->d_keys_b.ensure(n));
   PCC_HIP(ctx->d_idx_a.ensure(n));
   PCC_HIP(ctx->d_idx_b.ensure(n));
-  PCC_HIP(ctx->d_hist_rows.ensure(stiles * kMaxPasses * kMaxBins));
+  PCC_HIP(ctx->d_hist_rows.ensure(std::max(stiles, tiles) * kMaxPasses * kMaxBins));  // a row per sort tile, or per chunk (fused mode)
   PCC_HIP(ctx->d_digit_tot.ensure((size_t)kMaxPasses * kMaxBins));
   PCC_HIP(ctx->d_tile_prefix0.ensure(stiles * kMaxBins));
   PCC_HIP(ctx->d_sync.ensure(sync_area_bytes((uint32_t)n, kMaxPasses)));
@@ -404,7 +409,7 @@ void pcc_destroy(pcc_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->locked_host) { unlock_host_range(c->locked_host); c->locked_host = nullptr; }
   c->d_dec.release(); c->d_dec_points.release(); c->h_dec_stage.release(); c->h_dec_points.release();
-  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
+  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_plan.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release(); c->d_lines.release(); c->h_lines.release();
@@ -555,6 +560,15 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
     a.no_cell_ranks = (nr && nr[0] == '1') ? 1 : 0;
   }
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
+  {
+    // PCC_FUSED_KEYS=0: the two-kernel form (k_boxes_events reads the coordinates, k_make_keys reads the cloud again);
+    // PCC_PLAN_SPINS: how long a streaming workgroup waits for the plan (test hook: 1 = every chunk falls back)
+    static const int fused_env = [] { const char* e = getenv("PCC_FUSED_KEYS"); return e ? atoi(e) : 1; }();
+    static const int spins_env = [] { const char* e = getenv("PCC_PLAN_SPINS"); return e ? atoi(e) : 0; }();
+    a.fused_keys = fused_env ? 1 : 0;
+    a.plan = ctx->d_plan.p;
+    a.plan_spins = spins_env > 0 ? (uint32_t)spins_env : kDefaultPlanSpins;
+  }
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
   a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
   a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.tile_prefix0 = ctx->d_tile_prefix0.p; a.sync_area = ctx->d_sync.p;
@@ -622,6 +636,22 @@ int pcc_debug_sort_plan(pcc_ctx* ctx, int32_t out[5]) {
   PCC_NEED_GPU();
   const FrameState& st = *ctx->h_state.p;
   out[0] = st.npasses; out[1] = st.code_bits; out[2] = st.vbits; out[3] = st.code_low_bits; out[4] = st.payload ? 12 : 8;
+  return PCC_OK;
+}
+
+// developer aid (not part of include/pcc_codec.h): fused mode of the last frame launched on this context --
+// {chunks whose keys the streaming workgroups of k_boxes_events made themselves, chunks of the frame, 1 if the mode was on}
+int pcc_debug_fused_chunks(pcc_ctx* ctx, uint32_t out[3]) {
+  if (!ctx || !out) return PCC_ERR_ARG;
+  PCC_NEED_GPU();
+  PCC_HIP(hipSetDevice(ctx->device));
+  const uint32_t chunks = (uint32_t)((ctx->args.n + kTile - 1) / kTile);
+  out[0] = 0; out[1] = chunks; out[2] = (ctx->args.fused_keys && ctx->args.plan && chunks <= kFusedMaxChunks) ? 1u : 0u;
+  if (!out[2] || !chunks) return PCC_OK;
+  std::vector<uint64_t> w(chunks);
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  PCC_HIP(hipMemcpy(w.data(), ctx->args.plan + kPlanGranulesHost, chunks * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  for (uint64_t x : w) out[0] += ((uint32_t)(x >> 32) == ctx->args.frame_seq && (uint32_t)x != 0u) ? 1u : 0u;
   return PCC_OK;
 }
 

@@ -68,6 +68,9 @@ struct HotPathArgs {
   int need_index;  // somebody reads the point index of the sorted elements (centroids, macroblock trees): keep it in the key
   FixedBox box;    // defineBoundingBox before addPointsFromInputCloud
   int stop_after_leaf_scan;  // macroblock trees: only the sorted points and the leaf (= block) arrays are wanted
+  int fused_keys;      // 1: the streaming workgroups of k_boxes_events make the sort keys themselves (the cloud is read once)
+  uint64_t* plan;      // fused mode: 64 plan granules, then one granule per chunk, {frame_seq, value} each (zeroed when allocated)
+  uint32_t plan_spins; // fused mode: how often a streaming workgroup polls for the plan before it leaves its chunk to k_make_keys
   uint64_t* boxes;     // eight {value, frame_seq} words per 2048-point chunk (zeroed when allocated)
   uint32_t frame_seq;  // never 0, different from the frame before on this arena: tells this frame's chunk boxes from older ones
   FrameState* state;
@@ -138,6 +141,17 @@ class KernelTimer {
 };
 
 size_t sync_area_bytes(uint32_t n, int passes);
+// fused mode is for frames whose bounding-box chunks can all be resident at once (the streaming workgroups wait for the plan)
+constexpr uint32_t kFusedMaxChunks = 1024;
+constexpr size_t kPlanGranulesHost = 64;  // = kPlanGranules of pcc_kernels.hip
+// a poll and an s_sleep(32) take about a microsecond on the GPU: the plan of a lone frame arrives after ~15 us, so this
+// bound is only met when the grid is not resident as a whole (other frames' kernels in the way).  The CPU executor of
+// tests/emu has no clock to speak of: there the bound is large, and a test sets it to 1 to see the fallback work.
+#ifdef PCC_EMU
+constexpr uint32_t kDefaultPlanSpins = 1u << 22;
+#else
+constexpr uint32_t kDefaultPlanSpins = 96;
+#endif
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm);
 
 }  // namespace pcc

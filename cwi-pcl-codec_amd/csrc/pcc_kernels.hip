@@ -272,6 +272,61 @@ struct KSpan {
 // ------------------------------------------------------------------------------------------
 constexpr int kBoxWords = 8;  // mn xyz, mx xyz, first finite index, finite count
 
+// ---- octree key of a point (P3, genOctreeKeyforPoint) -> the code that is sorted.  Shared by k_make_keys and by the
+//      streaming workgroups of k_boxes_events when they make the keys themselves (fused mode, below).
+constexpr uint64_t kInvalidKey = ~0ull;
+struct KeyGeom {
+  int vb, cm, np, ibits, payload;
+  bool packed_mode, colour_in_key, ranked;
+  unsigned cbase[3], cdim[3], lm, m;
+  uint32_t prefix[3];
+  int pshift[kMaxPasses];
+  uint32_t pmask[kMaxPasses];
+};
+// `mn`, `shift`: origin and key offset of the epoch the point belongs to; `cell_rank`: FrameState::cell_rank or a copy
+__device__ __forceinline__ uint64_t point_code(const KeyGeom& g, const double* mn, const uint32_t* shift, const uint8_t* cell_rank, double res,
+                                               double inv_res_pow2, float x, float y, float z, bool& ok) {
+  const float p[3] = {x, y, z};
+  unsigned kk[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // x / res; when res is a power of two the product with its (exact) reciprocal is the same double
+    const double diff = __dsub_rn((double)p[a], mn[a]);
+    const double d = inv_res_pow2 != 0.0 ? __dmul_rn(diff, inv_res_pow2) : __ddiv_rn(diff, res);
+    kk[a] = (unsigned)d + shift[a];
+    ok &= g.vb >= 32 || ((kk[a] >> g.vb) == (g.prefix[a] >> g.vb));
+  }
+  if (!g.ranked) return morton3(kk[0] & g.m, kk[1] & g.m, kk[2] & g.m);
+  unsigned d[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { d[a] = (kk[a] >> g.cm) - g.cbase[a]; ok &= d[a] < g.cdim[a]; }
+  const unsigned cell = ok ? d[2] + g.cdim[2] * (d[1] + g.cdim[1] * d[0]) : 0u;
+  return ((uint64_t)cell_rank[cell] << (3 * g.cm)) | morton3(kk[0] & g.lm, kk[1] & g.lm, kk[2] & g.lm);
+}
+
+// ---- fused mode ("read the cloud once"): the streaming workgroups keep their 2048 points in registers, and once
+//      workgroup 0 has published the sort plan they turn them into sort keys and digit counts themselves; k_make_keys
+//      then only visits the chunks that could not do that (the chunk that holds the growth events -- normally chunk 0
+//      alone --, a workgroup whose wait for the plan ran out).  The plan is a block of self-describing 8-byte granules
+//      {frame sequence number, value} (cdna_hip_programming.md guideline 16, form R2: the data is the flag, every word
+//      one agent-scope store and one agent-scope load, no fence).  Behind the plan, one granule per chunk says what
+//      became of it: 1 = keys and digit counts written, 2 = the same, but a key fell outside the predicted window.
+//      A streaming workgroup waits for workgroup 0, which waits for every streaming workgroup's BOX -- published
+//      before the wait starts -- so nobody waits for anybody who waits for him; the wait is bounded all the same
+//      (`plan_spins`), because with other frames' kernels on the GPU the grid need not be resident as a whole.
+constexpr int kPlanMn = 0;          // 6 words: the final box origin (three doubles)
+constexpr int kPlanBits = 6;        // vb | cm << 8 | np << 16 | ibits << 24
+constexpr int kPlanFlags = 7;       // 1 valid | packed << 1 | payload << 2 | colour_in_key << 4
+constexpr int kPlanPrefix = 8;      // 3 words
+constexpr int kPlanCellBase = 11;   // 3 words
+constexpr int kPlanCellDim = 14;    // 3 words
+constexpr int kPlanLastEpoch = 17;  // index of the first point of the last epoch
+constexpr int kPlanPass = 18;       // kMaxPasses words: bits | shift << 8
+constexpr int kPlanRanks = 25;      // 16 words: cell_rank[64]
+constexpr int kPlanWords = 41;
+constexpr int kPlanGranules = 64;   // the per-chunk granules start here
+static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords <= 64 && kPlanGranules == (int)kPlanGranulesHost, "one wave sweeps the plan");
+
 __device__ __forceinline__ void publish_box(uint64_t* dst, const ChunkBox& b, uint32_t seq) {
   uint32_t v[kBoxWords];
   __builtin_memcpy(v, &b, sizeof(b));
@@ -296,8 +351,21 @@ __device__ __forceinline__ bool fetch_box(const uint64_t* src, uint32_t seq, Chu
   return decode_box(w, seq, b);
 }
 
+// what the streaming workgroups need to make keys themselves (fused mode); all null / zero otherwise
+struct FusedKeys {
+  uint64_t* plan;        // kPlanGranules plan granules, then one granule per chunk
+  uint64_t* keys;
+  uint32_t* idx;
+  uint32_t* hist_rows;   // one row of kMaxPasses x kMaxBins digit counts per CHUNK in this mode
+  double inv_res_pow2;
+  uint32_t plan_spins;   // polls of the plan before a workgroup gives up and leaves its chunk to k_make_keys
+  int do_color;
+};
+
+template <bool FUSED>
 __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n, uint32_t c, uint32_t n_chunks, uint64_t* __restrict__ boxes,
-                                                uint32_t seq, uint4* __restrict__ sync_area, uint32_t sync_vec16, float* s_f, int* s_i) {
+                                                uint32_t seq, uint4* __restrict__ sync_area, uint32_t sync_vec16, float* s_f, int* s_i,
+                                                double res, const FusedKeys& fk) {
   float(*s_mn)[kBlock / 64] = reinterpret_cast<float(*)[kBlock / 64]>(s_f);
   float(*s_mx)[kBlock / 64] = reinterpret_cast<float(*)[kBlock / 64]>(s_f + 3 * (kBlock / 64));
   int* s_first = s_i;
@@ -308,18 +376,25 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
   const uint32_t base = c * kTile;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   int first = 0x7fffffff, cnt = 0;
+  // fused mode: the chunk stays in registers until the plan is there (a non-finite point as NaN; colour words only when
+  // the frame has colours)
+  float px[FUSED ? kItems : 1], py[FUSED ? kItems : 1], pz[FUSED ? kItems : 1];
+  uint32_t pc[FUSED ? kItems : 1];
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
     const uint32_t i = base + k * kBlock + threadIdx.x;
+    if (FUSED) { px[FUSED ? k : 0] = __builtin_nanf(""); pc[FUSED ? k : 0] = 0u; }
     if (i < n) {
       float x, y, z;
       load_xyz(pv, i, x, y, z);
+      if (FUSED && fk.do_color) pc[FUSED ? k : 0] = load_rgba(pv, i);
       if (finite3(x, y, z)) {
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
         mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         first = min(first, (int)i);
         ++cnt;
+        if (FUSED) { px[FUSED ? k : 0] = x; py[FUSED ? k : 0] = y; pz[FUSED ? k : 0] = z; }
       }
     }
   }
@@ -346,17 +421,86 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     publish_box(boxes + (size_t)c * kBoxWords, b, seq);
   }
   PCC_KTR(6, 7);
+  if (!FUSED) return;
+
+  // ---- fused mode: wait for the plan (bounded), then keys and digit counts of this chunk ----
+  uint32_t* s_plan = reinterpret_cast<uint32_t*>(s_f) + 64;   // [kPlanWords] + {got it, a key missed the window}
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_f) + 128;  // [np][kMaxBins]
+  if (wave_id() == 0) {
+    const int l = lane_id();
+    bool got = false;
+    for (uint32_t spin = 0; spin < fk.plan_spins; ++spin) {
+      const uint64_t w = l < kPlanWords ? poll_u64(fk.plan + l) : ((uint64_t)seq << 32);
+      const bool there = (uint32_t)(w >> 32) == seq;
+      if (__ballot(!there) == 0ull) {
+        if (l < kPlanWords) s_plan[l] = (uint32_t)w;
+        got = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (l == 0) { s_plan[kPlanWords] = got ? 1u : 0u; s_plan[kPlanWords + 1] = 0u; }
+  }
+  __syncthreads();
+  if (!s_plan[kPlanWords]) return;                       // the wait ran out: k_make_keys does this chunk
+  const uint32_t flags = s_plan[kPlanFlags];
+  if (!(flags & 1u)) return;                            // the frame ended in an error or holds no finite point
+  if ((int)base < (int)s_plan[kPlanLastEpoch]) return;  // points of earlier epochs in here: k_make_keys has the epoch table
+  KeyGeom g;
+  {
+    const uint32_t bits = s_plan[kPlanBits];
+    g.vb = (int)(bits & 0xffu); g.cm = (int)((bits >> 8) & 0xffu); g.np = (int)((bits >> 16) & 0xffu); g.ibits = (int)(bits >> 24);
+    g.packed_mode = ((flags >> 1) & 1u) != 0; g.payload = (int)((flags >> 2) & 3u); g.colour_in_key = ((flags >> 4) & 1u) != 0;
+    g.ranked = g.cm < g.vb;
+    g.lm = g.cm >= 32 ? 0xffffffffu : ((1u << g.cm) - 1u);
+    g.m = g.vb >= 32 ? 0xffffffffu : ((1u << g.vb) - 1u);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g.prefix[a] = s_plan[kPlanPrefix + a]; g.cbase[a] = s_plan[kPlanCellBase + a]; g.cdim[a] = s_plan[kPlanCellDim + a]; }
+#pragma unroll
+    for (int q = 0; q < kMaxPasses; ++q) { const uint32_t w = s_plan[kPlanPass + q]; g.pshift[q] = (int)(w >> 8); g.pmask[q] = (1u << (w & 0xffu)) - 1u; }
+  }
+  double emn[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) emn[a] = __longlong_as_double((long long)(((uint64_t)s_plan[kPlanMn + 2 * a + 1] << 32) | s_plan[kPlanMn + 2 * a]));
+  const uint32_t no_shift[3] = {0u, 0u, 0u};  // nothing re-roots the tree after the last epoch has begun
+  const uint8_t* ranks = reinterpret_cast<const uint8_t*>(s_plan + kPlanRanks);
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) s_hist[k] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint32_t i = base + k * kBlock + threadIdx.x;
+    if (i >= n) break;
+    uint64_t key = kInvalidKey;
+    if (px[FUSED ? k : 0] == px[FUSED ? k : 0]) {  // finite (NaN marks the others)
+      bool ok = true;
+      const uint64_t code = point_code(g, emn, no_shift, ranks, res, fk.inv_res_pow2, px[FUSED ? k : 0], py[FUSED ? k : 0], pz[FUSED ? k : 0], ok);
+      if (!ok) s_plan[kPlanWords + 1] = 1u;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
+#pragma unroll
+      for (int q = 0; q < kMaxPasses; ++q)
+        if (q < g.np) atomicAdd(&s_hist[q * kMaxBins + ((uint32_t)(code >> g.pshift[q]) & g.pmask[q])], 1u);
+      const uint64_t low = g.colour_in_key ? (uint64_t)(pc[FUSED ? k : 0] & 0xffffffu) : (g.ibits ? (uint64_t)i : 0ull);
+      key = g.packed_mode ? ((code << g.ibits) | low) : code;
+    }
+    if (g.payload == 1) fk.idx[i] = i;
+    else if (g.payload == 2) fk.idx[i] = pc[FUSED ? k : 0];
+    fk.keys[i] = key;
+  }
+  __syncthreads();
+  uint32_t* row = fk.hist_rows + (size_t)c * kMaxPasses * kMaxBins;
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) row[k] = s_hist[k];
+  if (threadIdx.x == 0) publish_u64(fk.plan + kPlanGranules + c, ((uint64_t)seq << 32) | (s_plan[kPlanWords + 1] ? 2u : 1u));
 }
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
                                                          int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int do_color, FixedBox box,
-                                                         FrameState* __restrict__ st, unsigned long long* span) {
+                                                         FrameState* __restrict__ st, FusedKeys fk, unsigned long long* span) {
   const KSpan kspan(span);
-  __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction
+  __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction (fused mode: plan, digit counts)
   __shared__ int s_redi[2][kBlock / 64];
   if (blockIdx.x != 0) {
-    chunk_box_block(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0]);
+    if (fk.plan) chunk_box_block<true>(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0], res, fk);
+    else chunk_box_block<false>(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0], res, fk);
     return;
   }
   __shared__ int ev_index[kMaxEpochs], ev_lowered[kMaxEpochs], ev_depth_before[kMaxEpochs];
@@ -602,6 +746,8 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         st->code_low_bits = 0; st->code_bits = 0;
         st->passes_launched = passes_launched;
       }
+      // fused mode: nobody makes keys for this frame (the streaming workgroups need not wait for their time-out to learn it)
+      if (fk.plan && threadIdx.x < kPlanWords) publish_u64(fk.plan + threadIdx.x, (uint64_t)seq << 32);
       return;
     }
     float fx, fy, fz;  // chunk 0 held no finite point: the first one of the cloud comes from the chunk boxes
@@ -703,6 +849,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       if (passes_for(bits) < passes_for(cbits)) { cm = m; cbits = bits; for (int a = 0; a < 3; ++a) cdim[a] = d[a]; }
     }
     if (no_cell_ranks) { cm = vb; cbits = 3 * vb; cdim[0] = cdim[1] = cdim[2] = 1u; }
+    uint8_t st_rank_of_lane = 0;  // rank of cell `lane` (also goes into the fused mode's plan below)
     {
       const unsigned nc = cdim[0] * cdim[1] * cdim[2];
       const int i = lane_id();
@@ -717,6 +864,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         const uint64_t other = lane_of(mort, (int)j);
         rank += (other < mort) ? 1u : 0u;
       }
+      st_rank_of_lane = (uint8_t)rank;
       if ((unsigned)i < nc && nc > 1u) { st->cell_rank[i] = (uint8_t)rank; st->cell_abs[rank] = mort; }
       if (i < 3) { st->cell_base[i] = kmin[i] >> cm; st->cell_dim[i] = cdim[i]; }
       if (i == 0) { st->code_low_bits = cm; st->code_bits = cbits; }
@@ -761,6 +909,48 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->npasses = err != kErrNone ? 0 : np;
       st->error = err;
     }
+    // fused mode: the same plan for the streaming workgroups, who are waiting for it with their points in registers
+    // (one granule per lane; every value is uniform over the wave, or this lane's own: pass p, the cell ranks)
+    if (fk.plan) {
+      __shared__ uint8_t s_rank8[64];
+      {
+        const unsigned nc = cdim[0] * cdim[1] * cdim[2];
+        s_rank8[p] = ((unsigned)p < nc && nc > 1u) ? st_rank_of_lane : (uint8_t)0;
+      }
+      PCC_WAVE_LOCKSTEP();
+#define PCC_PICK3(arr, k) ((k) == 0 ? (arr)[0] : ((k) == 1 ? (arr)[1] : (arr)[2]))  /* (no indexed register arrays) */
+      uint32_t v = 0u;
+      if (p < 6) {
+        const uint64_t bits = (uint64_t)__double_as_longlong(PCC_PICK3(mn, p >> 1));
+        v = (p & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
+      } else if (p == kPlanBits) {
+        v = (uint32_t)vb | ((uint32_t)cm << 8) | ((uint32_t)np << 16) | ((uint32_t)ibits << 24);
+      } else if (p == kPlanFlags) {
+        const uint32_t payload = bare ? 0u : (packed ? (do_color ? 2u : 0u) : 1u);
+        v = (err == kErrNone ? 1u : 0u) | ((uint32_t)packed << 1) | (payload << 2) | (((bare && do_color) ? 1u : 0u) << 4);
+      } else if (p >= kPlanPrefix && p < kPlanPrefix + 3) {
+        v = vb >= 32 ? 0u : ((PCC_PICK3(kmin, p - kPlanPrefix) >> vb) << vb);
+      } else if (p >= kPlanCellBase && p < kPlanCellBase + 3) {
+        v = PCC_PICK3(kmin, p - kPlanCellBase) >> cm;
+      } else if (p >= kPlanCellDim && p < kPlanCellDim + 3) {
+        v = PCC_PICK3(cdim, p - kPlanCellDim);
+      } else if (p == kPlanLastEpoch) {
+        v = (uint32_t)ev_index[nev - 1];
+      } else if (p >= kPlanPass && p < kPlanPass + kMaxPasses) {
+        const int q = p - kPlanPass;
+        int bq = 0, sh = 0;
+        for (int r = 0; r <= q; ++r) {
+          int b = 0;
+          if (r < np) { b = vbits / np + (r < vbits % np ? 1 : 0); if (b < 1) b = 1; }
+          if (r < q) sh += b; else bq = b;
+        }
+        v = (uint32_t)bq | ((uint32_t)sh << 8);
+      } else if (p >= kPlanRanks && p < kPlanRanks + 16) {
+        v = reinterpret_cast<const uint32_t*>(s_rank8)[p - kPlanRanks];
+      }
+      if (p < kPlanWords) publish_u64(fk.plan + p, ((uint64_t)seq << 32) | v);
+#undef PCC_PICK3
+    }
   }
   PCC_KTR(6, 6);
 }
@@ -770,42 +960,52 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
 // point gets the marker ~0 and is dropped by the first sort pass.  The same kernel counts, per
 // 4096-point tile, the digits of EVERY sort pass in LDS and writes them as one row of hist_rows.
 // ------------------------------------------------------------------------------------------
-constexpr uint64_t kInvalidKey = ~0ull;
-
 
 // (1024 threads x 4 points; 512 x 8 was tried for the sake of frames in flight -- a smaller workgroup finds room on a
 // busy CU sooner, which took k_digit_totals from 22 to 14 us under load -- but here it lost both ways: 15.4 -> 18.9 us
 // alone, 38.6 -> 41.9 us under load)
-constexpr int kKeyThreads = kSortThreads, kKeyItems = kSortTile / kKeyThreads;
+// KEY_ITEMS = 4: one row of digit counts per 4096-key sort tile (the kernel makes every key of the frame);
+// KEY_ITEMS = 2: one row per 2048-point chunk, and the kernel only visits the chunks the streaming workgroups of
+// k_boxes_events left alone (fused mode: `chunk_state` = the per-chunk granules behind the plan)
+constexpr int kKeyThreads = kSortThreads;
+template <int KEY_ITEMS>
 __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows, unsigned long long* span) {
+                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows,
+                                                            const uint64_t* __restrict__ chunk_state, uint32_t seq, unsigned long long* span) {
   const KSpan kspan(span);
+  constexpr int kKeyTile = kKeyThreads * KEY_ITEMS;
   __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
-  const int np = st->npasses;
-  for (int k = threadIdx.x; k < np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
+  if (chunk_state) {
+    const uint64_t w = chunk_state[blockIdx.x];
+    if ((uint32_t)(w >> 32) == seq && (uint32_t)w != 0u) {  // keys and digit counts of this chunk are there already
+      if ((uint32_t)w == 2u && threadIdx.x == 0) st->error = kErrPrefix;
+      return;
+    }
+  }
+  KeyGeom g;
+  g.np = st->npasses;
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
   __syncthreads();
-  const int vb = st->vbits_axis, ibits = st->ibits;
-  const bool packed_mode = st->packed != 0;
-  const int payload = st->payload;
-  const bool colour_in_key = st->colour_in_key != 0;
-  const int cm = st->code_low_bits;
-  const bool ranked = cm < vb;  // the high key bits go into the code as the rank of their cell (FrameState::code_low_bits)
-  const unsigned cbase[3] = {st->cell_base[0], st->cell_base[1], st->cell_base[2]};
-  const unsigned cdim[3] = {st->cell_dim[0], st->cell_dim[1], st->cell_dim[2]};
-  const unsigned lm = cm >= 32 ? 0xffffffffu : ((1u << cm) - 1u);
+  g.vb = st->vbits_axis; g.ibits = st->ibits;
+  g.packed_mode = st->packed != 0;
+  g.payload = st->payload;
+  g.colour_in_key = st->colour_in_key != 0;
+  g.cm = st->code_low_bits;
+  g.ranked = g.cm < g.vb;  // the high key bits go into the code as the rank of their cell (FrameState::code_low_bits)
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { g.cbase[a] = st->cell_base[a]; g.cdim[a] = st->cell_dim[a]; g.prefix[a] = st->prefix[a]; }
+  g.lm = g.cm >= 32 ? 0xffffffffu : ((1u << g.cm) - 1u);
+  g.m = g.vb >= 32 ? 0xffffffffu : ((1u << g.vb) - 1u);
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
-  const uint32_t base = blockIdx.x * kSortTile;
+  const uint32_t base = blockIdx.x * kKeyTile;
   const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
-  const unsigned m = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-  int pshift[kMaxPasses];
-  uint32_t pmask[kMaxPasses];
 #pragma unroll
-  for (int p = 0; p < kMaxPasses; ++p) { pshift[p] = st->pass_shift[p]; pmask[p] = (1u << st->pass_bits[p]) - 1u; }
+  for (int p = 0; p < kMaxPasses; ++p) { g.pshift[p] = st->pass_shift[p]; g.pmask[p] = (1u << st->pass_bits[p]) - 1u; }
 #pragma unroll
-  for (int k = 0; k < kKeyItems; ++k) {
+  for (int k = 0; k < KEY_ITEMS; ++k) {
     const uint32_t i = base + k * kKeyThreads + threadIdx.x;
     if (i >= n) break;
     float x, y, z;
@@ -816,42 +1016,23 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
       if (!late) {  // rare: the tile overlaps an earlier epoch
         while (e > 0 && st->ep_index[e] > (int)i) --e;
       }
-      const float p[3] = {x, y, z};
-      unsigned kk[3];
       bool ok = true;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        // x / res; when res is a power of two the product with its (exact) reciprocal is the same double
-        const double diff = __dsub_rn((double)p[a], st->ep_mn[e][a]);
-        const double d = inv_res_pow2 != 0.0 ? __dmul_rn(diff, inv_res_pow2) : __ddiv_rn(diff, res);
-        kk[a] = (unsigned)d + st->ep_shift[e][a];
-        ok &= vb >= 32 || ((kk[a] >> vb) == (st->prefix[a] >> vb));
-      }
-      uint64_t code;
-      if (!ranked) {
-        code = morton3(kk[0] & m, kk[1] & m, kk[2] & m);
-      } else {
-        unsigned d[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { d[a] = (kk[a] >> cm) - cbase[a]; ok &= d[a] < cdim[a]; }
-        const unsigned cell = ok ? d[2] + cdim[2] * (d[1] + cdim[1] * d[0]) : 0u;
-        code = ((uint64_t)st->cell_rank[cell] << (3 * cm)) | morton3(kk[0] & lm, kk[1] & lm, kk[2] & lm);
-      }
+      const uint64_t code = point_code(g, st->ep_mn[e], st->ep_shift[e], st->cell_rank, res, inv_res_pow2, x, y, z, ok);
       if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
 #pragma unroll
       for (int p = 0; p < kMaxPasses; ++p)
-        if (p < np) atomicAdd(&s_h[p][(uint32_t)(code >> pshift[p]) & pmask[p]], 1u);
+        if (p < g.np) atomicAdd(&s_h[p][(uint32_t)(code >> g.pshift[p]) & g.pmask[p]], 1u);
       // low bits: the point index, or (nobody needs the index) the point's colour, or nothing
-      const uint64_t low = colour_in_key ? (uint64_t)(load_rgba(pv, i) & 0xffffffu) : (ibits ? (uint64_t)i : 0ull);
-      key = packed_mode ? ((code << ibits) | low) : code;
+      const uint64_t low = g.colour_in_key ? (uint64_t)(load_rgba(pv, i) & 0xffffffu) : (g.ibits ? (uint64_t)i : 0ull);
+      key = g.packed_mode ? ((code << g.ibits) | low) : code;
     }
-    if (payload == 1) idx[i] = i;
-    else if (payload == 2) idx[i] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
+    if (g.payload == 1) idx[i] = i;
+    else if (g.payload == 2) idx[i] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
     keys[i] = key;
   }
   __syncthreads();
   uint32_t* row = hist_rows + (size_t)blockIdx.x * kMaxPasses * kMaxBins;
-  for (int k = threadIdx.x; k < np * kMaxBins; k += kKeyThreads) row[k] = (&s_h[0][0])[k];
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) row[k] = (&s_h[0][0])[k];
 }
 
 // column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
@@ -865,7 +1046,7 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
 // (for frames of many tiles the wide shape stays: a thread of the narrow one would walk rows / 16 of them)
 constexpr uint32_t kDtCols = 16;
 template <uint32_t kDtThreads>
-__global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
+__global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows, uint32_t rows_per_tile,
                                                        const uint32_t* __restrict__ hist_rows,
                                                        uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0, unsigned long long* span) {
   const KSpan kspan(span);
@@ -904,14 +1085,14 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
   if (pass == 0 && held) {
     uint32_t run = before;
 #pragma unroll
-    for (uint32_t k = 0; k < kHeld; ++k) {
-      if (r0 + k < r1) tile_prefix0[(size_t)(r0 + k) * kMaxBins + col] = run;
+    for (uint32_t k = 0; k < kHeld; ++k) {  // (rows_per_tile = 2: the rows are 2048-point chunks, a sort tile starts at every other one)
+      if (r0 + k < r1 && (r0 + k) % rows_per_tile == 0u) tile_prefix0[(size_t)((r0 + k) / rows_per_tile) * kMaxBins + col] = run;
       run += mine[k];
     }
   } else if (pass == 0) {
     uint32_t run = before;
     for (uint32_t r = r0; r < r1; ++r) {
-      tile_prefix0[(size_t)r * kMaxBins + col] = run;
+      if (r % rows_per_tile == 0u) tile_prefix0[(size_t)(r / rows_per_tile) * kMaxBins + col] = run;
       run += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
     }
   }
@@ -2250,7 +2431,8 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
     out += line;
   };
   one("k_boxes_events", (const void*)k_boxes_events, kBlock);
-  one("k_make_keys", (const void*)k_make_keys, kKeyThreads);
+  one("k_make_keys<4>", (const void*)k_make_keys<4>, kKeyThreads);
+  one("k_make_keys<2>", (const void*)k_make_keys<2>, kKeyThreads);
   one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems>, kSortThreads);
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
   one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems>, kSortThreads);
@@ -2285,15 +2467,32 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + 64 + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
+  // Fused mode (frames of up to kFusedMaxChunks chunks): the streaming workgroups of k_boxes_events hold their points in
+  // registers until workgroup 0 has published the sort plan, then write keys and digit counts themselves -- the cloud is
+  // read once -- and k_make_keys only visits the chunks that were left alone (normally chunk 0, where the box grows).
+  const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks;
+  FusedKeys fk{};
+  if (fused) {
+    fk.plan = a.plan; fk.keys = a.keys_a; fk.idx = a.idx_a; fk.hist_rows = a.hist_rows;
+    fk.inv_res_pow2 = a.inv_res_pow2; fk.plan_spins = a.plan_spins; fk.do_color = (int)a.lp.do_color;
+  }
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, (int)a.lp.do_color, a.box, a.state, span("k_boxes_events"));
+                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
-  hipLaunchKernelGGL(k_make_keys, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows, span("k_make_keys"));
-  PCC_STAMP("k_make_keys");
-  if (s_tiles <= 512)
-    hipLaunchKernelGGL(k_digit_totals<256>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(256), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+  if (fused)
+    hipLaunchKernelGGL(k_make_keys<2>, dim3(n_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows,
+                       a.plan + kPlanGranules, a.frame_seq, span("k_make_keys"));
   else
-    hipLaunchKernelGGL(k_digit_totals<1024>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+    hipLaunchKernelGGL(k_make_keys<4>, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows,
+                       (const uint64_t*)nullptr, 0u, span("k_make_keys"));
+  PCC_STAMP("k_make_keys");
+  {
+    const uint32_t n_rows = fused ? n_tiles : s_tiles, rows_per_tile = fused ? 2u : 1u;
+    if (n_rows <= 512)
+      hipLaunchKernelGGL(k_digit_totals<256>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(256), 0, stream, a.state, n_rows, rows_per_tile, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+    else
+      hipLaunchKernelGGL(k_digit_totals<1024>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, n_rows, rows_per_tile, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+  }
   PCC_STAMP("k_digit_totals");
   // Few tiles (every tile has a CU to itself): 16 waves share a tile's latency-bound steps.  Many tiles: 8 waves with
   // twice the keys per thread need 62 KB of LDS instead of 87 KB, so two tiles share a CU and one loads or waits for

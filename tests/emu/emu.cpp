@@ -223,8 +223,11 @@ inline uint32_t next_rand(uint64_t& st) {
   return (uint32_t)(st >> 33);
 }
 
+void ask_for_a_thread();
+
 void run_workgroup(Worker* w) {
   const int T = w->nthreads, nw = (T + 63) / 64;
+  int sleepy_sweeps = 0;
   for (int i = 0; i < T; ++i) prepare_lane(w, i);
   uint64_t rnd = shuffle_seed() ? shuffle_seed() ^ ((uint64_t)w->block_linear * 0x9E3779B97F4A7C15ull) : 0ull;
   int wave_order[kMaxThreads / 64], lane_order[64];
@@ -289,12 +292,21 @@ void run_workgroup(Worker* w) {
       }
       continue;
     }
-    if (slept) { sched_yield(); continue; }
+    if (slept) {
+      if (++sleepy_sweeps % 16 == 0) ask_for_a_thread();
+      sched_yield();
+      continue;
+    }
     die("deadlock inside a workgroup: lanes wait for a cross-lane operation that the others cannot reach");
   }
 }
 
 // ------------------------------------------------------------------ pool
+// Workgroups are handed out in blockIdx order.  A workgroup that keeps sleeping (it polls for something another
+// workgroup has to produce) while workgroups of the launch are still waiting for a thread asks for one more thread:
+// what the hardware gives a kernel whose grid fits the chip -- every workgroup resident -- the pool gives up to
+// PCC_EMU_MAX_THREADS (default 1100) workgroups; beyond that a waiting workgroup runs into its own bound, as it
+// would on a GPU that is busy with other kernels.
 struct Pool {
   std::mutex launch_mu;   // one launch at a time (host threads of the pipeline share the pool)
   std::mutex mu;
@@ -306,40 +318,58 @@ struct Pool {
   dim3 grid, block;
   uint32_t total = 0;
   std::atomic<uint32_t> next{0};
-  uint32_t finished = 0;
+  uint32_t blocks_done = 0;
+  int busy = 0;           // workers inside the launch
   uint64_t generation = 0;
-  bool stop = false;
-  int nworkers = 0;
+  size_t max_threads = 1100;
 
-  void worker_main() {
+  int parked = 0, tokens = 0;  // helper threads: asleep until a sleeping workgroup asks for one
+  std::condition_variable cv_helper;
+
+  void worker_main(bool helper) {
     Worker* w = new Worker();
     w->stacks = (char*)mmap(nullptr, kStackBytes * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (w->stacks == MAP_FAILED) { perror("mmap"); abort(); }
     tl_worker = w;
     uint64_t seen = 0;
+    bool first = true;
     for (;;) {
+      dim3 g, b;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv_work.wait(lk, [&] { return stop || generation != seen; });
-        if (stop) break;
-        seen = generation;
+        if (helper) {
+          // a helper joins the launch that is in flight when it is asked for (the first time: the one it was made for)
+          if (!first) {
+            ++parked;
+            cv_helper.wait(lk, [&] { return tokens > 0; });
+            --tokens; --parked;
+          }
+          first = false;
+          if (!job) continue;  // that launch is over already
+        } else {
+          cv_work.wait(lk, [&] { return generation != seen; });
+          seen = generation;
+        }
+        ++busy;
+        w->job = job; w->kname = kname;
+        g = grid; b = block;
       }
       uint32_t mine = 0;
       for (;;) {
-        const uint32_t b = next.fetch_add(1u, std::memory_order_relaxed);
-        if (b >= total) break;
-        w->job = job; w->kname = kname; w->block_linear = b;
-        w->nthreads = (int)(block.x * block.y * block.z);
-        blockDim = {block.x, block.y, block.z};
-        gridDim = {grid.x, grid.y, grid.z};
-        blockIdx.x = b % grid.x; blockIdx.y = (b / grid.x) % grid.y; blockIdx.z = b / (grid.x * grid.y);
+        const uint32_t bi = next.fetch_add(1u, std::memory_order_relaxed);
+        if (bi >= total) break;
+        w->block_linear = bi;
+        w->nthreads = (int)(b.x * b.y * b.z);
+        blockDim = {b.x, b.y, b.z};
+        gridDim = {g.x, g.y, g.z};
+        blockIdx.x = bi % g.x; blockIdx.y = (bi / g.x) % g.y; blockIdx.z = bi / (g.x * g.y);
         run_workgroup(w);
         ++mine;
       }
       {
         std::lock_guard<std::mutex> lk(mu);
-        finished += mine + 1;  // + 1: this worker has left the launch
-        // (every worker adds one, so the launch is over at total + nworkers)
+        blocks_done += mine;
+        --busy;
       }
       cv_done.notify_all();
     }
@@ -347,32 +377,42 @@ struct Pool {
   void start() {
     const char* e = getenv("PCC_EMU_WORKERS");
     int n = e ? atoi(e) : (int)std::min<long>(8, sysconf(_SC_NPROCESSORS_ONLN));
-    nworkers = std::max(2, n);  // workgroup 0 of k_boxes_events waits for the others: they need a thread to run on
-    for (int i = 0; i < nworkers; ++i) threads.emplace_back([this] { worker_main(); });
+    n = std::max(2, n);  // workgroup 0 of k_boxes_events waits for the others: they need a thread to run on
+    if (const char* m = getenv("PCC_EMU_MAX_THREADS")) max_threads = (size_t)std::max(atoi(m), n);
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n; ++i) threads.emplace_back([this] { worker_main(false); });
+  }
+  // called by a workgroup that has been sleeping for a while: one more thread for the launch in flight (a parked helper,
+  // or a new one) while workgroups are still waiting to be started
+  void more_threads_please() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!job || next.load(std::memory_order_relaxed) >= total) return;
+    if (parked > tokens) { ++tokens; cv_helper.notify_one(); }
+    else if (threads.size() < max_threads) threads.emplace_back([this] { worker_main(true); });
   }
   void run(const char* name, dim3 g, dim3 b, Launcher& l) {
     std::lock_guard<std::mutex> one(launch_mu);
     if (threads.empty()) start();
     const uint64_t nt = (uint64_t)b.x * b.y * b.z;
     if (nt == 0 || nt > (uint64_t)kMaxThreads) { fprintf(stderr, "wave64 executor: %s: %llu threads per workgroup\n", name, (unsigned long long)nt); abort(); }
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      job = &l; kname = name; grid = g; block = b;
-      total = g.x * g.y * g.z;
-      next.store(0);
-      finished = 0;
-      ++generation;
-    }
-    cv_work.notify_all();
     std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return finished == total + (uint32_t)nworkers; });
+    cv_done.wait(lk, [&] { return busy == 0; });  // (a worker that woke up late for the launch before)
+    job = &l; kname = name; grid = g; block = b;
+    total = g.x * g.y * g.z;
+    next.store(0);
+    blocks_done = 0;
+    ++generation;
+    cv_work.notify_all();
+    cv_done.wait(lk, [&] { return blocks_done == total && busy == 0; });
     job = nullptr;
+    tokens = 0;
   }
 };
 Pool& pool() {
   static Pool* p = new Pool();  // never destroyed: the workers live as long as the process
   return *p;
 }
+void ask_for_a_thread() { pool().more_threads_please(); }
 
 }  // namespace
 

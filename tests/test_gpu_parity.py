@@ -347,6 +347,61 @@ def test_indexed_keys_match_bare_keys(pkg, oracle, monkeypatch):
             c.close()
 
 
+def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypatch):
+    """Fused mode (default): the streaming workgroups of k_boxes_events keep their points in registers and write sort
+    keys and digit counts themselves once workgroup 0 has published the plan; k_make_keys only visits the chunks that
+    were left alone.  Same bytes as the two-kernel form (PCC_FUSED_KEYS=0) and as a frame in which every workgroup's
+    wait for the plan runs out (PCC_PLAN_SPINS=1: everything falls back), for every key layout, with growth events
+    spread over the cloud (earlier epochs in later chunks), cell ranks, non-finite points, ragged sizes."""
+    import ctypes as C
+    b = pkg.binding
+    lib = b.load_library()
+    lib.pcc_debug_fused_chunks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(77)
+    clouds = []
+    for n in (1, 2047, 2048, 2049, 6000, 70_001):
+        clouds.append((cloud(pkg, rng.uniform(0.2, 0.8, (n, 3)), seed=n), dict(octree_bits=9)))
+    s = pkg.synthetic.sphere_shell(150_000, 0xF5)
+    clouds.append((s, dict(octree_bits=10, keep_centroid=1)))            # index in the key, colour payload
+    clouds.append((s, dict(octree_bits=10, color_bits=0)))               # bare code keys
+    clouds.append((s, dict(octree_bits=9, color_coding_type=2)))
+    srt = s[np.argsort(s["x"], kind="stable")]                           # growth events far into the cloud
+    clouds.append((srt, dict(octree_bits=10)))
+    holes = s.copy(); holes["y"][::7] = np.nan; holes["x"][:3000] = np.inf   # chunk 0 without a finite point
+    clouds.append((holes, dict(octree_bits=10)))
+    clouds.append((pkg.synthetic.voxelised_body(120_000, 0xB0D), dict(octree_bits=10)))   # cell ranks
+    seen_fused = seen_fallback = 0
+    c = b.Context(0)
+    try:
+        for pts, kw in clouds:
+            hot, want = assert_matches_oracle(pkg, oracle, c, pts, **kw)
+            out = (C.c_uint32 * 3)()
+            assert lib.pcc_debug_fused_chunks(c.h, out) == 0
+            seen_fused += out[0]; seen_fallback += out[1] - out[0]
+    finally:
+        c.close()
+    import os
+    if os.environ.get("PCC_FUSED_KEYS") == "0" or os.environ.get("PCC_PLAN_SPINS") == "1":
+        assert seen_fused == 0
+    else:
+        print("fused chunks", seen_fused, "left to k_make_keys", seen_fallback)
+        assert seen_fused > 100 and seen_fallback >= 3   # most chunks fused; chunks that hold earlier epochs are not
+
+
+@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "0"}, {"PCC_PLAN_SPINS": "1"}])
+def test_two_kernel_form_and_plan_timeouts_give_the_same_bytes(env):
+    """The same clouds with fused mode switched off, and with every wait for the plan running out (all chunks fall back to
+    k_make_keys): child processes, because the switches are read once."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points"],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=1800)
+    # with the mode off / all chunks timing out the fused-chunk counters of the first test do not hold: it is told so
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_cell_ranks_save_a_sort_pass_and_change_nothing(pkg, oracle, monkeypatch):
     """A capture-like cloud (1024-voxel lattice) that straddles a high power-of-two boundary of its adaptive box varies in
     13 key bits per axis: 39 code bits, five sort passes.  The sorted code carries the rank of the 2^m-cell instead of the
