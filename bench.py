@@ -351,6 +351,18 @@ def main():
             th = time.perf_counter()
             pipe.encode_host(seq_h, params, copy=False)
             legs[label] = hf * n_points / (time.perf_counter() - th) / 1e6
+        # the same with "pack_upload": the GPU-stage threads pack x, y, z, colour (16 of a point's 32 bytes) into page-locked
+        # buffers and half the bytes cross the link -- pays where the host has memory bandwidth and cores to spare
+        try:
+            pipe.set_option("pack_upload", 1)
+            seq_h = [host_frames[s % n_distinct] for s in range(hf)]
+            pipe.encode_host(seq_h[:min(hf, 2 * pipe.n_contexts)], params, copy=False)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            pipe.encode_host(seq_h, params, copy=False)
+            legs["packed"] = hf * n_points / (time.perf_counter() - th) / 1e6
+        finally:
+            pipe.set_option("pack_upload", 0)
         # one frame, one call, ordinary memory: what a caller of the reference's class gets per encodePointCloud
         lat = []
         for k in range(6):
@@ -360,6 +372,7 @@ def main():
         host_input = {
             "e2e_from_host_mpoints_per_s": round(legs["pinned"], 1),
             "e2e_from_pageable_host_mpoints_per_s": round(legs["pageable"], 1),
+            "e2e_from_host_packed_16B_mpoints_per_s": round(legs["packed"], 1),   # option pack_upload (off by default)
             "frames": hf,
             "pcie_bound_mpoints_per_s": round(56.0e9 / (32 * 1e6), 0),   # 56 GB/s measured host->device (tools/ubench/h2d.cpp), 32 B per point
             "single_call_latency_ms": round(1e3 * float(np.median(lat[1:])), 3),

@@ -148,6 +148,10 @@ struct pcc_ctx {
   PinnedBuf<int16_t> h_coefs;
   int jpeg_on_gpu = 2;  // 0 host JPEG, 1 coefficients from the GPU, 2 Huffman-coded MCU rows from the GPU
   bool copy_image = true;
+  // frames that start in host memory: 16 bytes per point (x, y, z, colour) are packed into a page-locked buffer of the
+  // context and uploaded instead of the caller's 32-byte points (option "pack_upload"; PCC_PACK_UPLOAD=1 makes it the default)
+  bool pack_upload = false;
+  PinnedBuf<uint8_t> h_pack;
   std::vector<pcc_point_xyzrgb> out_cloud;   // getOutputCloud()
   PointVec dec_points;  // decodePointCloud()
   // decodePointCloud with the data-parallel half on the GPU (pcc_decode_intra_gpu)
@@ -376,6 +380,7 @@ pcc_ctx* pcc_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   pcc_ctx* c = new pcc_ctx();
   c->device = device;
+  { const char* e = getenv("PCC_PACK_UPLOAD"); c->pack_upload = e && e[0] == '1'; }
   {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
@@ -417,7 +422,7 @@ void pcc_destroy(pcc_ctx* c) {
   c->d_qa.release(); c->d_qb.release(); c->d_qkeys.release(); c->d_qheads.release(); c->d_qnext.release();
   c->d_qidx.release(); c->d_qd2.release(); c->d_qpart.release();
   c->h_state.release(); c->h_occ.release(); c->h_bgr.release(); c->h_centroid.release(); c->h_image.release();
-  c->h_simplified.release();
+  c->h_simplified.release(); c->h_pack.release();
   for (pcc_ctx*& sc : c->sub) { if (sc) pcc_destroy(sc); sc = nullptr; }
   c->d_delta_i.release(); c->d_delta_p.release(); c->d_delta_intra.release(); c->d_delta_out.release(); c->d_ifull.release();
   c->d_pfull.release(); c->d_ixyzc.release(); c->d_pxyzc.release(); c->d_cur.release(); c->d_nn.release(); c->d_dst_intra.release();
@@ -447,6 +452,7 @@ int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return PCC_ERR_ARG;
   if (!strcmp(name, "jpeg_on_gpu")) ctx->jpeg_on_gpu = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "copy_image")) ctx->copy_image = value != 0;
+  else if (!strcmp(name, "pack_upload")) ctx->pack_upload = value != 0;
   else if (!strcmp(name, "profile_events")) ctx->profile_events = value != 0;
   else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
@@ -701,6 +707,26 @@ int pcc_hotpath_launch_host(pcc_ctx* ctx, pcc_upload_lane* lane, const void* hos
   if (lane && lane->device != ctx->device) return fail(ctx, PCC_ERR_ARG, "upload lane and context belong to different GPUs");
   if (n == 0) return launch_frame(ctx, nullptr, 0, stride, rgb_offset, prm, nullptr, 0, 0);
   PCC_HIP(hipSetDevice(ctx->device));
+  if (ctx->pack_upload && stride >= 16 && rgb_offset + 4 <= stride) {
+    // 16 of a point's bytes are read by the kernels: they are packed here (the calling thread: a GPU-stage thread of the
+    // pipeline, which would otherwise wait) and half the bytes cross the link
+    const size_t packed = 16 * n;
+    PCC_HIP(ctx->d_points.ensure(packed + 16));
+    PCC_HIP(ctx->h_pack.ensure(packed + 32));
+    if (ctx->locked_host) { unlock_host_range(ctx->locked_host); ctx->locked_host = nullptr; }
+    pack_points_16(ctx->h_pack.p, static_cast<const uint8_t*>(host_points), n, stride, rgb_offset);
+    hipError_t e;
+    if (lane) {
+      std::lock_guard<std::mutex> lk(lane->mu);
+      e = hipMemcpyAsync(ctx->d_points.p, ctx->h_pack.p, packed, hipMemcpyHostToDevice, lane->stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_h2d, lane->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0);
+    } else {
+      e = hipMemcpyAsync(ctx->d_points.p, ctx->h_pack.p, packed, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e != hipSuccess) return hip_fail(ctx, e, "upload of the packed frame");
+    return launch_frame(ctx, ctx->d_points.p, n, 16, 12, prm, nullptr, 0, 0);
+  }
   const size_t bytes = n * stride;
   PCC_HIP(ctx->d_points.ensure(bytes + 16));
   if (ctx->locked_host) { unlock_host_range(ctx->locked_host); ctx->locked_host = nullptr; }  // a frame that was never finished

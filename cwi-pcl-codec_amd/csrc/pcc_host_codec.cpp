@@ -1826,4 +1826,27 @@ int decode_frame(const uint8_t* stream, size_t len, PointVec& points, pcc_cloud&
   return PCC_OK;
 }
 
+void pack_points_16(uint8_t* dst, const uint8_t* src, size_t n, size_t stride, size_t rgb_offset) {
+  size_t i = 0;
+#ifdef __AVX2__
+  if (stride == 32 && rgb_offset == 16 && (reinterpret_cast<uintptr_t>(dst) & 31) == 0) {
+    // dwords 0,1,2 (x,y,z) and 4 (colour) of every point; two points per 32-byte streaming store
+    const __m256i pick = _mm256_setr_epi32(0, 1, 2, 4, 0, 1, 2, 4);
+    for (; i + 4 <= n; i += 4) {
+      const __m256i a = _mm256_permutevar8x32_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32 * i)), pick);
+      const __m256i b = _mm256_permutevar8x32_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32 * i + 32)), pick);
+      const __m256i c = _mm256_permutevar8x32_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32 * i + 64)), pick);
+      const __m256i d = _mm256_permutevar8x32_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32 * i + 96)), pick);
+      _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + 16 * i), _mm256_permute2x128_si256(a, b, 0x20));
+      _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + 16 * i + 32), _mm256_permute2x128_si256(c, d, 0x20));
+    }
+    _mm_sfence();
+  }
+#endif
+  for (; i < n; ++i) {
+    memcpy(dst + 16 * i, src + stride * i, 12);
+    memcpy(dst + 16 * i + 12, src + stride * i + rgb_offset, 4);
+  }
+}
+
 }  // namespace pcc

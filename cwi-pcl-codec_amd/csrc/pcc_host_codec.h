@@ -118,4 +118,9 @@ struct LeafParents {             // per node of level D-1, in stream order:
 };
 int walk_leaf_parents(const Bytes& occ, unsigned depth, uint64_t count, LeafParents& lp);
 
+// n points of `stride` bytes (x, y, z floats at 0, colour word at rgb_offset) -> 16 bytes each: x, y, z, colour word.
+// What the kernels read of a pcl::PointXYZRGB is 16 of its 32 bytes; packing on the host halves what crosses PCIe.
+// AVX2 with streaming stores for the PCL layout (32 / 16), scalar otherwise.  dst: 32-byte aligned.
+void pack_points_16(uint8_t* dst, const uint8_t* src, size_t n, size_t stride, size_t rgb_offset);
+
 }  // namespace pcc

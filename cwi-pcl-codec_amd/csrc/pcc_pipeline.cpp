@@ -565,6 +565,7 @@ int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
   std::lock_guard<std::mutex> lk(p->mu);  // between jobs: the threads read these when a job starts
   if (!strcmp(name, "entropy_on_gpu")) p->entropy_on_gpu = value != 0;
   else if (!strcmp(name, "entropy_gpu_batch")) p->gpu_batch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
+  else if (!strcmp(name, "pack_upload")) { for (pcc_ctx* c : p->ctxs) (void)pcc_set_option(c, "pack_upload", value); }  // host frames: 16 B per point over PCIe
   else return PCC_ERR_ARG;
   return PCC_OK;
 }

@@ -663,6 +663,18 @@ def test_host_frames_through_one_context(pkg, oracle):
                 hot = c.hotpath_finish(copy=False)
                 stream, _ = c.entropy_encode(hot.raw, b.make_params(frame_id=1, **kw))
                 assert stream == want
+        # option "pack_upload": x, y, z and the colour word of every point are packed to 16 bytes on the host and half the
+        # bytes cross the link; same bitstream, with centroids (the kernels go back to the points through the index) and
+        # for a ragged count (the vector loop's tail)
+        c.set_option("pack_upload", 1)
+        for m, kw2 in ((len(pts), kw), (len(pts) - 3, dict(kw, keep_centroid=1)), (5, kw), (1, dict(kw, color_coding_type=0))):
+            want2 = oracle.encode_intra(pts[:m], oracle.make_params(frame_id=1, **kw2)).bitstream
+            for ln in (None, lane):
+                c.hotpath_launch_host(pts[:m], b.make_params(frame_id=1, **kw2), lane=ln)
+                hot = c.hotpath_finish(copy=False)
+                stream, _ = c.entropy_encode(hot.raw, b.make_params(frame_id=1, **kw2))
+                assert stream == want2, (m, kw2)
+        c.set_option("pack_upload", 0)
         c.hotpath_launch_host(np.zeros(0, dtype=b.POINT_DTYPE), b.make_params(frame_id=1, **kw), lane=lane)
         with pytest.raises(b.PccError):
             c.hotpath_finish()
