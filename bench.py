@@ -240,6 +240,7 @@ def main():
                                        ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
     trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
+    entropy_mode_timed = pipe.last_entropy_mode()   # option "entropy_on_gpu" is -1: decided per call from a cost estimate
     ktimes, profiled = pipe.kernel_times()
     for c in prof_ctxs:
         c.set_profiling(False)
@@ -438,6 +439,11 @@ def main():
             "kernels_ms_per_frame": {k: round(v, 5) for k, v in sorted(span_frame_ms.items(), key=lambda kv: -kv[1])},
             "host_input": host_input,
             "host_cpus_for_this_rank": default_workers(world),
+            # what the host entropy stage can sustain on this rank's CPUs (CPU time per frame measured in the timed region)
+            "entropy_stage": {"ran_on": "gpu" if entropy_mode_timed else "host",
+                              "host_frames_per_s_bound": (round(default_workers(world) / (stats["entropy_cpu_us"] * 1e-6), 0)
+                                                          if stats["entropy_cpu_us"] > 0 and not entropy_mode_timed else None),
+                              "gpu_stage_frames_per_s": round(gpu_only_fps, 0)},
             "cgroup_throttled_ms_in_timed_region": throttled_ms,
             "warmup_frames_run": warm + args.steps * int(os.environ.get("PCC_BENCH_SHAPE_WARMUP", "1")),
             "cpu_baseline": cpu_baseline,

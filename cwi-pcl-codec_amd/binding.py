@@ -35,7 +35,7 @@ EXPORTS = [
     "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_host_times",
     "pcc_set_profiling",
     "pcc_set_option",
-    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_workers", "pcc_pipeline_contexts",
+    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_last_entropy_mode", "pcc_pipeline_workers", "pcc_pipeline_contexts",
     "pcc_pipeline_context",
     "pcc_pipeline_encode", "pcc_pipeline_encode_host", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
     "pcc_pipeline_last_error",
@@ -179,6 +179,7 @@ def load_library():
     lib.pcc_pipeline_destroy.argtypes = [vp]
     lib.pcc_pipeline_destroy.restype = None
     lib.pcc_pipeline_workers.argtypes = [vp]
+    lib.pcc_pipeline_last_entropy_mode.argtypes = [vp]
     lib.pcc_pipeline_contexts.argtypes = [vp]
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
@@ -554,6 +555,10 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+    def last_entropy_mode(self):
+        """Where the entropy stage of the last call ran: 0 host, 1 GPU (option "entropy_on_gpu" -1 decides per call)."""
+        return int(self.lib.pcc_pipeline_last_entropy_mode(self.h))
 
     def set_option(self, name, value):
         rc = self.lib.pcc_pipeline_set_option(self.h, name.encode(), int(value))

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -69,7 +70,12 @@ struct pcc_pipeline {
   std::vector<pcc_stream*> gpu_streams;  // one per GPU-stage thread, created one after the other: see pcc_use_stream in pcc_codec.h
   // Opt-in (pcc_pipeline_set_option "entropy_on_gpu"): the range coders run on the GPU, one wave per stream, in batches of
   // `gpu_batch` frames per entropy thread -- for hosts with fewer cores than the GPU stage can feed.
-  bool entropy_on_gpu = false;
+  bool entropy_on_gpu = false;   // what the job at hand uses (decided when the job starts)
+  // -1 (default): decided per call from a cost estimate -- the host coders need ~1.5 ns of one core per symbol, a flush of
+  // the device coder ~110 ns per symbol of its longest stream however many streams it holds: a long call on a host with
+  // few cores per GPU goes to the GPU, everything else stays on the host; 0 / 1: forced (option "entropy_on_gpu",
+  // PCC_PIPELINE_ENTROPY=host|gpu|auto)
+  int entropy_mode = -1;
   int gpu_batch = 256;
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
@@ -483,7 +489,7 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     for (int w = 0; w < p->n_gpu; ++w) p->gpu_streams.push_back(pcc_stream_create(device));
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
   p->batches.assign((size_t)p->n_entropy, nullptr);
-  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_on_gpu = !strcmp(e, "gpu");
+  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_mode = !strcmp(e, "gpu") ? 1 : (!strcmp(e, "host") ? 0 : -1);
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p, w] { p->entropy_thread(w); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
   // threads of one core run at about half speed each, and the scheduler does put them there (20 frames on 16 threads:
@@ -563,13 +569,14 @@ int pcc_pipeline_reserve(pcc_pipeline* p, size_t n_frames, size_t bytes_per_fram
 int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
   if (!p || !name) return PCC_ERR_ARG;
   std::lock_guard<std::mutex> lk(p->mu);  // between jobs: the threads read these when a job starts
-  if (!strcmp(name, "entropy_on_gpu")) p->entropy_on_gpu = value != 0;
+  if (!strcmp(name, "entropy_on_gpu")) p->entropy_mode = value < 0 ? -1 : (value != 0 ? 1 : 0);  // -1: per call, from the cost estimate
   else if (!strcmp(name, "entropy_gpu_batch")) p->gpu_batch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
   else if (!strcmp(name, "pack_upload")) { for (pcc_ctx* c : p->ctxs) (void)pcc_set_option(c, "pack_upload", value); }  // host frames: 16 B per point over PCIe
   else return PCC_ERR_ARG;
   return PCC_OK;
 }
 
+int pcc_pipeline_last_entropy_mode(pcc_pipeline* p) { return p && p->entropy_on_gpu ? 1 : 0; }
 int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }
 int pcc_pipeline_contexts(pcc_pipeline* p) { return p ? (int)p->ctxs.size() : 0; }
 
@@ -586,6 +593,21 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->job.frames = dev_frames; p->job.counts = n_points; p->job.n_frames = n_frames;
     p->job.stride = stride; p->job.rgb_offset = rgb_offset; p->job.params = *params; p->job.mode = mode;
     p->job.host_input = host_input;
+    {
+      // where the entropy stage of this call runs
+      bool on_gpu = p->entropy_mode == 1;
+      if (p->entropy_mode < 0 && mode == 0 && n_frames >= 64) {
+        double pts = 0;
+        for (size_t f = 0; f < n_frames; ++f) pts += (double)n_points[f];
+        const double sym = 1.15 * pts / (double)n_frames;          // occupancy bytes ~ points of a surface, + the colour payload
+        const double threads = (double)std::max(p->n_entropy, 1);
+        const double host_ms = (double)n_frames * sym * 1.5e-6 / threads;
+        const double per_thread = std::ceil((double)n_frames / threads);
+        const double gpu_ms = std::ceil(per_thread / (double)p->gpu_batch) * (sym * 110e-6 + 5.0);
+        on_gpu = host_ms > 2.0 * gpu_ms;
+      }
+      p->entropy_on_gpu = on_gpu && mode == 0;
+    }
     p->streams.assign(n_frames, std::vector<uint8_t>());
     if (mode == 0 && p->seen_max_len) p->arena_ensure(n_frames * ((p->seen_max_len + p->seen_max_len / 16 + 127) & ~(size_t)63));
     p->arena_used = 0;

@@ -78,15 +78,15 @@ __global__ __launch_bounds__(64) void k_range_encode(const RcJob* __restrict__ j
 
   for (uint32_t i0 = 0; i0 < n; i0 += 64) {
     const uint32_t cnt = min(64u, n - i0);
-    uint32_t fv = 0, wv = 0;
+    uint32_t fw = 0;  // start | width << 16 of the symbol's interval: both are below 2^16 (the table total is), one lane read per symbol
     if ((uint32_t)lane < cnt) {  // the next 64 symbols and their table entries: the data-parallel part
       const uint32_t sym = in[i0 + lane];
-      fv = s_freq[sym];
-      wv = s_freq[sym + 1] - fv;
+      const uint32_t fv = s_freq[sym];
+      fw = fv | ((s_freq[sym + 1] - fv) << 16);
     }
     for (uint32_t l = 0; l < cnt; ++l) {  // the serial part: wave-uniform, scalar ALU
-      const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)l);
-      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)l);
+      const uint32_t fwl = (uint32_t)__builtin_amdgcn_readlane((int)fw, (int)l);
+      const uint32_t f = fwl & 0xffffu, w = fwl >> 16;
       const uint64_t t = (uint64_t)range * mh + __umulhi(range, ml);
       const uint32_t q = (uint32_t)(t >> 32);  // range / total
       low += f * q;

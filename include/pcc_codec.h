@@ -248,11 +248,15 @@ typedef struct pcc_pipeline pcc_pipeline;
 pcc_pipeline *pcc_pipeline_create(int device, int n_workers);
 void pcc_pipeline_destroy(pcc_pipeline *p);
 /* pipeline knobs (no output byte changes), to be set between calls:
- *   "entropy_on_gpu" (default 0; environment PCC_PIPELINE_ENTROPY=gpu sets 1): the range coders of the entropy stage run
- *                 on the GPU (pcc_entropy_batch), the entropy threads only copy, stitch JPEG rows and assemble -- for hosts
- *                 with fewer cores than the GPU stage can feed.  A flush takes ~0.1 s whatever its size.
- *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread. */
+ *   "entropy_on_gpu" 1: the range coders of the entropy stage run on the GPU (pcc_entropy_batch), the entropy threads
+ *                 only copy, stitch JPEG rows and assemble -- for hosts with fewer cores than the GPU stage can feed; a flush
+ *                 takes ~0.1 s whatever its size.  0: always on the host.  -1 (default; PCC_PIPELINE_ENTROPY=host|gpu|auto):
+ *                 decided per call from a cost estimate (frames, symbols per frame, entropy threads): long calls on hosts
+ *                 with few cores per GPU go to the GPU, everything else stays on the host.
+ *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread.
+ *   "pack_upload" (default 0): frames from host memory are packed to 16 bytes per point before they cross PCIe. */
 int pcc_pipeline_set_option(pcc_pipeline *p, const char *name, int value);
+int pcc_pipeline_last_entropy_mode(pcc_pipeline *p); /* where the entropy stage of the last call ran: 0 host, 1 GPU */
 int pcc_pipeline_workers(pcc_pipeline *p);
 int pcc_pipeline_contexts(pcc_pipeline *p);
 pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option / pcc_set_profiling / kernel times */
