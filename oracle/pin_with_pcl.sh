@@ -8,9 +8,44 @@
 #   EIGEN_INC=/usr/include/eigen3   BOOST_INC=/usr/include   JPEG_LIB="-lturbojpeg -ljpeg"   (defaults below)
 #   REF=/root/reference
 #   bash oracle/pin_with_pcl.sh
+#   bash oracle/pin_with_pcl.sh --dry-run    # no PCL needed: checks that every file the build line names is where it is
+#                                            # expected, probes the usual places for REAL PCL / Eigen / Boost headers and,
+#                                            # only if all of them are found, type-checks the driver against them
+#                                            # (-fsyntax-only); never writes or uses stand-in headers
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)
 REF=${REF:-/root/reference}
+if [ "${1:-}" = "--dry-run" ]; then
+  rc=0
+  for f in "$HERE/ref_codec_driver.cpp" "$HERE/pin_check.py" "$REF/jpeg_io/src/jpeg_io.cpp" \
+           "$REF/cloud_codec_v2/include/pcl/cloud_codec_v2/point_cloud_codec_v2.h" \
+           "$REF/cloud_codec_v2/include/pcl/cloud_codec_v2/impl/point_cloud_codec_v2_impl.hpp" \
+           "$REF/jpeg_io/include/pcl/io/jpeg_io.h"; do
+    if [ -f "$f" ]; then echo "found    $f"; else echo "MISSING  $f"; rc=1; fi
+  done
+  PCL_INC=""; EIG=""; BST=""
+  for root in "${PCL_ROOT:-}" /usr /usr/local /opt/pcl /opt/conda; do
+    [ -n "$root" ] || continue
+    c=$(ls -d "$root"/include/pcl-1.* 2>/dev/null | sort -V | tail -1 || true)
+    [ -n "$c" ] && [ -f "$c/pcl/compression/octree_pointcloud_compression.h" ] && { PCL_INC=$c; break; }
+  done
+  for d in "${EIGEN_INC:-}" /usr/include/eigen3 /usr/local/include/eigen3 /opt/conda/include/eigen3; do
+    [ -n "$d" ] && [ -f "$d/Eigen/Core" ] && { EIG=$d; break; }
+  done
+  for d in "${BOOST_INC:-}" /usr/include /usr/local/include /opt/conda/include; do
+    [ -n "$d" ] && [ -f "$d/boost/shared_ptr.hpp" ] && { BST=$d; break; }
+  done
+  echo "PCL headers:   ${PCL_INC:-not installed}"
+  echo "Eigen headers: ${EIG:-not installed}"
+  echo "Boost headers: ${BST:-not installed}"
+  if [ -n "$PCL_INC" ] && [ -n "$EIG" ] && [ -n "$BST" ] && [ $rc -eq 0 ]; then
+    "${CXX:-g++}" -std=c++14 -fsyntax-only -w -I"$PCL_INC" -I"$EIG" -I"$BST" -I"$REF/cloud_codec_v2/include" -I"$REF/jpeg_io/include" \
+      "$HERE/ref_codec_driver.cpp" && echo "type check of ref_codec_driver.cpp against the real headers: ok" || rc=1
+  else
+    echo "type check skipped: it needs the real PCL, Eigen and Boost headers (no stand-ins are written); parity stays UNPINNED"
+  fi
+  exit $rc
+fi
 PCL_ROOT=${PCL_ROOT:?set PCL_ROOT to the prefix of a PCL 1.8.1-1.10 installation}
 EIGEN_INC=${EIGEN_INC:-/usr/include/eigen3}
 BOOST_INC=${BOOST_INC:-/usr/include}

@@ -212,3 +212,10 @@ def test_pin_recipe_stays_runnable(oracle):
     sh = open(os.path.join(root, "oracle", "pin_with_pcl.sh")).read()
     assert '"$REF/jpeg_io/src/jpeg_io.cpp"' in sh and "ref_codec_driver.cpp" in sh
     assert not any(line.strip().startswith(("cmake", "make ")) for line in sh.splitlines())   # a plain compiler line, not the reference's build system
+    # the dry run: one command that says whether the recipe could run here (file list, real headers or none)
+    if os.path.isdir("/root/reference"):
+        import subprocess
+        r = subprocess.run(["bash", os.path.join(root, "oracle", "pin_with_pcl.sh"), "--dry-run"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "MISSING" not in r.stdout
+        assert "type check" in r.stdout
