@@ -103,6 +103,8 @@ struct pcc_ctx {
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
   DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
+  DevBuf<uint32_t> d_idx2_a, d_idx2_b, d_leaf_hi;  // trees deeper than 21 levels only (two-word codes): allocated when one comes by
+  bool deep_hint = false;                          // the frame before was one: enqueue the deep kernels straight away
   DevBuf<uint8_t> d_leaf_t, d_bgr, d_centroid, d_image, d_sync;
   // the per-MCU-row Huffman records and, right behind them, the occupancy stream: what the host stage needs of a
   // colour frame is one contiguous piece of HBM and comes back in ONE copy (a copy costs some 40 us to set up)
@@ -229,7 +231,7 @@ int reserve(pcc_ctx* ctx, size_t n) {
   PCC_HIP(ctx->d_leaf_code.ensure(n));
   PCC_HIP(ctx->d_leaf_base.ensure(n));
   PCC_HIP(ctx->d_leaf_t.ensure(n));
-  PCC_HIP(ctx->d_occ.ensure(tiles_region(n) + n * (size_t)kMaxDepth + 64));  // records + worst case B = L * D
+  PCC_HIP(ctx->d_occ.ensure(tiles_region(n) + n * (size_t)kMaxDepthDeep + 64));  // records + worst case B = L * D
   PCC_HIP(ctx->d_bgr.ensure(3 * n + 16));
   PCC_HIP(ctx->d_centroid.ensure(3 * n + 16));
   PCC_HIP(ctx->d_image.ensure(3 * 256 * (n / 256 + 1) + 16));
@@ -414,7 +416,7 @@ void pcc_destroy(pcc_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->locked_host) { unlock_host_range(c->locked_host); c->locked_host = nullptr; }
   c->d_dec.release(); c->d_dec_points.release(); c->h_dec_stage.release(); c->h_dec_points.release();
-  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_plan.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release();
+  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_plan.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release(); c->d_idx2_a.release(); c->d_idx2_b.release(); c->d_leaf_hi.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release(); c->d_lines.release(); c->h_lines.release();
@@ -557,6 +559,7 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.lp.do_centroid = prm->do_voxel_centroid ? 1u : 0u;
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
   a.max_passes = std::min(std::max(ctx->pass_hint, 1), (int)kMaxPasses);
+  a.deep_launch = ctx->deep_hint ? 1 : 0;
   {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
@@ -577,6 +580,10 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   }
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
   a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
+  if (a.deep_launch) {
+    PCC_HIP(ctx->d_idx2_a.ensure(n)); PCC_HIP(ctx->d_idx2_b.ensure(n)); PCC_HIP(ctx->d_leaf_hi.ensure(n));
+    a.idx2_a = ctx->d_idx2_a.p; a.idx2_b = ctx->d_idx2_b.p; a.leaf_hi = ctx->d_leaf_hi.p;
+  }
   a.hist_rows = ctx->d_hist_rows.p; a.digit_tot = ctx->d_digit_tot.p; a.tile_prefix0 = ctx->d_tile_prefix0.p; a.sync_area = ctx->d_sync.p;
   a.leaf_start = ctx->d_leaf_start.p; a.leaf_code = ctx->d_leaf_code.p; a.leaf_base = ctx->d_leaf_base.p;
   a.leaf_t = ctx->d_leaf_t.p; a.occ = ctx->d_occ.p + tiles_region(n); a.bgr = ctx->d_bgr.p; a.centroid = ctx->d_centroid.p;
@@ -758,9 +765,15 @@ static int wait_frame_state(pcc_ctx* ctx) {
   // waited for was held up for tens of milliseconds -- another process on the GPU, a debugger; nothing is wrong with
   // the frame).  Either can show up on the re-run the other one caused, hence a loop; a poll may time out once.
   int spin_retries = 0;
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
     if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
       ctx->args.max_passes = kMaxPasses;
+    } else if (st.error == kErrDeep && !ctx->args.deep_launch) {
+      // a tree deeper than 21 levels: its Morton codes need two words; the kernels' DEEP instantiations and their arrays
+      ctx->args.deep_launch = 1;
+      ctx->args.max_passes = kMaxPasses;
+      PCC_HIP(ctx->d_idx2_a.ensure(ctx->n)); PCC_HIP(ctx->d_idx2_b.ensure(ctx->n)); PCC_HIP(ctx->d_leaf_hi.ensure(ctx->n));
+      ctx->args.idx2_a = ctx->d_idx2_a.p; ctx->args.idx2_b = ctx->d_idx2_b.p; ctx->args.leaf_hi = ctx->d_leaf_hi.p;
     } else if (st.error == kErrSpin && spin_retries == 0) {
       ++spin_retries;
     } else {
@@ -774,11 +787,12 @@ static int wait_frame_state(pcc_ctx* ctx) {
   if (st.error != kErrNone) {
     char buf[160];
     snprintf(buf, sizeof(buf), "unsupported frame geometry (device error %d: depth %d > %d, or key window %d bits missed)",
-             st.error, st.depth, kMaxDepth, st.vbits);
+             st.error, st.depth, kMaxDepthDeep, st.vbits);
     return fail(ctx, PCC_ERR_UNSUPPORTED, buf);
   }
   if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
   ctx->pass_hint = st.npasses;
+  ctx->deep_hint = st.depth > kMaxDepth;  // (a shallow frame behind a deep one goes back to the single-word kernels)
   return PCC_OK;
 }
 

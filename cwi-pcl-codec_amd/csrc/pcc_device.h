@@ -31,14 +31,19 @@ constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kItems = 8;          // items per thread in tiled kernels
 constexpr int kTile = kBlock * kItems;  // 2048 items per tile / bbox chunk
 constexpr int kMaxEpochs = 40;     // depth <= 32 => at most 33 growth events (+ first point)
-constexpr int kMaxDepth = 21;      // 3*D morton bits must fit 63 bits
+constexpr int kMaxDepth = 21;      // deepest tree whose Morton code (3 bits per level) fits one 64-bit word
+// Deeper trees (PCL allows them; a frame gets one when extent / resolution passes 2^19 or so) use TWO-WORD codes:
+// `lo` = the 21 low triples (63 bits, the sort key), `hi` = the triples above (up to 10: the sort's u32 payload); what
+// would ride in the payload otherwise (point index or colour word) rides in a second payload array.  Every kernel that
+// looks at a code has a DEEP instantiation; frames of up to 21 levels run the single-word instantiations unchanged.
+constexpr int kMaxDepthDeep = 31;  // 10 triples in the 32-bit high word (and PCL's own box growth stops at 31)
 // sort: onesweep-style LSD radix sort, one kernel per pass, digit width chosen per frame (<= 9 bits)
 constexpr int kSortThreads = 1024;         // 16 wave64 per workgroup: four per SIMD hide the ranking latencies
 constexpr int kSortItems = 4;              // keys per thread
 constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 keys per tile
 constexpr int kMaxDigitBits = 9;
 constexpr int kMaxBins = 1 << kMaxDigitBits;  // 512 = one digit per thread in the look-back
-constexpr int kMaxPasses = 7;              // 63 code bits / 9
+constexpr int kMaxPasses = 11;             // 63 low code bits / 9 + 30 high code bits / 9 (deep trees); 7 for single-word codes
 constexpr uint32_t kStatusAggregate = 1u << 30, kStatusInclusive = 2u << 30, kStatusValue = (1u << 30) - 1u;
 constexpr int kLookBackGroup = 16;         // tiles per look-back group (two-level look-back)
 constexpr uint32_t kSpinLimit = 1u << 20;  // bounded polling: a lost predecessor becomes an error, not a hang
@@ -52,11 +57,12 @@ struct ChunkBox {          // 32 bytes
 
 enum FrameError : int32_t {
   kErrNone = 0,
-  kErrDepth = 1,           // depth > kMaxDepth
+  kErrDepth = 1,           // depth > kMaxDepthDeep
   kErrPrefix = 2,          // a key fell outside the predicted varying-bit window (should not happen)
   kErrEpochs = 3,          // more than kMaxEpochs growth epochs
   kErrPasses = 4,          // the frame needs more sort passes than the host enqueued (host re-launches)
   kErrSpin = 5,            // a look-back poll ran into kSpinLimit (should not happen)
+  kErrDeep = 6,            // the tree is deeper than kMaxDepth and the host enqueued the single-word kernels (host re-launches)
 };
 
 struct FrameState {
@@ -78,6 +84,8 @@ struct FrameState {
   int32_t payload;                   // what the u32 payload of the sort carries: 0 nothing, 1 point index (pairs
                                      // mode), 2 the point's colour word (packed mode with colour: no gather later)
   int32_t colour_in_key;             // 1: the low 24 key bits (ibits = 24) are the point's colour, no payload, no index
+  int32_t deep;                      // 1: two-word codes (depth > kMaxDepth): key = low 63 code bits, payload = 3: the high code bits
+  int32_t payload2;                  // deep only, the second payload array: 0 nothing, 1 point index, 2 the point's colour word
   // cell ranks: the code that is SORTED may be shorter than the 3 * vbits_axis varying Morton bits.  A cloud that
   // straddles a high power-of-two boundary of its box varies in key bits far above its extent (a 1024-voxel capture in a
   // box of 8192: 13 bits per axis, 39 code bits, five sort passes), but touches only a few cells of side 2^code_low_bits

@@ -78,6 +78,11 @@ struct HotPathArgs {
   uint64_t* keys_b;
   uint32_t* idx_a;
   uint32_t* idx_b;
+  int deep_launch;     // 1: enqueue the DEEP instantiations (two-word Morton codes: trees of 22 to 31 levels); the device sends
+                       // a deep frame that meets the single-word kernels back with kErrDeep
+  uint32_t* idx2_a;    // deep only: second payload of the sort (point index or colour word), ping-pong
+  uint32_t* idx2_b;
+  uint32_t* leaf_hi;   // deep only: high word of each leaf's code
   uint32_t* hist_rows;  // [sort tiles][kMaxPasses][kMaxBins] digit counts from k_make_keys
   uint32_t* digit_tot;  // [kMaxPasses][kMaxBins]
   uint32_t* tile_prefix0;  // [sort tiles][kMaxBins] exclusive tile prefix of the pass-0 digit counts

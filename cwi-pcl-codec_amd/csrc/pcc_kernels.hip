@@ -276,8 +276,8 @@ constexpr int kBoxWords = 8;  // mn xyz, mx xyz, first finite index, finite coun
 //      streaming workgroups of k_boxes_events when they make the keys themselves (fused mode, below).
 constexpr uint64_t kInvalidKey = ~0ull;
 struct KeyGeom {
-  int vb, cm, np, ibits, payload;
-  bool packed_mode, colour_in_key, ranked;
+  int vb, cm, np, ibits, payload, payload2;
+  bool packed_mode, colour_in_key, ranked, deep;
   unsigned cbase[3], cdim[3], lm, m;
   uint32_t prefix[3];
   int pshift[kMaxPasses];
@@ -285,7 +285,8 @@ struct KeyGeom {
 };
 // `mn`, `shift`: origin and key offset of the epoch the point belongs to; `cell_rank`: FrameState::cell_rank or a copy
 __device__ __forceinline__ uint64_t point_code(const KeyGeom& g, const double* mn, const uint32_t* shift, const uint8_t* cell_rank, double res,
-                                               double inv_res_pow2, float x, float y, float z, bool& ok) {
+                                               double inv_res_pow2, float x, float y, float z, bool& ok, uint32_t& hi) {
+  hi = 0u;
   const float p[3] = {x, y, z};
   unsigned kk[3];
 #pragma unroll
@@ -296,12 +297,21 @@ __device__ __forceinline__ uint64_t point_code(const KeyGeom& g, const double* m
     kk[a] = (unsigned)d + shift[a];
     ok &= g.vb >= 32 || ((kk[a] >> g.vb) == (g.prefix[a] >> g.vb));
   }
+  if (g.deep) {  // two-word code: `hi` = the triples above the 21 low ones (pcc_device.h: kMaxDepthDeep)
+    hi = (uint32_t)morton3((kk[0] & g.m) >> 21, (kk[1] & g.m) >> 21, (kk[2] & g.m) >> 21);
+    return morton3(kk[0] & g.m & 0x1fffffu, kk[1] & g.m & 0x1fffffu, kk[2] & g.m & 0x1fffffu);
+  }
   if (!g.ranked) return morton3(kk[0] & g.m, kk[1] & g.m, kk[2] & g.m);
   unsigned d[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { d[a] = (kk[a] >> g.cm) - g.cbase[a]; ok &= d[a] < g.cdim[a]; }
   const unsigned cell = ok ? d[2] + g.cdim[2] * (d[1] + g.cdim[1] * d[0]) : 0u;
   return ((uint64_t)cell_rank[cell] << (3 * g.cm)) | morton3(kk[0] & g.lm, kk[1] & g.lm, kk[2] & g.lm);
+}
+
+// digit of pass q: of the low word, or (deep trees, shift >= 63) of the high word
+__device__ __forceinline__ uint32_t code_digit(const KeyGeom& g, int q, uint64_t lo, uint32_t hi) {
+  return (g.pshift[q] >= 63 ? (hi >> (g.pshift[q] - 63)) : (uint32_t)(lo >> g.pshift[q])) & g.pmask[q];
 }
 
 // ---- fused mode ("read the cloud once"): the streaming workgroups keep their 2048 points in registers, and once
@@ -322,8 +332,8 @@ constexpr int kPlanCellBase = 11;   // 3 words
 constexpr int kPlanCellDim = 14;    // 3 words
 constexpr int kPlanLastEpoch = 17;  // index of the first point of the last epoch
 constexpr int kPlanPass = 18;       // kMaxPasses words: bits | shift << 8
-constexpr int kPlanRanks = 25;      // 16 words: cell_rank[64]
-constexpr int kPlanWords = 41;
+constexpr int kPlanRanks = kPlanPass + kMaxPasses;  // 16 words: cell_rank[64]
+constexpr int kPlanWords = kPlanRanks + 16;
 constexpr int kPlanGranules = 64;   // the per-chunk granules start here
 static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords <= 64 && kPlanGranules == (int)kPlanGranulesHost, "one wave sweeps the plan");
 
@@ -451,6 +461,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     const uint32_t bits = s_plan[kPlanBits];
     g.vb = (int)(bits & 0xffu); g.cm = (int)((bits >> 8) & 0xffu); g.np = (int)((bits >> 16) & 0xffu); g.ibits = (int)(bits >> 24);
     g.packed_mode = ((flags >> 1) & 1u) != 0; g.payload = (int)((flags >> 2) & 3u); g.colour_in_key = ((flags >> 4) & 1u) != 0;
+    g.deep = false; g.payload2 = 0;  // (a deep frame's plan is not valid: k_make_keys makes its keys)
     g.ranked = g.cm < g.vb;
     g.lm = g.cm >= 32 ? 0xffffffffu : ((1u << g.cm) - 1u);
     g.m = g.vb >= 32 ? 0xffffffffu : ((1u << g.vb) - 1u);
@@ -473,11 +484,12 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     uint64_t key = kInvalidKey;
     if (px[FUSED ? k : 0] == px[FUSED ? k : 0]) {  // finite (NaN marks the others)
       bool ok = true;
-      const uint64_t code = point_code(g, emn, no_shift, ranks, res, fk.inv_res_pow2, px[FUSED ? k : 0], py[FUSED ? k : 0], pz[FUSED ? k : 0], ok);
+      uint32_t hi_unused;
+      const uint64_t code = point_code(g, emn, no_shift, ranks, res, fk.inv_res_pow2, px[FUSED ? k : 0], py[FUSED ? k : 0], pz[FUSED ? k : 0], ok, hi_unused);
       if (!ok) s_plan[kPlanWords + 1] = 1u;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
 #pragma unroll
       for (int q = 0; q < kMaxPasses; ++q)
-        if (q < g.np) atomicAdd(&s_hist[q * kMaxBins + ((uint32_t)(code >> g.pshift[q]) & g.pmask[q])], 1u);
+        if (q < g.np) atomicAdd(&s_hist[q * kMaxBins + code_digit(g, q, code, 0u)], 1u);
       const uint64_t low = g.colour_in_key ? (uint64_t)(pc[FUSED ? k : 0] & 0xffffffu) : (g.ibits ? (uint64_t)i : 0ull);
       key = g.packed_mode ? ((code << g.ibits) | low) : code;
     }
@@ -493,7 +505,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int do_color, FixedBox box,
+                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int deep_launched, int do_color, FixedBox box,
                                                          FrameState* __restrict__ st, FusedKeys fk, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction (fused mode: plan, digit counts)
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       if (threadIdx.x == 0) {
         st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
         st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0;
+        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0; st->deep = 0; st->payload2 = 0;
         st->code_low_bits = 0; st->code_bits = 0;
         st->passes_launched = passes_launched;
       }
@@ -815,7 +827,12 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->n_branches = 0;
     }
   } else if (wave_id() == 1) {
-    if (depth > kMaxDepth && err == kErrNone) err = kErrDepth;
+    if (depth > kMaxDepthDeep && err == kErrNone) err = kErrDepth;
+    // two-word codes (pcc_device.h): no cell ranks, no fused keys, pairs of payloads.  Which instantiations of the kernels
+    // behind this one were enqueued is the host's decision (it cannot know the depth): a frame in the deep sequence is
+    // treated as deep whatever its depth, a deep frame in the single-word sequence is sent back (kErrDeep)
+    const bool deep = deep_launched != 0;
+    if (depth > kMaxDepth && !deep && err == kErrNone) err = kErrDeep;
     // varying key bits from the global AABB under the final origin, +-1 voxel of slack
     int vb = 0;
     unsigned kmin[3], kmax[3];
@@ -848,7 +865,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       const int bits = 3 * m + rb;
       if (passes_for(bits) < passes_for(cbits)) { cm = m; cbits = bits; for (int a = 0; a < 3; ++a) cdim[a] = d[a]; }
     }
-    if (no_cell_ranks) { cm = vb; cbits = 3 * vb; cdim[0] = cdim[1] = cdim[2] = 1u; }
+    if (no_cell_ranks || deep) { cm = vb; cbits = 3 * vb; cdim[0] = cdim[1] = cdim[2] = 1u; }
     uint8_t st_rank_of_lane = 0;  // rank of cell `lane` (also goes into the fused mode's plan below)
     {
       const unsigned nc = cdim[0] * cdim[1] * cdim[2];
@@ -875,26 +892,34 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     // key is the code alone, or [code | the point's 24 colour bits] -- 8 B per key and pass, no payload array.
     // Otherwise code + index in one u64 when they fit (+ the colour word as a u32 payload: 12 B); otherwise u64 code
     // keys with a u32 index payload (12 B).  All of them give the same order.
-    const bool bare = !need_index && !force_pairs && (!do_color || cbits + 24 <= 63);
-    const int packed = (bare || (cbits + ibits <= 64 && !force_pairs)) ? 1 : 0;
+    const bool bare = !deep && !need_index && !force_pairs && (!do_color || cbits + 24 <= 63);
+    const int packed = (!deep && (bare || (cbits + ibits <= 64 && !force_pairs))) ? 1 : 0;
     if (bare) ibits = do_color ? 24 : 0;
     if (!packed) ibits = 0;
-    // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them
+    // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them.  Deep trees: the low word's
+    // bits first, then the high word's (a digit never straddles the two; a shift of 63 or more means "of the high word")
     const int vbits = cbits;  // what is sorted
-    int np = (vbits + kMaxDigitBits - 1) / kMaxDigitBits;
-    if (np < 1) np = 1;
+    const int lo_bits = vbits < 63 ? vbits : 63, hi_bits = vbits - lo_bits;
+    int np_lo = (lo_bits + kMaxDigitBits - 1) / kMaxDigitBits;
+    if (np_lo < 1) np_lo = 1;
+    const int np_hi = (hi_bits + kMaxDigitBits - 1) / kMaxDigitBits;
+    const int np = np_lo + np_hi;
     if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
+    // digit q of `n` digits over `bits` bits: width, and offset of its first bit
+    auto digit = [](int q, int n, int bits, int& width, int& offset) {
+      width = 0; offset = 0;
+      for (int r = 0; r <= q; ++r) {
+        int b = 0;
+        if (r < n) { b = bits / n + (r < bits % n ? 1 : 0); if (b < 1) b = 1; }
+        if (r < q) offset += b; else width = b;
+      }
+    };
     const int p = lane_id();
     if (p < kMaxPasses) {
       int bits = 0, sh = 0;
-      for (int q = 0; q <= p; ++q) {
-        int bq = 0;
-        if (q < np) {
-          bq = vbits / np + (q < vbits % np ? 1 : 0);
-          if (bq < 1) bq = 1;
-        }
-        if (q < p) sh += bq; else bits = bq;
-      }
+      if (p < np_lo) digit(p, np_lo, lo_bits, bits, sh);
+      else if (p < np) { digit(p - np_lo, np_hi, hi_bits, bits, sh); sh += 63; }
+      else { bits = 0; sh = vbits; }
       st->pass_bits[p] = bits;
       st->pass_shift[p] = sh;
     }
@@ -904,8 +929,10 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->vbits = 3 * vb;
       st->ibits = ibits;
       st->packed = packed;
-      st->payload = bare ? 0 : (packed ? (do_color ? 2 : 0) : 1);
+      st->payload = deep ? 3 : (bare ? 0 : (packed ? (do_color ? 2 : 0) : 1));
       st->colour_in_key = (bare && do_color) ? 1 : 0;
+      st->deep = deep ? 1 : 0;
+      st->payload2 = !deep ? 0 : (need_index ? 1 : (do_color ? 2 : 0));
       st->npasses = err != kErrNone ? 0 : np;
       st->error = err;
     }
@@ -927,7 +954,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         v = (uint32_t)vb | ((uint32_t)cm << 8) | ((uint32_t)np << 16) | ((uint32_t)ibits << 24);
       } else if (p == kPlanFlags) {
         const uint32_t payload = bare ? 0u : (packed ? (do_color ? 2u : 0u) : 1u);
-        v = (err == kErrNone ? 1u : 0u) | ((uint32_t)packed << 1) | (payload << 2) | (((bare && do_color) ? 1u : 0u) << 4);
+        v = ((err == kErrNone && !deep) ? 1u : 0u) | ((uint32_t)packed << 1) | (payload << 2) | (((bare && do_color) ? 1u : 0u) << 4);
       } else if (p >= kPlanPrefix && p < kPlanPrefix + 3) {
         v = vb >= 32 ? 0u : ((PCC_PICK3(kmin, p - kPlanPrefix) >> vb) << vb);
       } else if (p >= kPlanCellBase && p < kPlanCellBase + 3) {
@@ -937,13 +964,10 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       } else if (p == kPlanLastEpoch) {
         v = (uint32_t)ev_index[nev - 1];
       } else if (p >= kPlanPass && p < kPlanPass + kMaxPasses) {
-        const int q = p - kPlanPass;
+        const int q = p - kPlanPass;  // (the plan is only used for single-word codes: np = np_lo)
         int bq = 0, sh = 0;
-        for (int r = 0; r <= q; ++r) {
-          int b = 0;
-          if (r < np) { b = vbits / np + (r < vbits % np ? 1 : 0); if (b < 1) b = 1; }
-          if (r < q) sh += b; else bq = b;
-        }
+        digit(q, np_lo, lo_bits, bq, sh);
+        if (q >= np_lo) bq = 0;
         v = (uint32_t)bq | ((uint32_t)sh << 8);
       } else if (p >= kPlanRanks && p < kPlanRanks + 16) {
         v = reinterpret_cast<const uint32_t*>(s_rank8)[p - kPlanRanks];
@@ -971,7 +995,7 @@ constexpr int kKeyThreads = kSortThreads;
 template <int KEY_ITEMS>
 __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ hist_rows,
+                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ idx2, uint32_t* __restrict__ hist_rows,
                                                             const uint64_t* __restrict__ chunk_state, uint32_t seq, unsigned long long* span) {
   const KSpan kspan(span);
   constexpr int kKeyTile = kKeyThreads * KEY_ITEMS;
@@ -993,6 +1017,7 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   g.packed_mode = st->packed != 0;
   g.payload = st->payload;
   g.colour_in_key = st->colour_in_key != 0;
+  g.deep = st->deep != 0; g.payload2 = st->payload2;
   g.cm = st->code_low_bits;
   g.ranked = g.cm < g.vb;  // the high key bits go into the code as the rank of their cell (FrameState::code_low_bits)
 #pragma unroll
@@ -1011,23 +1036,27 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
     float x, y, z;
     load_xyz(pv, i, x, y, z);
     uint64_t key = kInvalidKey;
+    uint32_t hi = 0u;
     if (finite3(x, y, z) && (int)i >= ep0) {
       int e = ne - 1;
       if (!late) {  // rare: the tile overlaps an earlier epoch
         while (e > 0 && st->ep_index[e] > (int)i) --e;
       }
       bool ok = true;
-      const uint64_t code = point_code(g, st->ep_mn[e], st->ep_shift[e], st->cell_rank, res, inv_res_pow2, x, y, z, ok);
+      const uint64_t code = point_code(g, st->ep_mn[e], st->ep_shift[e], st->cell_rank, res, inv_res_pow2, x, y, z, ok, hi);
       if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
 #pragma unroll
       for (int p = 0; p < kMaxPasses; ++p)
-        if (p < g.np) atomicAdd(&s_h[p][(uint32_t)(code >> g.pshift[p]) & g.pmask[p]], 1u);
+        if (p < g.np) atomicAdd(&s_h[p][code_digit(g, p, code, hi)], 1u);
       // low bits: the point index, or (nobody needs the index) the point's colour, or nothing
       const uint64_t low = g.colour_in_key ? (uint64_t)(load_rgba(pv, i) & 0xffffffu) : (g.ibits ? (uint64_t)i : 0ull);
       key = g.packed_mode ? ((code << g.ibits) | low) : code;
     }
     if (g.payload == 1) idx[i] = i;
     else if (g.payload == 2) idx[i] = load_rgba(pv, i);  // same 32-byte point as x,y,z: no extra traffic
+    else if (g.payload == 3) idx[i] = hi;                // deep trees: the high word of the code
+    if (g.payload2 == 1) idx2[i] = i;
+    else if (g.payload2 == 2) idx2[i] = load_rgba(pv, i);
     keys[i] = key;
   }
   __syncthreads();
@@ -1108,10 +1137,12 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
 // (second launch bound = waves per SIMD the register allocation has to leave room for: four, i.e. one 1024-thread or
 // two 512-thread workgroups per CU.  Without it the 512-thread shape takes 151 registers -- it is allowed 256 -- and
 // only one workgroup fits a CU, which is the whole point of that shape gone.)
-template <int THREADS, int ITEMS>
+// (DEEP: two-word codes -- the u32 payload is the code's high word, whose digits the last passes sort by, and a second
+// payload array carries the point index or the colour word)
+template <int THREADS, int ITEMS, bool DEEP = false>
 __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
                                                             uint64_t* out_a, uint64_t* out_b,
-                                                            uint32_t* idx_a, uint32_t* idx_b, uint32_t n, int pass,
+                                                            uint32_t* idx_a, uint32_t* idx_b, uint32_t* idx2_a, uint32_t* idx2_b, uint32_t n, int pass,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
                                                             const uint32_t* __restrict__ tile_prefix0,
                                                             uint32_t* status_all, uint32_t* tickets,
@@ -1123,11 +1154,13 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   static_assert(THREADS * ITEMS == kSortTile && THREADS >= kMaxBins, "a tile is 4096 keys (the histogram rows of k_make_keys); one thread per digit");
   // s_raw is used twice: while ranking, one 64-bit lane mask per (wave, digit); afterwards the tile's
   // keys (and payload) in digit order, so that the global writes are runs
-  constexpr int kRawWords = NW * kMaxBins > kSortTile * 3 / 2 ? NW * kMaxBins : kSortTile * 3 / 2;
+  constexpr int kTileWords = DEEP ? kSortTile * 2 : kSortTile * 3 / 2;  // keys + one payload (+ a second one)
+  constexpr int kRawWords = NW * kMaxBins > kTileWords ? NW * kMaxBins : kTileWords;
   __shared__ __attribute__((aligned(16))) uint64_t s_raw[kRawWords];
   uint64_t* s_match = s_raw;
   uint64_t* s_keys = s_raw;
   uint32_t* s_pay = reinterpret_cast<uint32_t*>(s_raw + kSortTile);
+  uint32_t* s_pay2 = s_pay + kSortTile;  // DEEP only
   __shared__ uint16_t s_cnt[NW][kMaxBins];  // per-wave running digit counts, then wave start ranks
   __shared__ uint32_t s_gofs[kMaxBins];     // global position of a digit's first key minus its position in s_keys
   __shared__ uint16_t s_dstart[kMaxBins];   // position of a digit's first key in s_keys
@@ -1160,11 +1193,18 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   if (tile >= n_tiles) return;
 
   const bool with_payload = st->payload != 0;
+  const bool with_payload2 = DEEP && st->payload2 != 0;
   const int shift = st->ibits + st->pass_shift[pass];
+  // the digit of a key: of the key word or, in the last passes over a two-word code, of the payload (the high word)
+  const bool of_high = DEEP && shift >= 63;
+  const int hshift = of_high ? shift - 63 : 0;
+  auto digit_of = [&](uint64_t k, uint32_t p) { return (of_high ? (p >> hshift) : (uint32_t)(k >> shift)) & mask; };
   const uint64_t* in = (pass & 1) ? buf_b : buf_a;  // ping-pong: pass 0 reads a writes b
   uint64_t* out = (pass & 1) ? out_a : out_b;
   const uint32_t* pay_in = (pass & 1) ? idx_b : idx_a;
   uint32_t* pay_out = (pass & 1) ? idx_a : idx_b;
+  const uint32_t* pay2_in = (pass & 1) ? idx2_b : idx2_a;
+  uint32_t* pay2_out = (pass & 1) ? idx2_a : idx2_b;
   const uint32_t n_groups_max = (n_tiles_max + kLookBackGroup - 1) / kLookBackGroup;
   uint32_t* status = status_all + ((size_t)pass * (n_tiles_max + n_groups_max)) * kMaxBins;  // one word per (tile, digit)
   uint32_t* gstatus = status + (size_t)n_tiles_max * kMaxBins;                                // one per (group, digit)
@@ -1177,13 +1217,14 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   // Tile order = (wave, round, lane): every wave owns consecutive keys, read as rows of 64.
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
   uint64_t key[ITEMS];
-  uint32_t pay[ITEMS];
+  uint32_t pay[ITEMS], pay2[DEEP ? ITEMS : 1];
   uint16_t lrank[ITEMS];
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
     key[r] = i < count ? in[i] : kInvalidKey;
     pay[r] = (with_payload && i < count) ? pay_in[i] : 0u;
+    if (DEEP) pay2[DEEP ? r : 0] = (with_payload2 && i < count) ? pay2_in[i] : 0u;
   }
   // ---- ranking first: the tile's digit counts fall out of it (sum of the per-wave counts), so the separate counting
   //      pass over the keys that used to come first is gone; the tile's word is published right after, and the keys go
@@ -1197,7 +1238,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const bool valid = key[r] != kInvalidKey;
-    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    const uint32_t d = digit_of(key[r], pay[r]);
     // the peers of the row's first key come from one ballot (the most significant digit of a clustered cloud has few
     // values, and 64 lanes ORing into one LDS word would serialise), the others through LDS
     const uint64_t vm = __ballot(valid);
@@ -1240,10 +1281,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     if (key[r] != kInvalidKey) {
-      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+      const uint32_t d = digit_of(key[r], pay[r]);
       const uint32_t lp = (uint32_t)s_dstart[d] + s_cnt[wave][d] + lrank[r];
       s_keys[lp] = key[r];
       if (with_payload) s_pay[lp] = pay[r];
+      if (DEEP && with_payload2) s_pay2[lp] = pay2[DEEP ? r : 0];
     }
   }
   // Two-level decoupled look-back over one self-describing word per (tile, digit) / (group of 16 tiles, digit).
@@ -1356,11 +1398,12 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
     const uint32_t lp = (uint32_t)k * THREADS + threadIdx.x;
     if (lp < tile_valid) {
       const uint64_t kk = s_keys[lp];
-      const uint32_t d = (uint32_t)(kk >> shift) & mask;
+      const uint32_t d = digit_of(kk, DEEP ? s_pay[lp] : 0u);
       const uint32_t pos = s_gofs[d] + lp;
       if (pos < out_count) {  // always true unless a look-back gave up (kErrSpin)
         out[pos] = kk;
         if (with_payload) pay_out[pos] = s_pay[lp];
+        if (DEEP && with_payload2) pay2_out[pos] = s_pay2[lp];
       }
     }
   }
@@ -1374,24 +1417,72 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
 // SURVEY.md row P5) across the tiles: word = flag(2) | sum t (32) | leaf count (30).  The tile that
 // opens a piece of the DFS stream also zeroes it (B is only known on the device).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t head_t(uint64_t code, uint64_t prev, bool is_first, int depth) {
+// ---- Morton codes of one word (trees of up to 21 levels) or two (deeper ones, pcc_device.h): the few operations the
+//      leaf kernels need, so that their bodies read the same for both ----
+struct Code2 {
+  uint64_t lo;  // the 21 low triples
+  uint32_t hi;  // the triples above
+};
+template <bool DEEP> struct CodeOf { using type = uint64_t; };
+template <> struct CodeOf<true> { using type = Code2; };
+__device__ __forceinline__ bool code_eq(uint64_t a, uint64_t b) { return a == b; }
+__device__ __forceinline__ bool code_eq(Code2 a, Code2 b) { return a.lo == b.lo && a.hi == b.hi; }
+__device__ __forceinline__ bool code_lt(uint64_t a, uint64_t b) { return a < b; }
+__device__ __forceinline__ bool code_lt(Code2 a, Code2 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+// the highest triple in which two different codes differ
+__device__ __forceinline__ int code_top_triple(uint64_t a, uint64_t b) { return (63 - __clzll((long long)(a ^ b))) / 3; }
+__device__ __forceinline__ int code_top_triple(Code2 a, Code2 b) {
+  const uint32_t xh = a.hi ^ b.hi;
+  return xh ? 21 + (31 - __clz((int)xh)) / 3 : (63 - __clzll((long long)(a.lo ^ b.lo))) / 3;
+}
+// the code with its v low triples cleared
+__device__ __forceinline__ uint64_t code_clear_low(uint64_t c, int v) { return 3 * v >= 64 ? 0ull : ((c >> (3 * v)) << (3 * v)); }
+__device__ __forceinline__ Code2 code_clear_low(Code2 c, int v) {
+  if (v >= 21) { const int sh = 3 * (v - 21); return Code2{0ull, sh >= 32 ? 0u : ((c.hi >> sh) << sh)}; }
+  return Code2{(c.lo >> (3 * v)) << (3 * v), c.hi};
+}
+__device__ __forceinline__ uint32_t code_triple(uint64_t c, int t) { return (uint32_t)(c >> (3 * t)) & 7u; }
+__device__ __forceinline__ uint32_t code_triple(Code2 c, int t) { return t >= 21 ? ((c.hi >> (3 * (t - 21))) & 7u) : ((uint32_t)(c.lo >> (3 * t)) & 7u); }
+__device__ __forceinline__ uint64_t code_or(uint64_t a, uint64_t b) { return a | b; }
+__device__ __forceinline__ Code2 code_or(Code2 a, Code2 b) { return Code2{a.lo | b.lo, a.hi | b.hi}; }
+// key bits of axis a (0 x, 1 y, 2 z)
+__device__ __forceinline__ uint32_t code_axis(uint64_t c, int a) { return compact3(c >> (2 - a)); }
+__device__ __forceinline__ uint32_t code_axis(Code2 c, int a) { return compact3(c.lo >> (2 - a)) | (compact3((uint64_t)c.hi >> (2 - a)) << 21); }
+__device__ __forceinline__ void code_make(uint64_t& c, uint64_t lo, uint32_t) { c = lo; }
+__device__ __forceinline__ void code_make(Code2& c, uint64_t lo, uint32_t hi) { c.lo = lo; c.hi = hi; }
+__device__ __forceinline__ uint64_t code_low(uint64_t c) { return c; }
+__device__ __forceinline__ uint64_t code_low(Code2 c) { return c.lo; }
+__device__ __forceinline__ uint32_t code_high(uint64_t) { return 0u; }
+__device__ __forceinline__ uint32_t code_high(Code2 c) { return c.hi; }
+// Morton code of three key prefixes (the constant high key bits of a frame)
+__device__ __forceinline__ void code_of_keys(uint64_t& c, const uint32_t k[3]) { c = morton3(k[0], k[1], k[2]); }
+__device__ __forceinline__ void code_of_keys(Code2& c, const uint32_t k[3]) {
+  c.lo = morton3(k[0] & 0x1fffffu, k[1] & 0x1fffffu, k[2] & 0x1fffffu);
+  c.hi = (uint32_t)morton3(k[0] >> 21, k[1] >> 21, k[2] >> 21);
+}
+
+template <typename CodeT>
+__device__ __forceinline__ uint64_t head_t(CodeT code, CodeT prev, bool is_first, int depth) {
   if (is_first) return ((uint64_t)depth << 32) | 1ull;
-  const uint64_t x = code ^ prev;
-  if (x == 0) return 0ull;
-  const int msb = 63 - __clzll((long long)x);
-  return ((uint64_t)(msb / 3) << 32) | 1ull;
+  if (code_eq(code, prev)) return 0ull;
+  return ((uint64_t)code_top_triple(code, prev) << 32) | 1ull;
+}
+__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v, uint32_t first) {  // the value of the lane below; lane 0 keeps `first`
+  return (uint32_t)wave_shr1((uint64_t)v, (uint64_t)first);
 }
 __device__ __forceinline__ uint64_t scan_pack(uint64_t ht) { return ((ht >> 32) << 30) | (ht & 0x3fffffffull); }
 __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30) & 0xffffffffull) << 32) | (w & 0x3fffffffull); }
 
 // (two workgroup shapes, like k_sort_pass: 1024 threads x 4 keys for small grids, 512 x 8 -- two workgroups per CU, one
 // looks back while the other scans -- for the rest)
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool DEEP = false>
 __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+                                                            const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
-                                                            uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code,
+                                                            uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code, uint32_t* __restrict__ leaf_hi,
                                                             uint32_t* __restrict__ leaf_base, uint8_t* __restrict__ leaf_t,
                                                             uint8_t* __restrict__ occ, unsigned long long* span) {
+  using CodeT = typename CodeOf<DEEP>::type;
   const KSpan kspan(span);
   constexpr int NW = THREADS / 64;
   static_assert(THREADS * ITEMS == kSortTile, "a tile is 4096 keys");
@@ -1405,6 +1496,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
   const uint32_t tile = s_tile;
   if ((uint64_t)tile * kSortTile >= nfin) return;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const uint32_t* highs = (st->npasses & 1) ? idx_b : idx_a;  // DEEP: the codes' high words (the sort's payload)
   const int ibits = st->ibits, depth = st->depth;
   const int lane = lane_id(), wave = wave_id();
   // sorted codes whose high part is a cell rank (FrameState::code_low_bits) become Morton codes again here: nothing
@@ -1421,20 +1513,29 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
   // Every wave owns 512 consecutive sorted keys, read as 8 rows of 64 (coalesced); element (r, lane)
   // is key wbase + 64 r + lane, so scan order is row-major inside the wave, then wave-major.
   const uint32_t wbase = tile * kSortTile + (uint32_t)wave * (kSortTile / NW);
-  uint64_t ht[ITEMS], code[ITEMS], inc[ITEMS];
+  uint64_t ht[ITEMS], inc[ITEMS];
+  CodeT code[ITEMS];
+  auto code_at = [&](uint32_t i) {  // the code of sorted element i
+    CodeT c;
+    if (DEEP) code_make(c, keys[i], highs[i]);  // (no index bits, no cell ranks in a deep frame's keys)
+    else code_make(c, unrank(keys[i] >> ibits), 0u);
+    return c;
+  };
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-    code[r] = i < nfin ? unrank(keys[i] >> ibits) : 0ull;
+    if (i < nfin) code[r] = code_at(i); else code_make(code[r], 0ull, 0u);
   }
-  uint64_t carry = (lane == 0 && wbase > 0 && wbase < nfin) ? unrank(keys[wbase - 1] >> ibits) : 0ull;  // key before the segment
+  CodeT carry;  // key before the segment
+  if (lane == 0 && wbase > 0 && wbase < nfin) carry = code_at(wbase - 1); else code_make(carry, 0ull, 0u);
   uint64_t wave_tot = 0;
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-    const uint64_t prev = wave_shr1(code[r], carry);  // the key of the lane before; lane 0: the end of the row before
+    CodeT prev;  // the key of the lane before; lane 0: the end of the row before
+    code_make(prev, wave_shr1(code_low(code[r]), code_low(carry)), DEEP ? wave_shr1_u32(code_high(code[r]), code_high(carry)) : 0u);
     ht[r] = i < nfin ? head_t(code[r], prev, i == 0, depth) : 0ull;
-    carry = lane63(code[r]);  // lane 0 of the next row compares against the end of this one
+    code_make(carry, lane63(code_low(code[r])), DEEP ? lane63(code_high(code[r])) : 0u);  // lane 0 of the next row compares against the end of this one
     inc[r] = wave_incl_scan_u64(ht[r]) + wave_tot;
     wave_tot = lane63(inc[r]);
   }
@@ -1484,7 +1585,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
       const uint64_t ex = pre + woff + inc[r] - ht[r];
       const uint32_t id = (uint32_t)(ex & 0xffffffffu);
       leaf_start[id] = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-      leaf_code[id] = code[r];
+      leaf_code[id] = code_low(code[r]);
+      if (DEEP) leaf_hi[id] = code_high(code[r]);
       leaf_base[id] = (uint32_t)(ex >> 32);
       leaf_t[id] = (uint8_t)(ht[r] >> 32);
     }
@@ -1612,23 +1714,31 @@ constexpr int kFinRounds = 4;                          // leaves per thread
 constexpr int kFinTile = kFinThreads * kFinRounds;     // 2048 leaf positions
 constexpr int kFinSlots = kFinTile / 64;               // (wave, round) slots of 64 consecutive leaves
 constexpr int kOccWindow = 3072;                       // dwords of the DFS stream collected in LDS (a surface needs ~300, a dense cloud ~1 800)
-constexpr int kMaskStride = kMaxDepth + 1;
 constexpr int kColourStage = 2560;                     // colour words staged in LDS per tile (1.25 points per leaf)
 
 // (second launch bound: six waves per SIMD, i.e. three of these workgroups per CU -- the kernel spends two thirds of its
 // time waiting for its leaf records and for the parent search, and only other workgroups can fill that)
+// (DEEP: trees of 22 to 31 levels, two-word codes: per-level tables for 31 levels, the codes' high words beside the low
+// ones, point index or colour word from the sort's second payload)
+template <bool DEEP>
 __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, double res, LeafParams lp,
                                                            const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
                                                            const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
+                                                           const uint32_t* __restrict__ idx2_a, const uint32_t* __restrict__ idx2_b,
                                                            const FrameState* __restrict__ st,
                                                            const uint32_t* __restrict__ leaf_start, const uint64_t* __restrict__ leaf_code,
+                                                           const uint32_t* __restrict__ leaf_hi,
                                                            const uint32_t* __restrict__ leaf_base, const uint8_t* __restrict__ leaf_t,
                                                            uint8_t* __restrict__ occ, uint8_t* __restrict__ bgr, uint8_t* __restrict__ centroid,
                                                            uint8_t* __restrict__ image, float4* __restrict__ simplified, unsigned long long* span) {
   const KSpan kspan(span);
+  using CodeT = typename CodeOf<DEEP>::type;
+  constexpr int kDepthCap = DEEP ? kMaxDepthDeep : kMaxDepth;
+  constexpr int kMaskStride = kDepthCap + 1;
   PCC_KTR(5, 0);
   const uint32_t L = st->n_leaves;
   if (L == 0 || st->error != kErrNone) return;  // after an error upstream the leaf arrays are not to be trusted
+  if ((st->deep != 0) != DEEP) return;          // (cannot happen: k_boxes_events marks the frame by the sequence that was enqueued)
   const uint32_t W = 256u, H = L / 256u + 1u;  // jpegcc.h:194-198
   // Block row: image rows [8 br, 8 br + 8).  Workgroups go to the XCDs round robin (workgroup b to XCD b % 8), and a
   // block row looks at the leaf records just before its own (parent search): every XCD takes one contiguous range of
@@ -1646,9 +1756,10 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   __shared__ __attribute__((aligned(16))) uint32_t s_scratch[kFinTile + kOccWindow + kFinSlots * kMaskStride * 2 + kFinTile / 4];
   __shared__ uint32_t s_col[kColourStage];  // the tile's sorted colour words, loaded as one contiguous run
   __shared__ uint32_t s_pad;
-  __shared__ unsigned long long s_slotbits[kMaxDepth + 2];  // per level v: which slots hold a leaf with t >= v
-  __shared__ uint32_t s_far[kMaxDepth + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
+  __shared__ unsigned long long s_slotbits[kDepthCap + 2];  // per level v: which slots hold a leaf with t >= v
+  __shared__ uint32_t s_far[kDepthCap + 2];  // stream offset of the level-(D-v) node that was open when this tile starts
   __shared__ uint64_t s_probe[64];
+  __shared__ uint32_t s_probe_hi[DEEP ? 64 : 1];
   uint32_t* s_base = s_scratch;
   uint32_t* s_occ = s_scratch + kFinTile;
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
@@ -1660,41 +1771,45 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   IndexOf index_of;
   index_of.keys = keys;
   const uint32_t* pay_sorted = (st->npasses & 1) ? idx_b : idx_a;
-  index_of.idx = st->payload == 1 ? pay_sorted : nullptr;
+  const uint32_t* pay2_sorted = (st->npasses & 1) ? idx2_b : idx2_a;
+  index_of.idx = st->payload == 1 ? pay_sorted : ((DEEP && st->payload2 == 1) ? pay2_sorted : nullptr);
   index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
-  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : nullptr;
+  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : ((DEEP && st->payload2 == 2) ? pay2_sorted : nullptr);
   const uint64_t* colour_keys = st->colour_in_key ? keys : nullptr;
+  auto leaf_code_at = [&](uint32_t j) { CodeT c; code_make(c, leaf_code[j], DEEP ? leaf_hi[j] : 0u); return c; };
 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
-  if (threadIdx.x < kMaxDepth + 2) s_slotbits[threadIdx.x] = 0ull;
+  if (threadIdx.x < kDepthCap + 2) s_slotbits[threadIdx.x] = 0ull;
   __syncthreads();
   PCC_KTR(7, 0);
   // first probes of the parent search below (the same for every level): requested together with the leaf records
-  uint64_t probe_code = ~0ull;
+  CodeT probe_code;
+  code_make(probe_code, ~0ull, ~0u);
   const bool probes_here = wave == kFinThreads / 64 - 1 && nl && pos0 > 255u;
   if (probes_here) {
     const uint32_t step = (pos0 + 63u) / 64u, probe = (uint32_t)lane * step;
-    if (probe < pos0) probe_code = leaf_code[probe];
+    if (probe < pos0) probe_code = leaf_code_at(probe);
   }
   // every load that does not depend on another one is requested first (leaf records of all four rounds, the ends of
   // the tile's run of points, the code the parent search starts from), then the LDS work
   int t[kFinRounds];
   uint32_t base[kFinRounds], ls[kFinRounds], le[kFinRounds];
-  uint64_t code[kFinRounds];
+  CodeT code[kFinRounds];
 #pragma unroll
   for (int r = 0; r < kFinRounds; ++r) {
     const uint32_t lj = ((uint32_t)wave * kFinRounds + r) * 64u + (uint32_t)lane, j = pos0 + lj;
     const bool is_leaf = lj < nl;
     t[r] = is_leaf ? (int)leaf_t[j] : 0;
     base[r] = is_leaf ? leaf_base[j] : 0u;
-    code[r] = is_leaf ? leaf_code[j] : 0ull;
+    if (is_leaf) code[r] = leaf_code_at(j); else code_make(code[r], 0ull, 0u);
     ls[r] = is_leaf ? leaf_start[j] : 0u;
     le[r] = is_leaf ? leaf_start[j + 1] : 0u;
   }
   // the points of this tile's leaves are one contiguous run of the sorted arrays: their colour words are staged in LDS
   const uint32_t run0 = nl ? leaf_start[pos0] : 0u;
   const uint32_t run1 = nl ? leaf_start[pos0 + nl] : 0u;
-  const uint64_t code0 = (nl && pos0) ? leaf_code[pos0] : 0ull;
+  CodeT code0;
+  if (nl && pos0) code0 = leaf_code_at(pos0); else code_make(code0, 0ull, 0u);
   for (int k = threadIdx.x; k < kOccWindow; k += kFinThreads) s_occ[k] = 0u;
   const bool staged = (colour_pay != nullptr || colour_keys != nullptr) && lp.do_color;
   const uint32_t ncol = staged ? min(run1 - run0, (uint32_t)kColourStage) : 0u;
@@ -1723,7 +1838,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
     }
   }
   PCC_KTR(7, 1);
-  if (probes_here) s_probe[lane] = probe_code;
+  if (probes_here) { s_probe[lane] = code_low(probe_code); if (DEEP) s_probe_hi[DEEP ? lane : 0] = code_high(probe_code); }
   __syncthreads();
   PCC_KTR(7, 2);
   // Parents that were opened before this tile: for every v the nearest earlier leaf f with t(f) >= v is
@@ -1740,17 +1855,19 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
       vtop = any ? 64 - __clzll((long long)any) : 1;  // largest t in the tile, + 1
     }
     for (int v = wave + 1; v <= min(D, vtop); v += kFinThreads / 64) {
-      const int sh = 3 * v;
-      const uint64_t pcode = sh >= 64 ? 0ull : ((code0 >> sh) << sh);
+      const CodeT pcode = code_clear_low(code0, v);
       // invariant: the answer (first leaf with code >= pcode) lies in [lo, hi]; leaf hi has code >= pcode
       uint32_t lo = 0, hi = pos0;
       bool first_round = true;
       while (hi - lo > 255u) {
         const uint32_t step = (hi - lo + 63u) / 64u;
         const uint32_t probe = lo + (uint32_t)lane * step;
-        const uint64_t pc = first_round ? s_probe[lane] : (probe < hi ? leaf_code[probe] : ~0ull);
+        CodeT pc;
+        if (first_round) code_make(pc, s_probe[lane], DEEP ? s_probe_hi[DEEP ? lane : 0] : 0u);
+        else if (probe < hi) pc = leaf_code_at(probe);
+        else code_make(pc, ~0ull, ~0u);
         first_round = false;
-        const bool less = probe < hi && pc < pcode;
+        const bool less = probe < hi && code_lt(pc, pcode);
         const int cnt = __popcll(__ballot(less));  // the probes are ascending, so `less` holds for a prefix of the lanes
         if (cnt == 0) {
           hi = lo;
@@ -1765,10 +1882,11 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
       for (int k = 0; k < 4; ++k) {
         const uint32_t i = lo + 4u * (uint32_t)lane + (uint32_t)k;
         const bool in = i <= hi;
-        const uint64_t c = in ? leaf_code[i] : ~0ull;
+        CodeT c;
+        if (in) c = leaf_code_at(i); else code_make(c, ~0ull, ~0u);
         fb[k] = in ? leaf_base[i] : 0u;
         ft[k] = in ? (uint32_t)leaf_t[i] : 0u;
-        below += (uint32_t)__popcll(__ballot(i < hi && c < pcode));
+        below += (uint32_t)__popcll(__ballot(i < hi && code_lt(c, pcode)));
       }
       const uint32_t at = below;  // answer = lo + below
 #pragma unroll
@@ -1791,7 +1909,11 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   PCC_KTR(5, 1);
   const uint32_t seg0 = nl ? (s_base[0] & ~3u) : 0u;  // dword-aligned start of the tile's piece of the DFS stream
   const uint32_t seg1 = nl ? s_base[nl - 1] + s_t[nl - 1] : 0u;
-  const uint64_t pfx = morton3(st->prefix[0], st->prefix[1], st->prefix[2]);
+  CodeT pfx;
+  {
+    const uint32_t pk[3] = {st->prefix[0], st->prefix[1], st->prefix[2]};
+    code_of_keys(pfx, pk);
+  }
 
   // ---- A2: per leaf ----
 #pragma unroll
@@ -1804,8 +1926,8 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
       }
       continue;
     }
-    const uint64_t fullcode = code[r] | pfx;
-    const uint32_t key[3] = {compact3(fullcode >> 2), compact3(fullcode >> 1), compact3(fullcode)};
+    const CodeT fullcode = code_or(code[r], pfx);
+    const uint32_t key[3] = {code_axis(fullcode, 0), code_axis(fullcode, 1), code_axis(fullcode, 2)};
     uint32_t cb = 0, cg = 0, cr = 0;
     if (lp.do_color) {
       if (staged && le[r] - run0 <= (uint32_t)kColourStage) {  // the usual case: sum straight out of LDS
@@ -1870,14 +1992,14 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
     const int tt = t[r];
     for (int q = 0; q < tt; ++q) {
       const int level = D - tt + q;
-      const uint32_t child = (uint32_t)(fullcode >> (3 * (D - 1 - level))) & 7u;
+      const uint32_t child = code_triple(fullcode, D - 1 - level);
       const uint32_t lo = base[r] + (uint32_t)q - seg0;
       if ((lo >> 2) < (uint32_t)kOccWindow) atomicOr(&s_occ[lo >> 2], (1u << child) << (8u * (lo & 3u)));
       else or_byte(occ, base[r] + (uint32_t)q, 1u << child);
     }
     if (j > 0) {
       const int v = tt + 1;  // t < D for every leaf but the first
-      const uint32_t child = (uint32_t)(fullcode >> (3 * tt)) & 7u;
+      const uint32_t child = code_triple(fullcode, tt);
       int fl = -1;
       uint64_t mk = s_mask[slot * kMaskStride + v] & (lane ? (~0ull >> (64 - lane)) : 0ull);
       if (mk) {
@@ -2433,11 +2555,13 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_boxes_events", (const void*)k_boxes_events, kBlock);
   one("k_make_keys<4>", (const void*)k_make_keys<4>, kKeyThreads);
   one("k_make_keys<2>", (const void*)k_make_keys<2>, kKeyThreads);
-  one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems>, kSortThreads);
-  one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8>, 512);
-  one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems>, kSortThreads);
-  one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8>, 512);
-  one("k_leaf_tile", (const void*)k_leaf_tile, kFinThreads);
+  one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems, false>, kSortThreads);
+  one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8, false>, 512);
+  one("k_sort_pass<512,8,deep>", (const void*)k_sort_pass<512, 8, true>, 512);
+  one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems, false>, kSortThreads);
+  one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8, false>, 512);
+  one("k_leaf_tile", (const void*)k_leaf_tile<false>, kFinThreads);
+  one("k_leaf_tile<deep>", (const void*)k_leaf_tile<true>, kFinThreads);
   one("k_jpeg_rows", (const void*)k_jpeg_rows, kJpegThreads);
   one("k_occ_histogram", (const void*)k_occ_histogram, 256);
   if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
@@ -2470,20 +2594,21 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   // Fused mode (frames of up to kFusedMaxChunks chunks): the streaming workgroups of k_boxes_events hold their points in
   // registers until workgroup 0 has published the sort plan, then write keys and digit counts themselves -- the cloud is
   // read once -- and k_make_keys only visits the chunks that were left alone (normally chunk 0, where the box grows).
-  const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks;
+  const bool deep = a.deep_launch != 0;  // the DEEP instantiations (two-word codes): a frame deeper than 21 levels came by
+  const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks && !deep;
   FusedKeys fk{};
   if (fused) {
     fk.plan = a.plan; fk.keys = a.keys_a; fk.idx = a.idx_a; fk.hist_rows = a.hist_rows;
     fk.inv_res_pow2 = a.inv_res_pow2; fk.plan_spins = a.plan_spins; fk.do_color = (int)a.lp.do_color;
   }
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
+                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   if (fused)
-    hipLaunchKernelGGL(k_make_keys<2>, dim3(n_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows,
+    hipLaunchKernelGGL(k_make_keys<2>, dim3(n_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
                        a.plan + kPlanGranules, a.frame_seq, span("k_make_keys"));
   else
-    hipLaunchKernelGGL(k_make_keys<4>, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.hist_rows,
+    hipLaunchKernelGGL(k_make_keys<4>, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
                        (const uint64_t*)nullptr, 0u, span("k_make_keys"));
   PCC_STAMP("k_make_keys");
   {
@@ -2502,30 +2627,32 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
     return !e ? 0 : (!strcmp(e, "narrow") ? 1 : (!strcmp(e, "wide") ? 2 : 0));
   }();
   const bool many_tiles = forced_shape ? forced_shape == 1 : s_tiles > kSortSmallGridTiles;
+#define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass")
   for (int pass = 0; pass < passes; ++pass) {
-    if (many_tiles)
-      hipLaunchKernelGGL((k_sort_pass<512, 8>), dim3(s_tiles), dim3(512), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
-                         n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass"));
-    else
-      hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
-                         n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass"));
+    if (many_tiles && deep) hipLaunchKernelGGL((k_sort_pass<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
+    else if (many_tiles) hipLaunchKernelGGL((k_sort_pass<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
+    else if (deep) hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems, true>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SORT_ARGS);
+    else hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems, false>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SORT_ARGS);
     PCC_STAMP("k_sort_pass");
   }
-  if (many_tiles)
-    hipLaunchKernelGGL((k_leaf_scan<512, 8>), dim3(s_tiles), dim3(512), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
-                       a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
-  else
-    hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.keys_a, a.keys_b, a.state, leaf_status, tickets + kMaxPasses,
-                       a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan"));
+#undef PCC_SORT_ARGS
+#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
+  if (many_tiles && deep) hipLaunchKernelGGL((k_leaf_scan<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
+  else if (many_tiles) hipLaunchKernelGGL((k_leaf_scan<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
+  else if (deep) hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems, true>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SCAN_ARGS);
+  else hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems, false>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SCAN_ARGS);
+#undef PCC_SCAN_ARGS
   PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   static const bool linear_rows = [] { const char* e = getenv("PCC_LEAF_ROWS"); return e && !strcmp(e, "linear"); }();
   LeafParams lp = a.lp;
   lp.linear_rows = linear_rows ? 1u : 0u;
-  hipLaunchKernelGGL(k_leaf_tile, dim3(((max_h + 7u) / 8u + 7u) / 8u * 8u), dim3(kFinThreads), 0, stream, a.pv, a.res, lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b,
-                     a.state, a.leaf_start, a.leaf_code, a.leaf_base, a.leaf_t, a.occ, a.bgr, a.centroid, a.image,
-                     reinterpret_cast<float4*>(a.simplified), span("k_leaf_tile"));
+#define PCC_TILE_ARGS a.pv, a.res, lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, a.state, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, \
+                      a.occ, a.bgr, a.centroid, a.image, reinterpret_cast<float4*>(a.simplified), span("k_leaf_tile")
+  if (deep) hipLaunchKernelGGL(k_leaf_tile<true>, dim3(((max_h + 7u) / 8u + 7u) / 8u * 8u), dim3(kFinThreads), 0, stream, PCC_TILE_ARGS);
+  else hipLaunchKernelGGL(k_leaf_tile<false>, dim3(((max_h + 7u) / 8u + 7u) / 8u * 8u), dim3(kFinThreads), 0, stream, PCC_TILE_ARGS);
+#undef PCC_TILE_ARGS
   PCC_STAMP("k_leaf_tile");
   // B is only known on the device: enough workgroups for the worst usual case (a few bytes per point), at least 64 x 256 threads
   const uint32_t hist_wgs = std::min(1024u, std::max(64u, (n + 16383u) / 16384u));

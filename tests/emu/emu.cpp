@@ -328,8 +328,14 @@ struct Pool {
 
   void worker_main(bool helper) {
     Worker* w = new Worker();
-    w->stacks = (char*)mmap(nullptr, kStackBytes * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (w->stacks == MAP_FAILED) { perror("mmap"); abort(); }
+    size_t stack_lanes = 0;  // the lanes' stacks: address space for as many as the largest workgroup this thread has run
+    auto stacks_for = [&](size_t lanes) {
+      if (lanes <= stack_lanes) return;
+      if (w->stacks) munmap(w->stacks, kStackBytes * stack_lanes);
+      w->stacks = (char*)mmap(nullptr, kStackBytes * lanes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (w->stacks == MAP_FAILED) { perror("wave64 executor: mmap of the lanes' stacks"); abort(); }
+      stack_lanes = lanes;
+    };
     tl_worker = w;
     uint64_t seen = 0;
     bool first = true;
@@ -360,6 +366,7 @@ struct Pool {
         if (bi >= total) break;
         w->block_linear = bi;
         w->nthreads = (int)(b.x * b.y * b.z);
+        stacks_for((size_t)w->nthreads);
         blockDim = {b.x, b.y, b.z};
         gridDim = {g.x, g.y, g.z};
         blockIdx.x = bi % g.x; blockIdx.y = (bi / g.x) % g.y; blockIdx.z = bi / (g.x * g.y);

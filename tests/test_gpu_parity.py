@@ -147,6 +147,52 @@ def test_large_coordinates_and_deep_tree(pkg, oracle, ctx):
     assert hot.depth >= 15
 
 
+@pytest.mark.parametrize("bits,kw", [
+    (22, dict()),                                        # the first depth past the single-word codes (63 Morton bits)
+    (24, dict(keep_centroid=1)),                         # point index in the second payload, colours through it
+    (27, dict(color_bits=0)),                            # geometry only: no second payload at all
+    (29, dict(color_coding_type=2, jpeg_quality=75)),    # depth 31: every triple of the high word in use
+    (23, dict(color_coding_type=0, color_bits=6, keep_centroid=1)),
+])
+def test_trees_of_22_to_31_levels(pkg, oracle, ctx, bits, kw):
+    """OctreePointCloud allows 32 levels; Morton codes of more than 21 levels do not fit one 64-bit sort key.  Such
+    frames run the kernels' DEEP instantiations (two-word codes: the 21 low triples are the sort key, the triples above
+    its payload, index or colour ride in a second payload): same bytes as the oracle's pointer octree.  The device sends
+    the first deep frame back (kErrDeep), the host enqueues the deep kernels and keeps doing so until a shallow frame
+    comes by -- both transitions are part of the test, as are a sorted cloud (growth events all over it), non-finite
+    points and a cloud of more than one sort tile per look-back group."""
+    rng = np.random.default_rng(bits)
+    scale = 4096.0
+    res = scale * 2.0 ** -bits
+    n = 70_000 if bits == 27 else 9_000
+    xyz = rng.uniform(0.1, 0.9, (n, 3)) * scale
+    pts = cloud(pkg, xyz, seed=bits)
+    kw = dict(octree_resolution=res, point_resolution=res, **kw)
+    hot, want = assert_matches_oracle(pkg, oracle, ctx, pts, **kw)
+    assert hot.depth == want.depth and 22 <= hot.depth <= 31
+    if hot.depth <= 29:   # (in another order the same cloud's box may end two levels deeper, and 31 is the end: PCL's own
+        # growth arithmetic -- 1 << depth -- is undefined beyond it, and the oracle restates PCL)
+        srt = pts[np.argsort(pts["x"], kind="stable")].copy()
+        srt["z"][::11] = np.nan
+        hot, want = assert_matches_oracle(pkg, oracle, ctx, srt, **kw)                  # still deep: enqueued directly
+    shallow = cloud(pkg, rng.uniform(0.2, 0.8, (5_000, 3)), seed=1)
+    hot, want = assert_matches_oracle(pkg, oracle, ctx, shallow, octree_bits=9)          # deep kernels, shallow frame
+    assert hot.depth <= 21
+    hot, want = assert_matches_oracle(pkg, oracle, ctx, shallow, octree_bits=9)          # back on the single-word kernels
+    # the decoders: the host walk handles any depth (the GPU half is for trees of up to 21 levels and falls back)
+    stream = oracle.encode_intra(pts, oracle.make_params(frame_id=5, **kw)).bitstream
+    ref = oracle.decode_intra(stream).points
+    got, info = ctx.decode_intra(stream, on_gpu=True)
+    assert info["consumed"] == len(stream) and got.tobytes() == ref.tobytes()
+
+
+def test_a_tree_of_32_levels_is_refused(pkg, ctx):
+    """Two points 2^31 voxels apart: the box would need 32 levels (PCL's growth itself stops at 31)."""
+    pts = cloud(pkg, np.array([[0.0, 0.0, 0.0], [3.0e9, 1.0, 1.0]]), seed=3)
+    with pytest.raises(pkg.binding.PccError):
+        ctx.encode_intra_host(pts, pkg.binding.make_params(octree_resolution=1.0, point_resolution=1.0))
+
+
 def test_unaligned_stride_and_colour_offset(pkg, oracle, ctx):
     """pcc_encode_* takes stride / rgb_offset: a packed 16-byte XYZ+RGBA layout must give the same frame."""
     pts = pkg.synthetic.sphere_shell(20000, 31)
@@ -829,8 +875,10 @@ def test_random_sweep(pkg, oracle, ctx, seed):
         with pytest.raises(pkg.binding.PccError):
             ctx.encode_intra_host(pts, pkg.binding.make_params(**kw))
         return
-    if want.depth > 21:
-        pytest.skip("deeper than the 63-bit Morton limit (documented)")
+    if want.depth > 31:   # (PCL's own box growth stops there; the two-word codes hold 31 levels)
+        with pytest.raises(pkg.binding.PccError):
+            ctx.encode_intra_host(pts, pkg.binding.make_params(**kw))
+        return
     assert_matches_oracle(pkg, oracle, ctx, pts, **kw)
     # ... and back: the decoder with its data-parallel half on the GPU gives the oracle's cloud
     ref = oracle.decode_intra(want.bitstream).points
