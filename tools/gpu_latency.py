@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Single-context, one-frame-at-a-time GPU latency of the hot path (no host entropy stage, no
 concurrency): HIP-event time from the first to the last kernel, and per-kernel event times.
-    python tools/gpu_latency.py [workload] [frames]"""
+    python tools/gpu_latency.py [workload] [frames] [distinct frames]
+With `distinct frames` > 1 that many different frames (frame 0, 1, ...) sit in HBM and take turns: twelve 1 M-point frames
+are 384 MB, more than the 256 MB Infinity Cache, so that a PMC traffic figure taken over this tool is HBM traffic and not
+cache hits (one frame alone is re-read from the Infinity Cache from the second iteration on)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,12 +17,14 @@ pkg = G.load_package()
 b, syn = pkg.binding, pkg.synthetic
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+DISTINCT = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cfg = syn.CONFIGS[wl]
 p = b.make_params(octree_bits=cfg["octree_bits"], color_bits=cfg["color_bits"], color_coding_type=cfg["color_coding_type"],
                   jpeg_quality=cfg["jpeg_quality"], keep_centroid=cfg["keep_centroid"])
 ctx = b.Context(0)
-pts = syn.make_frame(wl)
-dev = ctx.upload(pts)
+frames = [syn.make_frame(wl, frame=f) for f in range(DISTINCT)]
+devs = [ctx.upload(f) for f in frames]
+pts, dev = frames[0], devs[0]
 n = len(pts)
 # parity line first: the frame that is about to be timed, with host copies and its bitstream, against the oracle's digests
 ctx.hotpath_launch(dev, n, p)
@@ -35,10 +40,10 @@ for prof in (0, 1, 2):   # 0 unprofiled, 1 HIP events between the launches + spa
     agg, spans = {}, {}
     for k in range(K + 3):
         t = time.perf_counter()
-        ctx.hotpath_launch(dev, n, p)
+        ctx.hotpath_launch(devs[k % DISTINCT], len(frames[k % DISTINCT]), p)
         hot = ctx.hotpath_finish(copy=False)
         w = time.perf_counter() - t
-        check_frame(wl, 0, hot)   # L, B, D and the bounding box of EVERY timed frame (no host copies in the timed loop)
+        check_frame(wl, k % DISTINCT, hot)   # L, B, D and the bounding box of EVERY timed frame (no host copies in the timed loop)
         if k >= 3:
             ms.append(hot.gpu_ms); wall.append(w * 1e3)
             if prof:

@@ -1,0 +1,39 @@
+#!/bin/bash
+# One GPU-box session of round 3, ordered so that whatever time the box gives is spent on the most important evidence first:
+#   1 parity: the whole -m gpu suite + smoke at HEAD (nothing else counts without it)
+#   2 bench lines: the driver's step count, the default, cfg4
+#   3 A/B of what round 3 built blind: fused keys on/off (latency + saturated GPU stage, parity for both), the shfl build
+#   4 single-stream rocprofv3 kernel traces + PMC traffic, cfg2 and cfg4, and cfg2 with 12 distinct frames (HBM, not the
+#     Infinity Cache)
+#   5 rocprofv3 kernel stats of the bench command itself; device range coder speed
+# Usage (through gpurun): bash tools/r03_round.sh <tag> [quick]      -> gpurun_out/<tag>/ ; copy the summaries to profiles/
+TAG=${1:-r03}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -3 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as G; G.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; echo "bench(20) rc=$?"; cat $OUT/bench_steps20.json
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
+python bench.py --workload cfg4 --steps 48 --warmup 4 --no-host-input > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; echo "bench(cfg4) rc=$?"; cat $OUT/bench_cfg4.json
+[ "$2" == "quick" ] && exit 0
+# ---- A/B: fused keys (the parity subset runs for both settings inside ab_probe)
+bash tools/ab_probe.sh $TAG/ab_fused PCC_FUSED_KEYS 1 0 cfg2 > $OUT/ab_fused.txt 2>&1; tail -40 $OUT/ab_fused.txt
+# ---- the shfl build of the wave helpers against the DPP one
+if [ -f cwi-pcl-codec_amd/libpcc_hip_shfl.so ]; then
+  bash tools/ab_probe.sh $TAG/ab_shfl PCC_LIB $PWD/cwi-pcl-codec_amd/libpcc_hip.so $PWD/cwi-pcl-codec_amd/libpcc_hip_shfl.so cfg2 > $OUT/ab_shfl.txt 2>&1; tail -24 $OUT/ab_shfl.txt
+fi
+# ---- single-stream kernel traces and HBM traffic
+for WL in cfg2 cfg4; do
+  bash tools/prof_latency.sh $TAG/lat_$WL $WL > $OUT/latency_$WL.txt 2>&1; tail -16 $OUT/latency_$WL.txt
+  bash tools/pmc_run.sh $TAG/pmc_$WL $WL > $OUT/pmc_$WL.log 2>&1; tail -3 $OUT/pmc_$WL.log
+done
+PCC_FUSED_KEYS=0 bash tools/pmc_run.sh $TAG/pmc_cfg2_two_kernels cfg2 > $OUT/pmc_cfg2_two_kernels.log 2>&1; tail -3 $OUT/pmc_cfg2_two_kernels.log
+PMC_DISTINCT=12 bash tools/pmc_run.sh $TAG/pmc_cfg2_12frames cfg2 > $OUT/pmc_cfg2_12frames.log 2>&1; tail -3 $OUT/pmc_cfg2_12frames.log
+# ---- the bench command under the kernel tracer; the device range coder
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-input --steps 256 > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err)
+DB=$(find $OUT/prof -name '*.db' | head -1)
+[ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/bench_kernel_stats.txt && cat $OUT/bench_kernel_stats.txt
+python tools/rc_device_speed.py > $OUT/rc_device_speed.txt 2>&1; tail -5 $OUT/rc_device_speed.txt
+find $OUT -name '*.db' -size +20M -delete
