@@ -65,6 +65,23 @@ def test_the_shfl_build_agrees(emu_libs):
     assert passed >= 100, tail
 
 
+def test_bench_script_runs_end_to_end_on_the_executor(emu_libs):
+    """Not a measurement (the numbers are the CPU's): every line of bench.py -- timed region, serialised roofline leg, host
+    legs including the packed one, entropy-stage report, CPU baseline -- has run before a GPU session depends on it."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(EMU, "bench_on_executor.py"), "--workload", "cfg1", "--steps", "3", "--warmup", "1",
+                        "--cpu-frames", "1"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "host_input", "entropy_stage"):
+        assert key in line, key
+    assert line["roofline"]["kernel"] == "k_sort_pass" and line["roofline"]["bound"] == "hbm"
+    assert line["entropy_stage"]["ran_on"] in ("host", "gpu")
+    assert "e2e_from_host_packed_16B_mpoints_per_s" in line["host_input"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+
+
 def test_product_library_has_no_cpu_fallback(pkg):
     """The library the product loads (libpcc_hip.so) refuses to work without a HIP device; the executor is only ever
     reached through an explicit PCC_LIB."""
