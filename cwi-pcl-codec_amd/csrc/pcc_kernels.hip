@@ -228,6 +228,14 @@ __device__ __forceinline__ uint64_t poll_u64(const uint64_t* p) {
 #else
 #define PCC_WAVE_LOCKSTEP() do { } while (0)
 #endif
+// The same between an LDS write of one lane and an LDS read of ANOTHER address by another lane of the wave: the hardware
+// keeps a wave's LDS operations in order, but to the compiler the two accesses of one thread are unrelated and may be
+// swapped -- a wavefront-scope fence and a wave barrier (no instruction beyond a wait for the LDS counter) forbid that.
+#ifdef PCC_EMU
+#define PCC_WAVE_SYNC_LDS() emu::wave_barrier()
+#else
+#define PCC_WAVE_SYNC_LDS() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 
 #ifdef PCC_KTIME  // developer build only: phase time stamps of k_sort_pass (shader clock), read by tools/ktime.py
 __device__ unsigned long long g_ktime[(7 + 2) * 1024 * 8];
@@ -944,7 +952,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         const unsigned nc = cdim[0] * cdim[1] * cdim[2];
         s_rank8[p] = ((unsigned)p < nc && nc > 1u) ? st_rank_of_lane : (uint8_t)0;
       }
-      PCC_WAVE_LOCKSTEP();
+      PCC_WAVE_SYNC_LDS();
 #define PCC_PICK3(arr, k) ((k) == 0 ? (arr)[0] : ((k) == 1 ? (arr)[1] : (arr)[2]))  /* (no indexed register arrays) */
       uint32_t v = 0u;
       if (p < 6) {
