@@ -32,6 +32,7 @@ struct LeafParams {
   uint32_t write_image;      // colour coding type 1: emit the snake-mapped 256 x H image
   uint32_t simplify_only;    // simplifyPCloud (impl.hpp:318-403): only the simplified cloud, centre = (key + 0.5) * res + min
   uint32_t linear_rows;      // developer knob (PCC_LEAF_ROWS=linear): block row = blockIdx instead of the per-XCD ranges of k_leaf_tile
+  uint32_t uniform_probes;   // developer knob (PCC_LEAF_PROBES=uniform): evenly spaced first probes of the parent search (round 2's layout)
 };
 
 // Quantiser of the JPEG front end: per component (0 luma, 1 chroma), natural order:

@@ -1726,6 +1726,25 @@ constexpr int kColourStage = 2560;                     // colour words staged in
 
 // (second launch bound: six waves per SIMD, i.e. three of these workgroups per CU -- the kernel spends two thirds of its
 // time waiting for its leaf records and for the parent search, and only other workgroups can fill that)
+// First probes of the parent search: distances back from the tile's first leaf that grow geometrically (ratio 2^(30/63): 64
+// probes reach 2^30 leaves back).  The ancestor of height v of the tile's first leaf was opened some 4^v leaves earlier (a
+// surface), so for all but the one or two highest levels the answer lies between two probes a few hundred leaves apart,
+// inside leaf records the previous block rows of the same XCD have just read; evenly spaced probes (round 2's layout,
+// PCC_LEAF_PROBES=uniform) send every level into a second round of 64 cold lines of its own.
+__device__ const uint32_t kGeoBack[64] = {
+    1u, 2u, 2u, 3u, 4u, 6u, 8u, 11u,
+    15u, 20u, 28u, 38u, 53u, 74u, 102u, 142u,
+    197u, 274u, 381u, 530u, 737u, 1024u, 1425u, 1982u,
+    2757u, 3835u, 5334u, 7420u, 10322u, 14358u, 19973u, 27783u,
+    38648u, 53762u, 74786u, 104032u, 144716u, 201309u, 280034u, 389545u,
+    541882u, 753794u, 1048576u, 1458639u, 2029062u, 2822558u, 3926363u, 5461828u,
+    7597761u, 10568984u, 14702150u, 20451656u, 28449595u, 39575254u, 55051774u, 76580630u,
+    106528682u, 148188387u, 206139769u, 286753946u, 398893555u, 554887110u, 771884381u, 1073741824u};
+__device__ __forceinline__ uint32_t geo_probe(int l, uint32_t pos0) {  // ascending in l; probe 0 is leaf 0 (pos0 < 2^30)
+  const uint32_t off = kGeoBack[63 - l];
+  return pos0 > off ? pos0 - off : 0u;
+}
+
 // (DEEP: trees of 22 to 31 levels, two-word codes: per-level tables for 31 levels, the codes' high words beside the low
 // ones, point index or colour word from the sort's second payload)
 template <bool DEEP>
@@ -1795,7 +1814,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   code_make(probe_code, ~0ull, ~0u);
   const bool probes_here = wave == kFinThreads / 64 - 1 && nl && pos0 > 255u;
   if (probes_here) {
-    const uint32_t step = (pos0 + 63u) / 64u, probe = (uint32_t)lane * step;
+    const uint32_t step = (pos0 + 63u) / 64u, probe = lp.uniform_probes ? (uint32_t)lane * step : geo_probe(lane, pos0);
     if (probe < pos0) probe_code = leaf_code_at(probe);
   }
   // every load that does not depend on another one is requested first (leaf records of all four rounds, the ends of
@@ -1866,7 +1885,18 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
       const CodeT pcode = code_clear_low(code0, v);
       // invariant: the answer (first leaf with code >= pcode) lies in [lo, hi]; leaf hi has code >= pcode
       uint32_t lo = 0, hi = pos0;
-      bool first_round = true;
+      if (pos0 > 255u && !lp.uniform_probes) {  // first round: the shared, geometrically spaced probes (s_probe)
+        CodeT pc;
+        code_make(pc, s_probe[lane], DEEP ? s_probe_hi[DEEP ? lane : 0] : 0u);
+        const int cnt = __popcll(__ballot(geo_probe(lane, pos0) < pos0 && code_lt(pc, pcode)));  // ascending probes: a prefix of the lanes
+        if (cnt == 0) {
+          hi = 0u;  // probe 0 is leaf 0
+        } else {
+          lo = geo_probe(cnt - 1, pos0) + 1u;
+          if (cnt < 64) hi = geo_probe(cnt, pos0);
+        }
+      }
+      bool first_round = lp.uniform_probes != 0u;
       while (hi - lo > 255u) {
         const uint32_t step = (hi - lo + 63u) / 64u;
         const uint32_t probe = lo + (uint32_t)lane * step;
@@ -2654,8 +2684,10 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
   static const bool linear_rows = [] { const char* e = getenv("PCC_LEAF_ROWS"); return e && !strcmp(e, "linear"); }();
+  static const bool uniform_probes = [] { const char* e = getenv("PCC_LEAF_PROBES"); return e && !strcmp(e, "uniform"); }();
   LeafParams lp = a.lp;
   lp.linear_rows = linear_rows ? 1u : 0u;
+  lp.uniform_probes = uniform_probes ? 1u : 0u;
 #define PCC_TILE_ARGS a.pv, a.res, lp, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, a.state, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, \
                       a.occ, a.bgr, a.centroid, a.image, reinterpret_cast<float4*>(a.simplified), span("k_leaf_tile")
   if (deep) hipLaunchKernelGGL(k_leaf_tile<true>, dim3(((max_h + 7u) / 8u + 7u) / 8u * 8u), dim3(kFinThreads), 0, stream, PCC_TILE_ARGS);

@@ -434,15 +434,16 @@ def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypa
         assert seen_fused > 100 and seen_fallback >= 3   # most chunks fused; chunks that hold earlier epochs are not
 
 
-@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "0"}, {"PCC_PLAN_SPINS": "1"}])
+@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "0"}, {"PCC_PLAN_SPINS": "1"}, {"PCC_LEAF_PROBES": "uniform"}])
 def test_two_kernel_form_and_plan_timeouts_give_the_same_bytes(env):
-    """The same clouds with fused mode switched off, and with every wait for the plan running out (all chunks fall back to
-    k_make_keys): child processes, because the switches are read once."""
+    """The same clouds with fused mode switched off, with every wait for the plan running out (all chunks fall back to
+    k_make_keys), and with the parent search of k_leaf_tile on evenly spaced first probes (round 2's layout; the default
+    spaces them geometrically back from the tile): child processes, because the switches are read once."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points"],
+                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points or cfg3_capture"],
                        cwd=root, env=e, capture_output=True, text=True, timeout=1800)
     # with the mode off / all chunks timing out the fused-chunk counters of the first test do not hold: it is told so
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
