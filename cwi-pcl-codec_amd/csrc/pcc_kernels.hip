@@ -996,11 +996,11 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
 // (1024 threads x 4 points; 512 x 8 was tried for the sake of frames in flight -- a smaller workgroup finds room on a
 // busy CU sooner, which took k_digit_totals from 22 to 14 us under load -- but here it lost both ways: 15.4 -> 18.9 us
 // alone, 38.6 -> 41.9 us under load)
-// KEY_ITEMS = 4: one row of digit counts per 4096-key sort tile (the kernel makes every key of the frame);
-// KEY_ITEMS = 2: one row per 2048-point chunk, and the kernel only visits the chunks the streaming workgroups of
-// k_boxes_events left alone (fused mode: `chunk_state` = the per-chunk granules behind the plan)
-constexpr int kKeyThreads = kSortThreads;
-template <int KEY_ITEMS>
+// <1024, 4>: one row of digit counts per 4096-key sort tile (the kernel makes every key of the frame);
+// <256, 8>: one row per 2048-point chunk, and the kernel only visits the chunks the streaming workgroups of
+// k_boxes_events left alone (fused mode: `chunk_state` = the per-chunk granules behind the plan) -- nearly all of its
+// workgroups return at once, so they are small ones (four waves to dispatch instead of sixteen)
+template <int kKeyThreads, int KEY_ITEMS>
 __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
                                                             uint32_t* __restrict__ idx, uint32_t* __restrict__ idx2, uint32_t* __restrict__ hist_rows,
@@ -2591,8 +2591,8 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
     out += line;
   };
   one("k_boxes_events", (const void*)k_boxes_events, kBlock);
-  one("k_make_keys<4>", (const void*)k_make_keys<4>, kKeyThreads);
-  one("k_make_keys<2>", (const void*)k_make_keys<2>, kKeyThreads);
+  one("k_make_keys<1024,4>", (const void*)k_make_keys<kSortThreads, kSortItems>, kSortThreads);
+  one("k_make_keys<256,8>", (const void*)k_make_keys<kBlock, kItems>, kBlock);
   one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems, false>, kSortThreads);
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8, false>, 512);
   one("k_sort_pass<512,8,deep>", (const void*)k_sort_pass<512, 8, true>, 512);
@@ -2643,10 +2643,10 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   if (fused)
-    hipLaunchKernelGGL(k_make_keys<2>, dim3(n_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
+    hipLaunchKernelGGL((k_make_keys<kBlock, kItems>), dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
                        a.plan + kPlanGranules, a.frame_seq, span("k_make_keys"));
   else
-    hipLaunchKernelGGL(k_make_keys<4>, dim3(s_tiles), dim3(kKeyThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
+    hipLaunchKernelGGL((k_make_keys<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
                        (const uint64_t*)nullptr, 0u, span("k_make_keys"));
   PCC_STAMP("k_make_keys");
   {
