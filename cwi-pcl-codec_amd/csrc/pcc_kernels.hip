@@ -447,7 +447,16 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
   if (wave_id() == 0) {
     const int l = lane_id();
     bool got = false;
+    // Hundreds of workgroups wait here: while the plan is not there they all look at ONE word (the whole wave reads the same
+    // address: one request), and only sweep the granules once that one carries this frame's tag (the others follow
+    // within nanoseconds: they are stored by one instruction of one wave) -- polling traffic on the lines workgroup 0 is
+    // about to write is what would slow everybody down (guideline 16, pitfall 9).
+    bool first_seen = false;
     for (uint32_t spin = 0; spin < fk.plan_spins; ++spin) {
+      if (!first_seen) {
+        first_seen = (uint32_t)(poll_u64(fk.plan + kPlanFlags) >> 32) == seq;
+        if (!first_seen) { __builtin_amdgcn_s_sleep(32); continue; }
+      }
       const uint64_t w = l < kPlanWords ? poll_u64(fk.plan + l) : ((uint64_t)seq << 32);
       const bool there = (uint32_t)(w >> 32) == seq;
       if (__ballot(!there) == 0ull) {
@@ -455,7 +464,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
         got = true;
         break;
       }
-      __builtin_amdgcn_s_sleep(32);
+      __builtin_amdgcn_s_sleep(1);
     }
     if (l == 0) { s_plan[kPlanWords] = got ? 1u : 0u; s_plan[kPlanWords + 1] = 0u; }
   }
