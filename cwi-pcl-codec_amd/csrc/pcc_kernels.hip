@@ -2113,15 +2113,38 @@ __device__ __forceinline__ void occ_histogram_block(FrameState* __restrict__ st,
   const uint32_t vec = B / 16u;
   const uint4* v = reinterpret_cast<const uint4*>(occ);
   const int copy = threadIdx.x & 3;
+  // Most bytes of a deep tree's stream have ONE bit set (a node with a single child; 8 values take most of the counts of a
+  // sparse cloud's stream): LDS atomics on eight hot words serialise, four copies or not.  Those eight values are counted
+  // in a register instead -- eight 8-bit counters in one 64-bit word, emptied into LDS before one can overflow -- and
+  // only the other values go to LDS one by one.
+  uint64_t hot = 0ull;   // counter k (bits 8k .. 8k+7): bytes equal to 1 << k
+  uint32_t hot_n = 0u;   // bytes counted in `hot` since it was emptied (<= 255)
+  auto spill_hot = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t c = (uint32_t)(hot >> (8 * k)) & 0xffu;
+      if (c) atomicAdd(&s_h[copy][1u << k], c);
+    }
+    hot = 0ull; hot_n = 0u;
+  };
+  auto count = [&](uint32_t b) {
+    if (b != 0u && (b & (b - 1u)) == 0u) {
+      hot += 1ull << (8 * (__ffs((int)b) - 1));
+      ++hot_n;
+    } else {
+      atomicAdd(&s_h[copy][b], 1u);
+    }
+  };
   for (uint32_t i = wg * THREADS + threadIdx.x; i < vec; i += n_wgs * THREADS) {
     const uint4 q = v[i];
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    if (hot_n > 255u - 16u) spill_hot();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      atomicAdd(&s_h[copy][w[k] & 0xffu], 1u); atomicAdd(&s_h[copy][(w[k] >> 8) & 0xffu], 1u);
-      atomicAdd(&s_h[copy][(w[k] >> 16) & 0xffu], 1u); atomicAdd(&s_h[copy][w[k] >> 24], 1u);
+      count(w[k] & 0xffu); count((w[k] >> 8) & 0xffu); count((w[k] >> 16) & 0xffu); count(w[k] >> 24);
     }
   }
+  spill_hot();
   if (wg == 0)  // the tail
     for (uint32_t i = vec * 16u + threadIdx.x; i < B; i += THREADS) atomicAdd(&s_h[0][occ[i]], 1u);
   __syncthreads();
