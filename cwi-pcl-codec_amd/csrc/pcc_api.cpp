@@ -1222,7 +1222,7 @@ int pcc_decode_intra(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud*
 }
 
 // decodePointCloud (impl.hpp:224-310) with everything behind the sequential stages on the GPU.  Falls back to the
-// host decoder for what the kernels do not cover (trees deeper than 21 levels, inconsistent vector lengths of a
+// host decoder for what the kernels do not cover (trees deeper than 31 levels, inconsistent vector lengths of a
 // corrupt stream): same results either way.
 int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cloud* out) {
   if (!ctx || !out || (!stream && len)) return PCC_ERR_ARG;
@@ -1244,7 +1244,7 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     const size_t L = (size_t)fs.count;
     int img_w = 0, img_h = 0;
     const bool jpeg = fs.with_color && fs.cct == 1;
-    if (out->depth > (uint32_t)kMaxDepth || L >= (1ull << 31) || L == 0) host_only = true;
+    if (out->depth > (uint32_t)kMaxDepthDeep || L >= (1ull << 31) || L == 0) host_only = true;
     if (!host_only && out->params.do_voxel_centroid && fs.cen.size() < 3 * L) host_only = true;
     if (!host_only && fs.with_color && !jpeg && fs.col.size() < 3 * L) host_only = true;
     // the JPEG's Huffman decoding and the walk over the occupancy stream are both sequential, but not on each other:
@@ -1280,6 +1280,7 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     if (!host_only && rc != PCC_OK) return fail(ctx, rc, "decode: occupancy stream does not describe the announced number of voxels");
     if (!host_only && jpeg && (!jpeg_ok || img_w % 8 != 0 || (size_t)img_w * (size_t)img_h < L)) host_only = true;
     if (host_only) {
+      ctx->dec_ms[1] = 0.0;  // (pcc_get_decode_times: no GPU half this time)
       rc = decode_frame(stream, len, ctx->dec_points, *out);
       out->points = ctx->dec_points.data();
       out->n = ctx->dec_points.size();
@@ -1293,8 +1294,9 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     // one staging buffer, one upload
     const size_t np = lp.prefix.size();
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_prefix = 0, o_first = up16(o_prefix + 8 * np), o_bits = up16(o_first + 4 * np);
-    const size_t o_cen = up16(o_bits + np), n_cen = out->params.do_voxel_centroid ? 3 * L : 0;
+    const size_t n_hi = lp.prefix_hi.size() == np ? 4 * np : 0;  // two-word keys: trees of more than 22 levels
+    const size_t o_prefix = 0, o_first = up16(o_prefix + 8 * np), o_bits = up16(o_first + 4 * np), o_hi = up16(o_bits + np);
+    const size_t o_cen = up16(o_hi + n_hi), n_cen = out->params.do_voxel_centroid ? 3 * L : 0;
     const size_t o_col = up16(o_cen + n_cen), n_col = (fs.with_color && !jpeg) ? 3 * L : 0;
     const size_t o_coef = up16(o_col + n_col), n_coef = jpeg ? ctx->dec_coefs.blocks.size() * sizeof(int16_t) : 0;
     const size_t staged = up16(o_coef + n_coef);
@@ -1308,6 +1310,7 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
     memcpy(h + o_prefix, lp.prefix.data(), 8 * np);
     memcpy(h + o_first, lp.first.data(), 4 * np);
     memcpy(h + o_bits, lp.bits.data(), np);
+    if (n_hi) memcpy(h + o_hi, lp.prefix_hi.data(), n_hi);
     if (n_cen) memcpy(h + o_cen, fs.cen.data(), n_cen);
     if (n_col) memcpy(h + o_col, fs.col.data(), n_col);
     if (n_coef) memcpy(h + o_coef, ctx->dec_coefs.blocks.data(), n_coef);
@@ -1326,6 +1329,7 @@ int pcc_decode_intra_gpu(pcc_ctx* ctx, const uint8_t* stream, size_t len, pcc_cl
       da.y_stride = (uint32_t)(16 * mx); da.c_stride = (uint32_t)(8 * mx);
     }
     da.prefix = reinterpret_cast<const uint64_t*>(d + o_prefix);
+    da.prefix_hi = n_hi ? reinterpret_cast<const uint32_t*>(d + o_hi) : nullptr;
     da.first = reinterpret_cast<const uint32_t*>(d + o_first);
     da.bits = d + o_bits;
     da.n_parents = (uint32_t)np;

@@ -8,7 +8,8 @@ namespace pcc {
 
 struct DecodeArgs {
   // geometry: one entry per node of level D-1 ("leaf parent"), in stream order
-  const uint64_t* prefix;   // key of the node, 3 bits per level, x-major triples
+  const uint64_t* prefix;   // key of the node, 3 bits per level, x-major triples (the 21 low triples)
+  const uint32_t* prefix_hi;  // the triples above them, or null (trees of up to 22 levels)
   const uint8_t* bits;      // its occupancy byte
   const uint32_t* first;    // voxels before it
   uint32_t n_parents;

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void k_dec_points(DecodeArgs a) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= a.n_parents) return;
   const uint64_t prefix = a.prefix[t];
+  const uint32_t prefix_hi = a.prefix_hi ? a.prefix_hi[t] : 0u;
+  // the node's key per axis (x-major triples); a voxel's key is that, shifted up, plus its child bit
+  const uint32_t pk[3] = {compact3(prefix >> 2) | (compact3((uint64_t)prefix_hi >> 2) << 21), compact3(prefix >> 1) | (compact3((uint64_t)prefix_hi >> 1) << 21),
+                          compact3(prefix) | (compact3((uint64_t)prefix_hi) << 21)};
   uint32_t bits = a.bits[t];
   uint32_t leaf = a.first[t];
   const uint32_t cw = (a.img_w + 1u) / 2u, chh = (a.img_h + 1u) / 2u;
@@ -144,8 +148,7 @@ __global__ __launch_bounds__(256) void k_dec_points(DecodeArgs a) {
     const uint32_t c = (uint32_t)__ffs((int)bits) - 1u;
     bits &= bits - 1u;
     if (leaf >= a.n_leaves) return;  // (the host has checked the counts)
-    const uint64_t code = (prefix << 3) | c;
-    const uint32_t key[3] = {compact3(code >> 2), compact3(code >> 1), compact3(code)};
+    const uint32_t key[3] = {(pk[0] << 1) | ((c >> 2) & 1u), (pk[1] << 1) | ((c >> 1) & 1u), (pk[2] << 1) | (c & 1u)};
     float xyz[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {

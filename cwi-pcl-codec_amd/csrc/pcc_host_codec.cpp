@@ -1647,22 +1647,20 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
 // The leaf parents of the depth-first occupancy stream: a node of level D-1 has its voxels as children, so everything
 // a voxel needs is its parent's key, its parent's byte and how many voxels came before.  The walk is the sequential
 // part of deserializeTree (the level of a byte depends on every byte before it); it visits branch nodes only.
-int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents& lp) {
-  lp.prefix.clear(); lp.bits.clear(); lp.first.clear();
-  if (D == 0 || D > 21 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
-  if (count >= (1ull << 32)) return PCC_ERR_STREAM;  // `first` counts voxels in 32 bits (and B < 2^32 bytes cannot hold more)
-  {  // a level-(D-1) node holds at least one voxel and is one byte of the stream
-    const size_t most = (size_t)std::min<uint64_t>(count, occ.size());
-    lp.prefix.reserve(most); lp.bits.reserve(most); lp.first.reserve(most);
-  }
-  uint8_t rem[24];
+namespace {
+template <typename PrefixT>
+int walk_leaf_parents_t(const Bytes& occ, unsigned D, uint64_t count, LeafParents& lp) {
+  constexpr bool kWide = sizeof(PrefixT) > 8;
+  uint8_t rem[40];
   int sp = 0;
   size_t op = 0;
-  uint64_t prefix = 0, leaves = 0;
+  PrefixT prefix = 0;
+  uint64_t leaves = 0;
   rem[0] = occ[op++];
   while (sp >= 0) {
     if ((unsigned)sp == D - 1) {
-      lp.prefix.push_back(prefix);
+      lp.prefix.push_back((uint64_t)prefix & 0x7fffffffffffffffull);
+      if (kWide) lp.prefix_hi.push_back((uint32_t)(prefix >> 63));
       lp.bits.push_back(rem[sp]);
       lp.first.push_back((uint32_t)leaves);
       leaves += (uint64_t)__builtin_popcount(rem[sp]);
@@ -1674,10 +1672,24 @@ int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents&
     const int c = __builtin_ctz(rem[sp]);
     rem[sp] = (uint8_t)(rem[sp] & (rem[sp] - 1));
     if (op >= occ.size()) return PCC_ERR_STREAM;
-    prefix = (prefix << 3) | (uint64_t)c;
+    prefix = (prefix << 3) | (PrefixT)c;
     rem[++sp] = occ[op++];
   }
   return leaves == count ? PCC_OK : PCC_ERR_STREAM;
+}
+}  // namespace
+
+int walk_leaf_parents(const Bytes& occ, unsigned D, uint64_t count, LeafParents& lp) {
+  lp.prefix.clear(); lp.prefix_hi.clear(); lp.bits.clear(); lp.first.clear();
+  if (D == 0 || D > 31 || occ.empty()) return count == 0 ? PCC_OK : PCC_ERR_STREAM;
+  if (count >= (1ull << 32)) return PCC_ERR_STREAM;  // `first` counts voxels in 32 bits (and B < 2^32 bytes cannot hold more)
+  {  // a level-(D-1) node holds at least one voxel and is one byte of the stream
+    const size_t most = (size_t)std::min<uint64_t>(count, occ.size());
+    lp.prefix.reserve(most); lp.bits.reserve(most); lp.first.reserve(most);
+    if (D > 22) lp.prefix_hi.reserve(most);
+  }
+  // the key of a level-(D-1) node has 3 (D - 1) bits: one word up to 22 levels, two beyond
+  return D > 22 ? walk_leaf_parents_t<unsigned __int128>(occ, D, count, lp) : walk_leaf_parents_t<uint64_t>(occ, D, count, lp);
 }
 
 

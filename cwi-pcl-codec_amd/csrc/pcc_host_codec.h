@@ -112,7 +112,8 @@ struct FrameStreams {
 int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too,
                          const std::function<void()>& after_occupancy = std::function<void()>());
 struct LeafParents {             // per node of level D-1, in stream order:
-  std::vector<uint64_t> prefix;  //   its key, 3 bits per level, x-major triples
+  std::vector<uint64_t> prefix;  //   its key, 3 bits per level, x-major triples (the 21 low triples)
+  std::vector<uint32_t> prefix_hi;  // the triples above them: only filled for trees of more than 22 levels
   std::vector<uint8_t> bits;     //   its occupancy byte = which of its eight voxels exist
   std::vector<uint32_t> first;   //   how many voxels the nodes before it hold
 };

@@ -179,11 +179,14 @@ def test_trees_of_22_to_31_levels(pkg, oracle, ctx, bits, kw):
     hot, want = assert_matches_oracle(pkg, oracle, ctx, shallow, octree_bits=9)          # deep kernels, shallow frame
     assert hot.depth <= 21
     hot, want = assert_matches_oracle(pkg, oracle, ctx, shallow, octree_bits=9)          # back on the single-word kernels
-    # the decoders: the host walk handles any depth (the GPU half is for trees of up to 21 levels and falls back)
+    # the decoders: the host's walk handles any depth, and so does the GPU half (node keys of two words beyond 22 levels)
     stream = oracle.encode_intra(pts, oracle.make_params(frame_id=5, **kw)).bitstream
     ref = oracle.decode_intra(stream).points
     got, info = ctx.decode_intra(stream, on_gpu=True)
     assert info["consumed"] == len(stream) and got.tobytes() == ref.tobytes()
+    assert ctx.decode_times()["gpu_ms"] > 0      # (really on the GPU: the host fallback reports 0)
+    host, _ = ctx.decode_intra(stream)
+    assert host.tobytes() == ref.tobytes()
 
 
 def test_a_tree_of_32_levels_is_refused(pkg, ctx):
