@@ -1154,6 +1154,8 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
 // (second launch bound = waves per SIMD the register allocation has to leave room for: four, i.e. one 1024-thread or
 // two 512-thread workgroups per CU.  Without it the 512-thread shape takes 151 registers -- it is allowed 256 -- and
 // only one workgroup fits a CU, which is the whole point of that shape gone.)
+constexpr uint32_t kXcdTicketBase = 16;                           // tickets[16 + 8 pass + xcd]
+constexpr size_t kTicketBytes = (16 + 8 * kMaxPasses + 8) * sizeof(uint32_t) / 16 * 16 + 16;
 // (DEEP: two-word codes -- the u32 payload is the code's high word, whose digits the last passes sort by, and a second
 // payload array carries the point index or the colour word)
 template <int THREADS, int ITEMS, bool DEEP = false>
@@ -1163,7 +1165,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
                                                             const uint32_t* __restrict__ tile_prefix0,
                                                             uint32_t* status_all, uint32_t* tickets,
-                                                            uint32_t n_tiles_max, unsigned long long* span) {
+                                                            uint32_t n_tiles_max, int xcd_chunk, unsigned long long* span) {
   const KSpan kspan(span);
   PCC_KT(0);
   if (pass >= st->npasses) return;
@@ -1196,8 +1198,29 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   // one that cannot start because of workgroups waiting the other way round.)  Pass 0 waits for nobody -- its
   // tile prefixes come from k_digit_totals -- and keeps blockIdx.  The ticket, 245 workgroups queueing on one
   // word, takes a microsecond or two to come back: the digit totals are fetched meanwhile.
+  // XCD-aware tickets (xcd_chunk = tiles per chunk, 0 = off): consecutive tiles write adjacent runs of every digit, so two
+  // neighbours on the same XCD fill whole lines in ONE L2, while neighbours on different XCDs each write a partial line
+  // (workgroups go to the XCDs round robin: with one counter for everybody, neighbouring tiles never share an XCD).  Every
+  // XCD has a counter of its own and takes the tiles of every eighth chunk of `xcd_chunk` consecutive tiles, in ascending
+  // order; a workgroup whose XCD has no tile left takes one of another XCD's.  Which XCD a workgroup runs on is read from
+  // the hardware and is only a hint: whatever the register says, every tile is taken exactly once, and -- per-XCD
+  // tickets ascend -- the lowest tile not started yet is always somebody's next ticket, so a tile still only ever waits
+  // for tiles that can start.
   uint32_t ticket = blockIdx.x;
-  if (pass != 0 && threadIdx.x == 0) ticket = atomicAdd(&tickets[pass], 1u);
+  if (xcd_chunk > 0) {
+    if (threadIdx.x == 0) {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID
+      ticket = ~0u;
+      for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t y = (x + k) & 7u;
+        const uint32_t t = atomicAdd(&tickets[kXcdTicketBase + (uint32_t)pass * 8u + y], 1u);
+        const uint32_t cand = ((t / (uint32_t)xcd_chunk) * 8u + y) * (uint32_t)xcd_chunk + t % (uint32_t)xcd_chunk;
+        if (cand < n_tiles) { ticket = cand; break; }
+      }
+    }
+  } else if (pass != 0 && threadIdx.x == 0) {
+    ticket = atomicAdd(&tickets[pass], 1u);
+  }
   const uint32_t dtot = d_me < nbins ? digit_tot[(size_t)pass * kMaxBins + d_me] : 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins; k += THREADS) s_match[k] = 0ull;
@@ -2594,7 +2617,7 @@ extern "C" int pcc_debug_read_ktime(unsigned long long* out, size_t count) {
 
 size_t sync_area_bytes(uint32_t n, int passes) {
   const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
-  size_t b = 64;                                   // tickets
+  size_t b = kTicketBytes;                         // tickets: one per pass, the leaf scan's, eight per pass for the XCD-aware form
   b += ((tiles * sizeof(uint64_t) + 15) / 16) * 16;  // leaf scan status
   const size_t groups = (tiles + kLookBackGroup - 1) / kLookBackGroup;
   b += (size_t)passes * (tiles + groups) * kMaxBins * sizeof(uint32_t);  // sort status: per tile, per group of tiles
@@ -2657,8 +2680,8 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   const int passes = a.max_passes;
   uint8_t* sync = a.sync_area;
   uint32_t* tickets = reinterpret_cast<uint32_t*>(sync);
-  uint64_t* leaf_status = reinterpret_cast<uint64_t*>(sync + 64);
-  uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + 64 + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
+  uint64_t* leaf_status = reinterpret_cast<uint64_t*>(sync + kTicketBytes);
+  uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + kTicketBytes + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
   // Fused mode (frames of up to kFusedMaxChunks chunks): the streaming workgroups of k_boxes_events hold their points in
@@ -2697,7 +2720,11 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
     return !e ? 0 : (!strcmp(e, "narrow") ? 1 : (!strcmp(e, "wide") ? 2 : 0));
   }();
   const bool many_tiles = forced_shape ? forced_shape == 1 : s_tiles > kSortSmallGridTiles;
-#define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass")
+  // PCC_SORT_XCD=0: one ticket counter for all workgroups of a pass (round 2's form); default: XCD-aware tickets, chunks of
+  // 16 tiles (one look-back group) when every XCD gets at least two chunks' worth of tiles
+  static const int xcd_env = [] { const char* e = getenv("PCC_SORT_XCD"); return e ? atoi(e) : 16; }();
+  const int xcd_chunk = (xcd_env > 0 && s_tiles >= 32u) ? xcd_env : 0;
+#define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, xcd_chunk, span("k_sort_pass")
   for (int pass = 0; pass < passes; ++pass) {
     if (many_tiles && deep) hipLaunchKernelGGL((k_sort_pass<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
     else if (many_tiles) hipLaunchKernelGGL((k_sort_pass<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);

@@ -73,6 +73,7 @@ int syncthreads_and(int pred);
 int syncthreads_or(int pred);
 int syncthreads_count(int pred);
 void sleep(int n);
+int getreg(int imm);  // HW_REG_XCC_ID (id 20): workgroup b "runs on XCD" b mod 8, as observed on the chip; others: 0
 unsigned long long wall_clock();
 struct Launcher {
   virtual void run_lane() = 0;
@@ -111,6 +112,7 @@ static constexpr int warpSize = 64;
 #define __builtin_amdgcn_readlane(v, l) ((int)emu::readlane((uint32_t)(v), l))
 #define __builtin_amdgcn_readfirstlane(v) ((int)emu::readfirstlane((uint32_t)(v)))
 #define __builtin_amdgcn_s_sleep(n) emu::sleep(n)
+#define __builtin_amdgcn_s_getreg(imm) emu::getreg(imm)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()

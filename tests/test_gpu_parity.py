@@ -437,11 +437,13 @@ def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypa
         assert seen_fused > 100 and seen_fallback >= 3   # most chunks fused; chunks that hold earlier epochs are not
 
 
-@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "0"}, {"PCC_PLAN_SPINS": "1"}, {"PCC_LEAF_PROBES": "uniform"}])
+@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "0"}, {"PCC_PLAN_SPINS": "1"}, {"PCC_LEAF_PROBES": "uniform"}, {"PCC_SORT_XCD": "0"},
+                                 {"PCC_SORT_XCD": "3"}])
 def test_two_kernel_form_and_plan_timeouts_give_the_same_bytes(env):
     """The same clouds with fused mode switched off, with every wait for the plan running out (all chunks fall back to
     k_make_keys), and with the parent search of k_leaf_tile on evenly spaced first probes (round 2's layout; the default
-    spaces them geometrically back from the tile): child processes, because the switches are read once."""
+    spaces them geometrically back from the tile), and with the sort passes' tiles handed out by one ticket counter (round 2)
+    or in XCD-aware chunks of three tiles (the default is sixteen): child processes, because the switches are read once."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ, **env)

@@ -22,6 +22,9 @@ python bench.py --workload cfg4 --steps 48 --warmup 4 --no-host-input > $OUT/ben
 bash tools/ab_probe.sh $TAG/ab_fused PCC_FUSED_KEYS 1 0 cfg2 > $OUT/ab_fused.txt 2>&1; tail -40 $OUT/ab_fused.txt
 # ---- A/B: first probes of k_leaf_tile's parent search (geometric, the default, against round 2's evenly spaced ones)
 bash tools/ab_probe.sh $TAG/ab_probes PCC_LEAF_PROBES - uniform cfg2 > $OUT/ab_probes.txt 2>&1; tail -24 $OUT/ab_probes.txt
+# ---- A/B: XCD-aware sort tickets (default: chunks of 16 tiles per XCD) against one counter for all workgroups
+bash tools/ab_probe.sh $TAG/ab_sortxcd PCC_SORT_XCD 16 0 cfg2 > $OUT/ab_sortxcd.txt 2>&1; tail -24 $OUT/ab_sortxcd.txt
+bash tools/ab_probe.sh $TAG/ab_sortxcd4 PCC_SORT_XCD 16 0 cfg4 > $OUT/ab_sortxcd_cfg4.txt 2>&1; tail -24 $OUT/ab_sortxcd_cfg4.txt
 # ---- the shfl build of the wave helpers against the DPP one
 if [ -f cwi-pcl-codec_amd/libpcc_hip_shfl.so ]; then
   bash tools/ab_probe.sh $TAG/ab_shfl PCC_LIB $PWD/cwi-pcl-codec_amd/libpcc_hip.so $PWD/cwi-pcl-codec_amd/libpcc_hip_shfl.so cfg2 > $OUT/ab_shfl.txt 2>&1; tail -24 $OUT/ab_shfl.txt
@@ -31,7 +34,7 @@ for WL in cfg2 cfg4; do
   bash tools/prof_latency.sh $TAG/lat_$WL $WL > $OUT/latency_$WL.txt 2>&1; tail -16 $OUT/latency_$WL.txt
   bash tools/pmc_run.sh $TAG/pmc_$WL $WL > $OUT/pmc_$WL.log 2>&1; tail -3 $OUT/pmc_$WL.log
 done
-PCC_FUSED_KEYS=0 PCC_LEAF_PROBES=uniform bash tools/pmc_run.sh $TAG/pmc_cfg2_round2_form cfg2 > $OUT/pmc_cfg2_round2_form.log 2>&1; tail -3 $OUT/pmc_cfg2_round2_form.log
+PCC_FUSED_KEYS=0 PCC_LEAF_PROBES=uniform PCC_SORT_XCD=0 bash tools/pmc_run.sh $TAG/pmc_cfg2_round2_form cfg2 > $OUT/pmc_cfg2_round2_form.log 2>&1; tail -3 $OUT/pmc_cfg2_round2_form.log
 PMC_DISTINCT=12 bash tools/pmc_run.sh $TAG/pmc_cfg2_12frames cfg2 > $OUT/pmc_cfg2_12frames.log 2>&1; tail -3 $OUT/pmc_cfg2_12frames.log
 # ---- the bench command under the kernel tracer; the device range coder
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-input --steps 256 > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err)
