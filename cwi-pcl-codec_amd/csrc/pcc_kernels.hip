@@ -1099,7 +1099,10 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
   constexpr uint32_t kDtGroups = kDtThreads / kDtCols;
   __shared__ uint32_t s_part[kDtGroups][kDtCols];
   const uint32_t c = threadIdx.x % kDtCols;
-  const uint32_t col = blockIdx.x * kDtCols + c;
+  // 16 columns are half a 128-byte line of every row: the two workgroups that share the lines are put on the same XCD
+  // (workgroup b runs on XCD b mod 8: every XCD takes a contiguous eighth of the column blocks; the grid is a multiple of 8)
+  const uint32_t cb = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t col = cb * kDtCols + c;
   const uint32_t pass = col / kMaxBins;
   if ((int)pass >= st->npasses) return;  // uniform per workgroup (512 columns per pass)
   const uint32_t g = threadIdx.x / kDtCols;
