@@ -535,7 +535,15 @@ int syncthreads_and(int pred) { return (int)yield_lane(kBarrier, kSyncAnd, pred 
 int syncthreads_or(int pred) { return (int)yield_lane(kBarrier, kSyncOr, pred != 0, 0); }
 int syncthreads_count(int pred) { return (int)yield_lane(kBarrier, kSyncCount, pred != 0, 0); }
 void sleep(int) { (void)yield_lane(kSleep, 0, 0, 0); }
-int getreg(int imm) { return ((imm & 63) == 20 && tl_worker) ? (int)(tl_worker->block_linear & 7u) : 0; }
+// HW_REG_XCC_ID: workgroup b on XCD b mod 8, as observed on the chip.  PCC_EMU_XCC=<n>: every workgroup claims XCD n;
+// PCC_EMU_XCC=rand: a pseudo-random one -- the kernels may use the register as a hint only, and must give the same bytes
+int getreg(int imm) {
+  if ((imm & 63) != 20 || !tl_worker) return 0;
+  static const int mode = [] { const char* e = getenv("PCC_EMU_XCC"); return !e ? -1 : (!strcmp(e, "rand") ? -2 : atoi(e) & 7); }();
+  if (mode >= 0) return mode;
+  if (mode == -2) return (int)((tl_worker->block_linear * 2654435761u) >> 29);
+  return (int)(tl_worker->block_linear & 7u);
+}
 unsigned long long wall_clock() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);

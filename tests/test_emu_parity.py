@@ -65,6 +65,36 @@ def test_the_shfl_build_agrees(emu_libs):
     assert passed >= 100, tail
 
 
+@pytest.mark.parametrize("xcc", ["5", "rand"])
+def test_the_xcd_register_is_only_a_hint(emu_libs, xcc):
+    """The sort passes hand their tiles out per XCD (HW_REG_XCC_ID).  Whatever that register says -- every workgroup
+    claiming XCD 5, or a random one -- every tile must be taken exactly once and the bytes must be the same."""
+    env = dict(os.environ, PCC_LIB=emu_libs[0], PCC_EMU_XCC=xcc)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "tests/test_gpu_parity.py",
+                        "-k", "cfg2_1m_depth10_surface or random_sweep or 22_to_31 or pair_sort"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+
+
+def test_fused_keys_read_the_cloud_once_in_the_traffic_model(emu_libs):
+    """The executor's traffic model (outline access instrumentation; first-touch lines per XCD and launch): with fused keys the
+    kernels in front of the sort touch the cloud's lines once, in the two-kernel form twice."""
+    subprocess.run(["make", "-s", "-j8", "-C", EMU, "traffic"], check=True)
+
+    def front(env):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, os.path.join(EMU, "traffic_model.py"), "cfg1"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        mb = 0.0
+        for line in r.stdout.splitlines():
+            f = line.split()
+            if f and f[0] in ("k_boxes_events", "k_make_keys"):
+                mb += float(f[6])   # first-touch read, MB
+        return mb
+    cloud_mb = 100_000 * 32 / 1e6
+    fused, two = front({}), front({"PCC_FUSED_KEYS": "0"})
+    assert fused < 1.2 * cloud_mb and two > 1.9 * cloud_mb, (fused, two)
+
+
 def test_bench_script_runs_end_to_end_on_the_executor(emu_libs):
     """Not a measurement (the numbers are the CPU's): every line of bench.py -- timed region, serialised roofline leg, host
     legs including the packed one, entropy-stage report, CPU baseline -- has run before a GPU session depends on it."""
