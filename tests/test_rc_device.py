@@ -109,8 +109,8 @@ def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
         assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         assert pipe.last_entropy_mode() == 0
         # ... a long call on a host with two entropy threads goes to the GPU (1 024 frames announced as 1 M points each
-        # would, by the estimate; here 600 small frames with a batch of 8 per flush: the estimate counts flushes)
-        many = [frames[0], frames[1], frames[2]] * 200
+        # would, by the estimate; here 192 small frames with a batch of 8 per flush: the estimate counts flushes)
+        many = [frames[0], frames[1], frames[2]] * 64
         want = []
         fid = 2
         for k in range(len(many)):
