@@ -149,7 +149,7 @@ class KernelTimer {
 size_t sync_area_bytes(uint32_t n, int passes);
 // fused mode is for frames whose bounding-box chunks can all be resident at once (the streaming workgroups wait for the plan)
 constexpr uint32_t kFusedMaxChunks = 1024;
-constexpr size_t kPlanGranulesHost = 64;  // = kPlanGranules of pcc_kernels.hip
+constexpr size_t kPlanGranulesHost = 512;  // = kPlanGranules of pcc_kernels.hip (plan words, epoch table)
 // a poll and an s_sleep(32) take about a microsecond on the GPU: the plan of a lone frame arrives after ~15 us, so this
 // bound is only met when the grid is not resident as a whole (other frames' kernels in the way).  The CPU executor of
 // tests/emu has no clock to speak of: there the bound is large, and a test sets it to 1 to see the fallback work.

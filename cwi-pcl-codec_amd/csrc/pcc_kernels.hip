@@ -341,9 +341,14 @@ constexpr int kPlanCellDim = 14;    // 3 words
 constexpr int kPlanLastEpoch = 17;  // index of the first point of the last epoch
 constexpr int kPlanPass = 18;       // kMaxPasses words: bits | shift << 8
 constexpr int kPlanRanks = kPlanPass + kMaxPasses;  // 16 words: cell_rank[64]
-constexpr int kPlanWords = kPlanRanks + 16;
-constexpr int kPlanGranules = 64;   // the per-chunk granules start here
-static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords <= 64 && kPlanGranules == (int)kPlanGranulesHost, "one wave sweeps the plan");
+constexpr int kPlanEpochs = kPlanRanks + 16;        // number of epochs
+constexpr int kPlanWords = kPlanEpochs + 1;
+// behind the plan's words: the epoch table, ten granules per epoch {first index, origin (three doubles), key offsets (3)},
+// for the workgroups whose chunk holds points of earlier epochs (the chunk with the growth events)
+constexpr int kPlanEpochBase = 64, kPlanEpochWords = 10;
+constexpr int kPlanGranules = 512;  // the per-chunk granules start here
+static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords <= 64 && kPlanEpochBase + kPlanEpochWords * kMaxEpochs <= kPlanGranules &&
+              kPlanGranules == (int)kPlanGranulesHost, "one wave sweeps the plan");
 
 __device__ __forceinline__ void publish_box(uint64_t* dst, const ChunkBox& b, uint32_t seq) {
   uint32_t v[kBoxWords];
@@ -472,7 +477,6 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
   if (!s_plan[kPlanWords]) return;                       // the wait ran out: k_make_keys does this chunk
   const uint32_t flags = s_plan[kPlanFlags];
   if (!(flags & 1u)) return;                            // the frame ended in an error or holds no finite point
-  if ((int)base < (int)s_plan[kPlanLastEpoch]) return;  // points of earlier epochs in here: k_make_keys has the epoch table
   KeyGeom g;
   {
     const uint32_t bits = s_plan[kPlanBits];
@@ -487,11 +491,39 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 #pragma unroll
     for (int q = 0; q < kMaxPasses; ++q) { const uint32_t w = s_plan[kPlanPass + q]; g.pshift[q] = (int)(w >> 8); g.pmask[q] = (1u << (w & 0xffu)) - 1u; }
   }
+  if (g.np > 7) return;  // (single-word codes have at most seven passes; the LDS behind the digit counts is laid out for that)
   double emn[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) emn[a] = __longlong_as_double((long long)(((uint64_t)s_plan[kPlanMn + 2 * a + 1] << 32) | s_plan[kPlanMn + 2 * a]));
   const uint32_t no_shift[3] = {0u, 0u, 0u};  // nothing re-roots the tree after the last epoch has begun
   const uint8_t* ranks = reinterpret_cast<const uint8_t*>(s_plan + kPlanRanks);
+  // A chunk that holds points of earlier epochs (the one with the growth events: chunk 0 of a shuffled cloud; many chunks of
+  // a cloud sorted along an axis) needs the epoch table: ten granules per epoch behind the plan's words, swept the same way.
+  const int ne = (int)s_plan[kPlanEpochs];
+  const bool early = (int)base < (int)s_plan[kPlanLastEpoch];
+  uint32_t* s_ep = s_hist + 7 * kMaxBins;  // [ne][kPlanEpochWords]
+  if (early) {
+    if (wave_id() == 0) {
+      const int l = lane_id(), nw = ne * kPlanEpochWords;
+      bool all_there = true;
+      for (int r0 = 0; r0 < nw && all_there; r0 += 64) {
+        bool got = false;
+        for (uint32_t spin = 0; spin < fk.plan_spins; ++spin) {
+          const uint64_t w = r0 + l < nw ? poll_u64(fk.plan + kPlanEpochBase + r0 + l) : ((uint64_t)seq << 32);
+          if (__ballot((uint32_t)(w >> 32) != seq) == 0ull) {
+            if (r0 + l < nw) s_ep[r0 + l] = (uint32_t)w;
+            got = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        all_there = got;
+      }
+      if (l == 0) s_plan[kPlanWords] = all_there ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_plan[kPlanWords]) return;  // (the table did not arrive in time: k_make_keys does this chunk)
+  }
   for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) s_hist[k] = 0u;
   __syncthreads();
 #pragma unroll
@@ -499,10 +531,27 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     const uint32_t i = base + k * kBlock + threadIdx.x;
     if (i >= n) break;
     uint64_t key = kInvalidKey;
-    if (px[FUSED ? k : 0] == px[FUSED ? k : 0]) {  // finite (NaN marks the others)
+    bool counted = px[FUSED ? k : 0] == px[FUSED ? k : 0];  // finite (NaN marks the others)
+    const double* pmn = emn;
+    const uint32_t* pshift = no_shift;
+    double lmn[3];
+    uint32_t lshift[3];
+    if (early && counted) {  // the epoch the point belongs to (points in front of the first epoch are the non-finite ones)
+      int e = ne - 1;
+      while (e > 0 && (int)s_ep[e * kPlanEpochWords] > (int)i) --e;
+      const uint32_t* q = s_ep + e * kPlanEpochWords;
+      counted = (int)i >= (int)s_ep[0];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lmn[a] = __longlong_as_double((long long)(((uint64_t)q[2 + 2 * a] << 32) | q[1 + 2 * a]));
+        lshift[a] = q[7 + a];
+      }
+      pmn = lmn; pshift = lshift;
+    }
+    if (counted) {
       bool ok = true;
       uint32_t hi_unused;
-      const uint64_t code = point_code(g, emn, no_shift, ranks, res, fk.inv_res_pow2, px[FUSED ? k : 0], py[FUSED ? k : 0], pz[FUSED ? k : 0], ok, hi_unused);
+      const uint64_t code = point_code(g, pmn, pshift, ranks, res, fk.inv_res_pow2, px[FUSED ? k : 0], py[FUSED ? k : 0], pz[FUSED ? k : 0], ok, hi_unused);
       if (!ok) s_plan[kPlanWords + 1] = 1u;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
 #pragma unroll
       for (int q = 0; q < kMaxPasses; ++q)
@@ -831,6 +880,17 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (last_of_run) {
       st->ep_index[w] = ev_index[k];
       for (int a = 0; a < 3; ++a) { st->ep_mn[w][a] = ev_mn[k][a]; st->ep_shift[w][a] = later[a]; }
+      if (fk.plan) {  // fused mode: the same row for the streaming workgroups whose chunk holds points of earlier epochs
+        uint64_t* q = fk.plan + kPlanEpochBase + w * kPlanEpochWords;
+        const uint64_t tag = (uint64_t)seq << 32;
+        publish_u64(q, tag | (uint32_t)ev_index[k]);
+        for (int a = 0; a < 3; ++a) {
+          const uint64_t bits = (uint64_t)__double_as_longlong(ev_mn[k][a]);
+          publish_u64(q + 1 + 2 * a, tag | (uint32_t)bits);
+          publish_u64(q + 2 + 2 * a, tag | (uint32_t)(bits >> 32));
+          publish_u64(q + 7 + a, tag | later[a]);
+        }
+      }
     }
     if (k == 0) {
       st->n_epochs = ne;
@@ -980,6 +1040,10 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         v = PCC_PICK3(cdim, p - kPlanCellDim);
       } else if (p == kPlanLastEpoch) {
         v = (uint32_t)ev_index[nev - 1];
+      } else if (p == kPlanEpochs) {  // runs of growth events at one point count once (the last of a run stands for the epoch)
+        int runs = 0;
+        for (int k2 = 0; k2 < nev; ++k2) runs += !(k2 + 1 < nev && ev_index[k2 + 1] == ev_index[k2]);
+        v = (uint32_t)runs;
       } else if (p >= kPlanPass && p < kPlanPass + kMaxPasses) {
         const int q = p - kPlanPass;  // (the plan is only used for single-word codes: np = np_lo)
         int bq = 0, sh = 0;
@@ -1019,17 +1083,11 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
   const int ne = st->n_epochs;
   if (ne == 0 || st->error != kErrNone) return;
-  if (chunk_state) {
-    const uint64_t w = chunk_state[blockIdx.x];
-    if ((uint32_t)(w >> 32) == seq && (uint32_t)w != 0u) {  // keys and digit counts of this chunk are there already
-      if ((uint32_t)w == 2u && threadIdx.x == 0) st->error = kErrPrefix;
-      return;
-    }
-  }
+  // one workgroup per tile, or (fused mode: nearly every chunk has its keys already) a few workgroups that look at all
+  // chunks' granules in turn and make the keys of those that were left alone
+  const uint32_t n_tiles_all = (n + (uint32_t)kKeyTile - 1u) / (uint32_t)kKeyTile;
   KeyGeom g;
   g.np = st->npasses;
-  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
-  __syncthreads();
   g.vb = st->vbits_axis; g.ibits = st->ibits;
   g.packed_mode = st->packed != 0;
   g.payload = st->payload;
@@ -1042,10 +1100,21 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   g.lm = g.cm >= 32 ? 0xffffffffu : ((1u << g.cm) - 1u);
   g.m = g.vb >= 32 ? 0xffffffffu : ((1u << g.vb) - 1u);
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
-  const uint32_t base = blockIdx.x * kKeyTile;
-  const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
 #pragma unroll
   for (int p = 0; p < kMaxPasses; ++p) { g.pshift[p] = st->pass_shift[p]; g.pmask[p] = (1u << st->pass_bits[p]) - 1u; }
+  for (uint32_t tile = blockIdx.x; tile < n_tiles_all; tile += gridDim.x) {
+  if (chunk_state) {
+    const uint64_t w = chunk_state[tile];
+    if ((uint32_t)(w >> 32) == seq && (uint32_t)w != 0u) {  // keys and digit counts of this chunk are there already
+      if ((uint32_t)w == 2u && threadIdx.x == 0) st->error = kErrPrefix;
+      continue;
+    }
+  }
+  __syncthreads();  // (nobody is still reading the digit counts of the tile before)
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
+  __syncthreads();
+  const uint32_t base = tile * kKeyTile;
+  const bool late = (int)base >= ep_last;  // the whole tile lies in the last epoch (all but the first tiles)
 #pragma unroll
   for (int k = 0; k < KEY_ITEMS; ++k) {
     const uint32_t i = base + k * kKeyThreads + threadIdx.x;
@@ -1077,8 +1146,9 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
     keys[i] = key;
   }
   __syncthreads();
-  uint32_t* row = hist_rows + (size_t)blockIdx.x * kMaxPasses * kMaxBins;
+  uint32_t* row = hist_rows + (size_t)tile * kMaxPasses * kMaxBins;
   for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) row[k] = (&s_h[0][0])[k];
+  }
 }
 
 // column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
@@ -2701,7 +2771,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
                      a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   if (fused)
-    hipLaunchKernelGGL((k_make_keys<kBlock, kItems>), dim3(n_tiles), dim3(kBlock), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
+    hipLaunchKernelGGL((k_make_keys<kBlock, kItems>), dim3(std::min(n_tiles, 64u)), dim3(kBlock), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
                        a.plan + kPlanGranules, a.frame_seq, span("k_make_keys"));
   else
     hipLaunchKernelGGL((k_make_keys<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
