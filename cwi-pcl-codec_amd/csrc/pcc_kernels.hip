@@ -495,7 +495,6 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
   double emn[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) emn[a] = __longlong_as_double((long long)(((uint64_t)s_plan[kPlanMn + 2 * a + 1] << 32) | s_plan[kPlanMn + 2 * a]));
-  const uint32_t no_shift[3] = {0u, 0u, 0u};  // nothing re-roots the tree after the last epoch has begun
   const uint8_t* ranks = reinterpret_cast<const uint8_t*>(s_plan + kPlanRanks);
   // A chunk that holds points of earlier epochs (the one with the growth events: chunk 0 of a shuffled cloud; many chunks of
   // a cloud sorted along an axis) needs the epoch table: ten granules per epoch behind the plan's words, swept the same way.
@@ -532,10 +531,8 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     if (i >= n) break;
     uint64_t key = kInvalidKey;
     bool counted = px[FUSED ? k : 0] == px[FUSED ? k : 0];  // finite (NaN marks the others)
-    const double* pmn = emn;
-    const uint32_t* pshift = no_shift;
-    double lmn[3];
-    uint32_t lshift[3];
+    double pmn[3] = {emn[0], emn[1], emn[2]};   // (copies, not pointers: the arrays stay in registers)
+    uint32_t pshift[3] = {0u, 0u, 0u};
     if (early && counted) {  // the epoch the point belongs to (points in front of the first epoch are the non-finite ones)
       int e = ne - 1;
       while (e > 0 && (int)s_ep[e * kPlanEpochWords] > (int)i) --e;
@@ -543,10 +540,9 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
       counted = (int)i >= (int)s_ep[0];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        lmn[a] = __longlong_as_double((long long)(((uint64_t)q[2 + 2 * a] << 32) | q[1 + 2 * a]));
-        lshift[a] = q[7 + a];
+        pmn[a] = __longlong_as_double((long long)(((uint64_t)q[2 + 2 * a] << 32) | q[1 + 2 * a]));
+        pshift[a] = q[7 + a];
       }
-      pmn = lmn; pshift = lshift;
     }
     if (counted) {
       bool ok = true;
@@ -1102,7 +1098,9 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
 #pragma unroll
   for (int p = 0; p < kMaxPasses; ++p) { g.pshift[p] = st->pass_shift[p]; g.pmask[p] = (1u << st->pass_bits[p]) - 1u; }
-  for (uint32_t tile = blockIdx.x; tile < n_tiles_all; tile += gridDim.x) {
+  // (the one-workgroup-per-tile form takes exactly one turn: the compiler is told so, and keeps that form's registers)
+  constexpr bool kLooping = kKeyThreads == kBlock;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles_all; tile = kLooping ? tile + gridDim.x : n_tiles_all) {
   if (chunk_state) {
     const uint64_t w = chunk_state[tile];
     if ((uint32_t)(w >> 32) == seq && (uint32_t)w != 0u) {  // keys and digit counts of this chunk are there already
@@ -1110,7 +1108,7 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
       continue;
     }
   }
-  __syncthreads();  // (nobody is still reading the digit counts of the tile before)
+  if (kLooping) __syncthreads();  // (nobody is still reading the digit counts of the tile before)
   for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
   __syncthreads();
   const uint32_t base = tile * kKeyTile;
