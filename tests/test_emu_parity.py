@@ -38,7 +38,8 @@ def run_gpu_tests(lib, targets, deselect=(), extra=()):
     # LD_PRELOAD: the external executables of the tests (evaluation app, shim examples: linked against libpcc_hip.so) get the
     # executor's definitions of the C ABI as well
     env = dict(os.environ, PCC_LIB=lib, LD_PRELOAD=lib)
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "1500"] + list(targets)
+    # (four test processes side by side: between launches a test is single-threaded Python and oracle work)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "1500", "-n", "4"] + list(targets)
     for d in deselect:
         cmd += ["--deselect", d]
     r = subprocess.run(cmd + list(extra), cwd=ROOT, env=env, capture_output=True, text=True)
