@@ -105,6 +105,7 @@ struct pcc_ctx {
   DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint32_t> d_idx2_a, d_idx2_b, d_leaf_hi;  // trees deeper than 21 levels only (two-word codes): allocated when one comes by
   bool deep_hint = false;                          // the frame before was one: enqueue the deep kernels straight away
+  bool payload_hint = false;                       // the frame before had a payload in its sort (PCC_SORT_BARE only)
   DevBuf<uint8_t> d_leaf_t, d_bgr, d_centroid, d_image, d_sync;
   // the per-MCU-row Huffman records and, right behind them, the occupancy stream: what the host stage needs of a
   // colour frame is one contiguous piece of HBM and comes back in ONE copy (a copy costs some 40 us to set up)
@@ -561,6 +562,12 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.max_passes = std::min(std::max(ctx->pass_hint, 1), (int)kMaxPasses);
   a.deep_launch = ctx->deep_hint ? 1 : 0;
   {
+    // PCC_SORT_BARE=1 (experiment, off by default): sort passes without the payload path, three tiles per CU; frames that
+    // turn out to need a payload (centroids, codes too long for the colour to share the key) are sent back once
+    static const bool bare_env = [] { const char* e = getenv("PCC_SORT_BARE"); return e && e[0] == '1'; }();
+    a.bare_launch = (bare_env && !ctx->payload_hint && !a.deep_launch) ? 1 : 0;
+  }
+  {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
     a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
     // '2': keep the point index in the key although nothing needs it (the packed [code | index] + colour payload sort)
@@ -765,10 +772,13 @@ static int wait_frame_state(pcc_ctx* ctx) {
   // waited for was held up for tens of milliseconds -- another process on the GPU, a debugger; nothing is wrong with
   // the frame).  Either can show up on the re-run the other one caused, hence a loop; a poll may time out once.
   int spin_retries = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  for (int attempt = 0; attempt < 5; ++attempt) {
     if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
       ctx->args.max_passes = kMaxPasses;
+    } else if (st.error == kErrPayload && ctx->args.bare_launch) {
+      ctx->args.bare_launch = 0;
     } else if (st.error == kErrDeep && !ctx->args.deep_launch) {
+      ctx->args.bare_launch = 0;
       // a tree deeper than 21 levels: its Morton codes need two words; the kernels' DEEP instantiations and their arrays
       ctx->args.deep_launch = 1;
       ctx->args.max_passes = kMaxPasses;
@@ -793,6 +803,7 @@ static int wait_frame_state(pcc_ctx* ctx) {
   if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
   ctx->pass_hint = st.npasses;
   ctx->deep_hint = st.depth > kMaxDepth;  // (a shallow frame behind a deep one goes back to the single-word kernels)
+  ctx->payload_hint = st.payload != 0;
   return PCC_OK;
 }
 

@@ -63,6 +63,7 @@ enum FrameError : int32_t {
   kErrPasses = 4,          // the frame needs more sort passes than the host enqueued (host re-launches)
   kErrSpin = 5,            // a look-back poll ran into kSpinLimit (should not happen)
   kErrDeep = 6,            // the tree is deeper than kMaxDepth and the host enqueued the single-word kernels (host re-launches)
+  kErrPayload = 7,         // the keys carry a payload and the host enqueued the payload-free sort passes (host re-launches)
 };
 
 struct FrameState {

@@ -79,6 +79,8 @@ struct HotPathArgs {
   uint64_t* keys_b;
   uint32_t* idx_a;
   uint32_t* idx_b;
+  int bare_launch;     // 1: enqueue the payload-free sort passes (PCC_SORT_BARE=1, an experiment): a frame whose keys carry a
+                       // payload comes back with kErrPayload
   int deep_launch;     // 1: enqueue the DEEP instantiations (two-word Morton codes: trees of 22 to 31 levels); the device sends
                        // a deep frame that meets the single-word kernels back with kErrDeep
   uint32_t* idx2_a;    // deep only: second payload of the sort (point index or colour word), ping-pong

@@ -567,7 +567,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int deep_launched, int do_color, FixedBox box,
+                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int deep_launched, int bare_launched, int do_color, FixedBox box,
                                                          FrameState* __restrict__ st, FusedKeys fk, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction (fused mode: plan, digit counts)
@@ -978,6 +978,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     const int np_hi = (hi_bits + kMaxDigitBits - 1) / kMaxDigitBits;
     const int np = np_lo + np_hi;
     if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
+    if (err == kErrNone && bare_launched && !bare) err = kErrPayload;  // ... with the sort passes that move a payload
     // digit q of `n` digits over `bits` bits: width, and offset of its first bit
     auto digit = [](int q, int n, int bits, int& width, int& offset) {
       width = 0; offset = 0;
@@ -1229,8 +1230,10 @@ constexpr uint32_t kXcdTicketBase = 16;                           // tickets[16 
 constexpr size_t kTicketBytes = (16 + 8 * kMaxPasses + 8) * sizeof(uint32_t) / 16 * 16 + 16;
 // (DEEP: two-word codes -- the u32 payload is the code's high word, whose digits the last passes sort by, and a second
 // payload array carries the point index or the colour word)
-template <int THREADS, int ITEMS, bool DEEP = false>
-__global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
+// (PAY = false: no payload path, two thirds of the LDS and a six-waves-per-SIMD register budget, so that THREE 512-thread
+// tiles share a CU -- an experiment behind PCC_SORT_BARE=1 until a GPU has timed it: 80 registers, 64 bytes of scratch per lane)
+template <int THREADS, int ITEMS, bool DEEP = false, bool PAY = true>
+__global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
                                                             uint64_t* out_a, uint64_t* out_b,
                                                             uint32_t* idx_a, uint32_t* idx_b, uint32_t* idx2_a, uint32_t* idx2_b, uint32_t n, int pass,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
@@ -1244,7 +1247,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   static_assert(THREADS * ITEMS == kSortTile && THREADS >= kMaxBins, "a tile is 4096 keys (the histogram rows of k_make_keys); one thread per digit");
   // s_raw is used twice: while ranking, one 64-bit lane mask per (wave, digit); afterwards the tile's
   // keys (and payload) in digit order, so that the global writes are runs
-  constexpr int kTileWords = DEEP ? kSortTile * 2 : kSortTile * 3 / 2;  // keys + one payload (+ a second one)
+  constexpr int kTileWords = DEEP ? kSortTile * 2 : (PAY ? kSortTile * 3 / 2 : kSortTile);  // keys + one payload (+ a second one)
   constexpr int kRawWords = NW * kMaxBins > kTileWords ? NW * kMaxBins : kTileWords;
   __shared__ __attribute__((aligned(16))) uint64_t s_raw[kRawWords];
   uint64_t* s_match = s_raw;
@@ -1303,7 +1306,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a,
   PCC_KT(1);
   if (tile >= n_tiles) return;
 
-  const bool with_payload = st->payload != 0;
+  const bool with_payload = PAY && st->payload != 0;
   const bool with_payload2 = DEEP && st->payload2 != 0;
   const int shift = st->ibits + st->pass_shift[pass];
   // the digit of a key: of the key word or, in the last passes over a two-word code, of the payload (the high word)
@@ -2722,6 +2725,7 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems, false>, kSortThreads);
   one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8, false>, 512);
   one("k_sort_pass<512,8,deep>", (const void*)k_sort_pass<512, 8, true>, 512);
+  one("k_sort_pass<512,8,bare>", (const void*)k_sort_pass<512, 8, false, false>, 512);
   one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems, false>, kSortThreads);
   one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8, false>, 512);
   one("k_leaf_tile", (const void*)k_leaf_tile<false>, kFinThreads);
@@ -2759,6 +2763,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   // registers until workgroup 0 has published the sort plan, then write keys and digit counts themselves -- the cloud is
   // read once -- and k_make_keys only visits the chunks that were left alone (normally chunk 0, where the box grows).
   const bool deep = a.deep_launch != 0;  // the DEEP instantiations (two-word codes): a frame deeper than 21 levels came by
+  const bool bare_sort = a.bare_launch != 0 && !deep && s_tiles > kSortSmallGridTiles;  // payload-free sort passes (experiment)
   const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks && !deep;
   FusedKeys fk{};
   if (fused) {
@@ -2766,7 +2771,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
     fk.inv_res_pow2 = a.inv_res_pow2; fk.plan_spins = a.plan_spins; fk.do_color = (int)a.lp.do_color;
   }
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
+                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, bare_sort ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   if (fused)
     hipLaunchKernelGGL((k_make_keys<kBlock, kItems>), dim3(std::min(n_tiles, 64u)), dim3(kBlock), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
@@ -2797,7 +2802,8 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   const int xcd_chunk = (xcd_env > 0 && s_tiles >= 32u) ? xcd_env : 0;
 #define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, xcd_chunk, span("k_sort_pass")
   for (int pass = 0; pass < passes; ++pass) {
-    if (many_tiles && deep) hipLaunchKernelGGL((k_sort_pass<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
+    if (many_tiles && bare_sort) hipLaunchKernelGGL((k_sort_pass<512, 8, false, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
+    else if (many_tiles && deep) hipLaunchKernelGGL((k_sort_pass<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
     else if (many_tiles) hipLaunchKernelGGL((k_sort_pass<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
     else if (deep) hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems, true>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SORT_ARGS);
     else hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems, false>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SORT_ARGS);

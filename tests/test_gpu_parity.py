@@ -438,17 +438,18 @@ def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypa
 
 
 @pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "0"}, {"PCC_PLAN_SPINS": "1"}, {"PCC_LEAF_PROBES": "uniform"}, {"PCC_SORT_XCD": "0"},
-                                 {"PCC_SORT_XCD": "3"}])
+                                 {"PCC_SORT_XCD": "3"}, {"PCC_SORT_BARE": "1"}])
 def test_two_kernel_form_and_plan_timeouts_give_the_same_bytes(env):
     """The same clouds with fused mode switched off, with every wait for the plan running out (all chunks fall back to
     k_make_keys), and with the parent search of k_leaf_tile on evenly spaced first probes (round 2's layout; the default
     spaces them geometrically back from the tile), and with the sort passes' tiles handed out by one ticket counter (round 2)
-    or in XCD-aware chunks of three tiles (the default is sixteen): child processes, because the switches are read once."""
+    or in XCD-aware chunks of three tiles (the default is sixteen), and with the payload-free sort passes enqueued first (an
+    experiment: frames whose keys carry a payload are sent back once): child processes, because the switches are read once."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points or cfg3_capture"],
+                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points or cfg3_capture or cfg2_1m_depth10_surface"],
                        cwd=root, env=e, capture_output=True, text=True, timeout=1800)
     # with the mode off / all chunks timing out the fused-chunk counters of the first test do not hold: it is told so
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
