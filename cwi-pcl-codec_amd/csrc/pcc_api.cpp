@@ -105,6 +105,7 @@ struct pcc_ctx {
   DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint32_t> d_idx2_a, d_idx2_b, d_leaf_hi;  // trees deeper than 21 levels only (two-word codes): allocated when one comes by
   bool deep_hint = false;                          // the frame before was one: enqueue the deep kernels straight away
+  bool local_off = false;                          // a frame came by whose groups were too long for the local fix-up (PCC_SORT_LOCAL only)
   bool payload_hint = false;                       // the frame before had a payload in its sort (PCC_SORT_BARE only)
   DevBuf<uint8_t> d_leaf_t, d_bgr, d_centroid, d_image, d_sync;
   // the per-MCU-row Huffman records and, right behind them, the occupancy stream: what the host stage needs of a
@@ -566,6 +567,10 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
     // turn out to need a payload (centroids, codes too long for the colour to share the key) are sent back once
     static const bool bare_env = [] { const char* e = getenv("PCC_SORT_BARE"); return e && e[0] == '1'; }();
     a.bare_launch = (bare_env && !ctx->payload_hint && !a.deep_launch) ? 1 : 0;
+    // PCC_SORT_LOCAL=1 (experiment, off by default): the lowest code bits are sorted locally in k_leaf_scan when that saves
+    // a global sort pass; a frame with a group too long for it is sent back once and the context stops trying
+    static const bool local_env = [] { const char* e = getenv("PCC_SORT_LOCAL"); return e && e[0] == '1'; }();
+    a.local_launch = (local_env && !ctx->local_off && !a.deep_launch && !stop_after_leaf_scan) ? 1 : 0;
   }
   {
     const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
@@ -772,9 +777,12 @@ static int wait_frame_state(pcc_ctx* ctx) {
   // waited for was held up for tens of milliseconds -- another process on the GPU, a debugger; nothing is wrong with
   // the frame).  Either can show up on the re-run the other one caused, hence a loop; a poll may time out once.
   int spin_retries = 0;
-  for (int attempt = 0; attempt < 5; ++attempt) {
+  for (int attempt = 0; attempt < 6; ++attempt) {
     if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
       ctx->args.max_passes = kMaxPasses;
+    } else if (st.error == kErrLocal && ctx->args.local_launch) {
+      ctx->args.local_launch = 0;
+      ctx->local_off = true;
     } else if (st.error == kErrPayload && ctx->args.bare_launch) {
       ctx->args.bare_launch = 0;
     } else if (st.error == kErrDeep && !ctx->args.deep_launch) {
@@ -1790,7 +1798,7 @@ static int block_tree_of(pcc_ctx* owner, pcc_ctx* sc, const void* dev_points, si
   if (rc != PCC_OK) return fail(owner, rc, std::string("macroblock tree: ") + sc->err);
   const FrameState& st = *sc->h_state.p;
   if (!st.packed) return fail(owner, PCC_ERR_UNSUPPORTED, "macroblock tree: key and point index do not fit 64 bits");
-  t.sorted_keys = (st.npasses & 1) ? sc->d_keys_b.p : sc->d_keys_a.p;
+  t.sorted_keys = st.keys_final ? sc->d_keys_b.p : sc->d_keys_a.p;
   t.leaf_start = sc->d_leaf_start.p;
   t.leaf_code = sc->d_leaf_code.p;
   t.prefix_code = host_morton3(st.prefix[0], st.prefix[1], st.prefix[2]);

@@ -79,6 +79,8 @@ struct HotPathArgs {
   uint64_t* keys_b;
   uint32_t* idx_a;
   uint32_t* idx_b;
+  int local_launch;    // 1: enqueue the LOCAL leaf scan (PCC_SORT_LOCAL=1, an experiment): the device may then leave the lowest code bits
+                       // to a local fix-up and save a sort pass; kErrLocal sends a frame back whose groups are too long for it
   int bare_launch;     // 1: enqueue the payload-free sort passes (PCC_SORT_BARE=1, an experiment): a frame whose keys carry a
                        // payload comes back with kErrPayload
   int deep_launch;     // 1: enqueue the DEEP instantiations (two-word Morton codes: trees of 22 to 31 levels); the device sends

@@ -567,7 +567,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
 
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
                                                          uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int deep_launched, int bare_launched, int do_color, FixedBox box,
+                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int deep_launched, int bare_launched, int local_launched, int do_color, FixedBox box,
                                                          FrameState* __restrict__ st, FusedKeys fk, unsigned long long* span) {
   const KSpan kspan(span);
   __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction (fused mode: plan, digit counts)
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       if (threadIdx.x == 0) {
         st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
         st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0; st->deep = 0; st->payload2 = 0;
+        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0; st->deep = 0; st->payload2 = 0; st->local_bits = 0; st->keys_final = 0;
         st->code_low_bits = 0; st->code_bits = 0;
         st->passes_launched = passes_launched;
       }
@@ -971,7 +971,14 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (!packed) ibits = 0;
     // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them.  Deep trees: the low word's
     // bits first, then the high word's (a digit never straddles the two; a shift of 63 or more means "of the high word")
-    const int vbits = cbits;  // what is sorted
+    // Experiment (PCC_SORT_LOCAL, the host enqueued the LOCAL leaf scan): when leaving the lowest 3, 6 or 9 code bits to a
+    // local fix-up saves a global pass, the passes only sort the bits above them -- keys with equal higher bits (one cube of
+    // 2, 4 or 8 voxels a side) end up next to each other and k_leaf_scan sorts each such group in LDS
+    int local_bits = 0;
+    if (local_launched && bare && !deep)
+      for (int lb = 3; lb <= 9 && lb <= 3 * cm && !local_bits; lb += 3)
+        if (cbits - lb >= 1 && passes_for(cbits - lb) < passes_for(cbits)) local_bits = lb;
+    const int vbits = cbits - local_bits;  // what the passes sort
     const int lo_bits = vbits < 63 ? vbits : 63, hi_bits = vbits - lo_bits;
     int np_lo = (lo_bits + kMaxDigitBits - 1) / kMaxDigitBits;
     if (np_lo < 1) np_lo = 1;
@@ -991,9 +998,9 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     const int p = lane_id();
     if (p < kMaxPasses) {
       int bits = 0, sh = 0;
-      if (p < np_lo) digit(p, np_lo, lo_bits, bits, sh);
+      if (p < np_lo) { digit(p, np_lo, lo_bits, bits, sh); sh += local_bits; }
       else if (p < np) { digit(p - np_lo, np_hi, hi_bits, bits, sh); sh += 63; }
-      else { bits = 0; sh = vbits; }
+      else { bits = 0; sh = vbits + local_bits; }
       st->pass_bits[p] = bits;
       st->pass_shift[p] = sh;
     }
@@ -1007,6 +1014,8 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->colour_in_key = (bare && do_color) ? 1 : 0;
       st->deep = deep ? 1 : 0;
       st->payload2 = !deep ? 0 : (need_index ? 1 : (do_color ? 2 : 0));
+      st->local_bits = local_bits;
+      st->keys_final = (np & 1) ^ (local_bits ? 1 : 0);
       st->npasses = err != kErrNone ? 0 : np;
       st->error = err;
     }
@@ -1045,6 +1054,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         const int q = p - kPlanPass;  // (the plan is only used for single-word codes: np = np_lo)
         int bq = 0, sh = 0;
         digit(q, np_lo, lo_bits, bq, sh);
+        sh += local_bits;
         if (q >= np_lo) bq = 0;
         v = (uint32_t)bq | ((uint32_t)sh << 8);
       } else if (p >= kPlanRanks && p < kPlanRanks + 16) {
@@ -1589,8 +1599,9 @@ __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30)
 
 // (two workgroup shapes, like k_sort_pass: 1024 threads x 4 keys for small grids, 512 x 8 -- two workgroups per CU, one
 // looks back while the other scans -- for the rest)
-template <int THREADS, int ITEMS, bool DEEP = false>
-__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __restrict__ buf_a, const uint64_t* __restrict__ buf_b,
+constexpr uint32_t kLocalGroupMax = 192;  // longest group of equal higher code bits the local fix-up takes on
+template <int THREADS, int ITEMS, bool DEEP = false, bool LOCAL = false>
+__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a, const uint64_t* buf_b, uint64_t* out_a, uint64_t* out_b,
                                                             const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code, uint32_t* __restrict__ leaf_hi,
@@ -1613,6 +1624,79 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
   const uint32_t* highs = (st->npasses & 1) ? idx_b : idx_a;  // DEEP: the codes' high words (the sort's payload)
   const int ibits = st->ibits, depth = st->depth;
   const int lane = lane_id(), wave = wave_id();
+  // ---- LOCAL (experiment): the passes sorted the code bits above `local_bits` only.  Keys with equal higher bits form a
+  // group of consecutive positions; sorting every group by its low bits (ties by position) sorts the array, and moves no
+  // key out of its group's positions.  A tile takes the complete groups that touch its positions [W0 - 1, W1) into LDS (the
+  // key before the tile is needed for the first head flag), ranks every key inside its group by walking the group -- a
+  // cube of 4 x 4 x 4 voxels holds a few dozen points of a surface --, and writes ITS positions of the result to the other
+  // key buffer; neighbouring tiles sort a shared boundary group each for itself, to the same order.
+  const int lbits = LOCAL ? st->local_bits : 0;
+  __shared__ uint64_t s_in[LOCAL ? kSortTile + 2 * kLocalGroupMax + 2 : 1], s_srt[LOCAL ? kSortTile + 2 * kLocalGroupMax + 2 : 1];
+  __shared__ uint32_t s_halo[2];
+  uint32_t win0 = 0;  // global position of s_srt[0]
+  if (LOCAL && lbits > 0) {
+    const uint32_t W0 = tile * kSortTile, W1 = min(W0 + (uint32_t)kSortTile, nfin);
+    const int gshift = ibits + lbits;
+    if (wave == 0) {  // how far the group of position W0 - 1 reaches back, how far the group of position W1 - 1 reaches on
+      uint32_t hb = 0, ha = 0;
+      if (W0 > 0) {
+        const uint64_t g0 = keys[W0 - 1] >> gshift;
+        hb = 1;
+        for (uint32_t r0 = 1; r0 <= kLocalGroupMax; r0 += 64) {  // positions W0 - 1 - (r0 + lane)
+          const uint32_t back = r0 + (uint32_t)lane;
+          const bool same = back < W0 && (keys[W0 - 1 - back] >> gshift) == g0;
+          const uint64_t diff = __ballot(!same);
+          if (diff) { hb += (uint32_t)__ffsll((long long)diff) - 1u; break; }
+          hb += 64u;
+        }
+      }
+      {
+        const uint64_t g1 = keys[W1 - 1] >> gshift;
+        for (uint32_t r0 = 0; r0 <= kLocalGroupMax; r0 += 64) {  // positions W1 + r0 + lane
+          const uint32_t at = W1 + r0 + (uint32_t)lane;
+          const bool same = at < nfin && (keys[at] >> gshift) == g1;
+          const uint64_t diff = __ballot(!same);
+          if (diff) { ha += (uint32_t)__ffsll((long long)diff) - 1u; break; }
+          ha += 64u;
+        }
+      }
+      if (lane == 0) { s_halo[0] = hb; s_halo[1] = ha; }
+    }
+    __syncthreads();
+    const uint32_t hb = s_halo[0], ha = s_halo[1];
+    // (a tile that gives up still tells the tiles behind it not to wait for its sums: the frame is run again anyway)
+    constexpr uint64_t kGiveUp = 2ull << 62;
+    if (hb > kLocalGroupMax || ha > kLocalGroupMax) {  // (uniform) a group too long for this: the frame runs again without
+      if (threadIdx.x == 0) { st->error = kErrLocal; publish_u64(leaf_status + tile, kGiveUp); }
+      return;
+    }
+    win0 = W0 - hb;
+    const uint32_t wn = W1 + ha - win0;
+    for (uint32_t j = threadIdx.x; j < wn; j += THREADS) s_in[j] = keys[win0 + j];
+    __syncthreads();
+    const uint64_t lmask = ((1ull << lbits) - 1ull) << ibits;
+    bool too_long = false;
+    for (uint32_t j = threadIdx.x; j < wn; j += THREADS) {
+      const uint64_t k = s_in[j], g = k >> gshift, low = k & lmask;
+      uint32_t first = j, less = 0, steps = 0;
+      while (first > 0 && (s_in[first - 1] >> gshift) == g) {  // (the window starts and ends at group boundaries)
+        --first;
+        less += (s_in[first] & lmask) <= low ? 1u : 0u;  // earlier position: ties go first
+        if (++steps > 2 * kLocalGroupMax) { too_long = true; break; }
+      }
+      for (uint32_t q = j + 1; q < wn && (s_in[q] >> gshift) == g; ++q) {
+        less += (s_in[q] & lmask) < low ? 1u : 0u;
+        if (++steps > 2 * kLocalGroupMax) { too_long = true; break; }
+      }
+      s_srt[first + less] = k;
+    }
+    if (__syncthreads_or(too_long ? 1 : 0)) {
+      if (threadIdx.x == 0) { st->error = kErrLocal; publish_u64(leaf_status + tile, kGiveUp); }
+      return;
+    }
+    uint64_t* out = (st->npasses & 1) ? out_a : out_b;  // the buffer the last pass did not write
+    for (uint32_t i = W0 + threadIdx.x; i < W1; i += THREADS) out[i] = s_srt[i - win0];
+  }
   // sorted codes whose high part is a cell rank (FrameState::code_low_bits) become Morton codes again here: nothing
   // downstream of this kernel sees a rank
   __shared__ uint64_t s_cell_abs[64];
@@ -1632,6 +1716,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* __rest
   auto code_at = [&](uint32_t i) {  // the code of sorted element i
     CodeT c;
     if (DEEP) code_make(c, keys[i], highs[i]);  // (no index bits, no cell ranks in a deep frame's keys)
+    else if (LOCAL && lbits > 0) code_make(c, unrank(s_srt[i - win0] >> ibits), 0u);  // the fixed-up keys, from LDS
     else code_make(c, unrank(keys[i] >> ibits), 0u);
     return c;
   };
@@ -1898,7 +1983,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
   uint8_t* s_t = reinterpret_cast<uint8_t*>(s_mask + kFinSlots * kMaskStride);
 
-  const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
+  const uint64_t* keys = st->keys_final ? buf_b : buf_a;  // (= the last pass's output, or k_leaf_scan's when it fixed the low bits up)
   const int ibits = st->ibits, D = st->depth;
   const int lane = lane_id(), wave = wave_id();
   IndexOf index_of;
@@ -2728,6 +2813,7 @@ extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
   one("k_sort_pass<512,8,bare>", (const void*)k_sort_pass<512, 8, false, false>, 512);
   one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems, false>, kSortThreads);
   one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8, false>, 512);
+  one("k_leaf_scan<512,8,local>", (const void*)k_leaf_scan<512, 8, false, true>, 512);
   one("k_leaf_tile", (const void*)k_leaf_tile<false>, kFinThreads);
   one("k_leaf_tile<deep>", (const void*)k_leaf_tile<true>, kFinThreads);
   one("k_jpeg_rows", (const void*)k_jpeg_rows, kJpegThreads);
@@ -2763,6 +2849,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   // registers until workgroup 0 has published the sort plan, then write keys and digit counts themselves -- the cloud is
   // read once -- and k_make_keys only visits the chunks that were left alone (normally chunk 0, where the box grows).
   const bool deep = a.deep_launch != 0;  // the DEEP instantiations (two-word codes): a frame deeper than 21 levels came by
+  const bool local_scan = a.local_launch != 0 && !deep && s_tiles > kSortSmallGridTiles;  // local fix-up of the low code bits (experiment)
   const bool bare_sort = a.bare_launch != 0 && !deep && s_tiles > kSortSmallGridTiles;  // payload-free sort passes (experiment)
   const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks && !deep;
   FusedKeys fk{};
@@ -2771,7 +2858,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
     fk.inv_res_pow2 = a.inv_res_pow2; fk.plan_spins = a.plan_spins; fk.do_color = (int)a.lp.do_color;
   }
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, bare_sort ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
+                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, bare_sort ? 1 : 0, local_scan ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
   if (fused)
     hipLaunchKernelGGL((k_make_keys<kBlock, kItems>), dim3(std::min(n_tiles, 64u)), dim3(kBlock), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
@@ -2810,8 +2897,9 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
     PCC_STAMP("k_sort_pass");
   }
 #undef PCC_SORT_ARGS
-#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
-  if (many_tiles && deep) hipLaunchKernelGGL((k_leaf_scan<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
+#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
+  if (many_tiles && local_scan) hipLaunchKernelGGL((k_leaf_scan<512, 8, false, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
+  else if (many_tiles && deep) hipLaunchKernelGGL((k_leaf_scan<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
   else if (many_tiles) hipLaunchKernelGGL((k_leaf_scan<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
   else if (deep) hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems, true>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SCAN_ARGS);
   else hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems, false>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SCAN_ARGS);

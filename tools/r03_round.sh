@@ -27,6 +27,9 @@ bash tools/ab_probe.sh $TAG/ab_sortxcd PCC_SORT_XCD 16 0 cfg2 > $OUT/ab_sortxcd.
 bash tools/ab_probe.sh $TAG/ab_sortxcd4 PCC_SORT_XCD 16 0 cfg4 > $OUT/ab_sortxcd_cfg4.txt 2>&1; tail -24 $OUT/ab_sortxcd_cfg4.txt
 # ---- A/B: payload-free sort passes, three tiles per CU (an experiment, off by default)
 bash tools/ab_probe.sh $TAG/ab_sortbare PCC_SORT_BARE - 1 cfg2 > $OUT/ab_sortbare.txt 2>&1; tail -24 $OUT/ab_sortbare.txt
+# ---- A/B: local fix-up of the low code bits in the leaf scan, one global sort pass fewer (an experiment, off by default)
+bash tools/ab_probe.sh $TAG/ab_sortlocal PCC_SORT_LOCAL - 1 cfg2 > $OUT/ab_sortlocal.txt 2>&1; tail -24 $OUT/ab_sortlocal.txt
+bash tools/ab_probe.sh $TAG/ab_sortlocal4 PCC_SORT_LOCAL - 1 cfg4 > $OUT/ab_sortlocal_cfg4.txt 2>&1; tail -24 $OUT/ab_sortlocal_cfg4.txt
 # ---- the shfl build of the wave helpers against the DPP one
 if [ -f cwi-pcl-codec_amd/libpcc_hip_shfl.so ]; then
   bash tools/ab_probe.sh $TAG/ab_shfl PCC_LIB $PWD/cwi-pcl-codec_amd/libpcc_hip.so $PWD/cwi-pcl-codec_amd/libpcc_hip_shfl.so cfg2 > $OUT/ab_shfl.txt 2>&1; tail -24 $OUT/ab_shfl.txt
