@@ -1675,20 +1675,65 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
     for (uint32_t j = threadIdx.x; j < wn; j += THREADS) s_in[j] = keys[win0 + j];
     __syncthreads();
     const uint64_t lmask = ((1ull << lbits) - 1ull) << ibits;
+    // Every thread takes kPer consecutive window positions.  The ends of a key's group are the nearest group boundaries to
+    // its left and right: a running maximum of "a group starts here" positions from the left and a running minimum from the
+    // right, carried across the threads by two block-wide scans -- so that the ranking loop below knows its bounds up front
+    // and its LDS reads do not hang on each other (a walk that looks at a key to decide whether to go on is a chain of
+    // LDS latencies).
+    constexpr uint32_t kPer = (kSortTile + 2 * kLocalGroupMax + 2 + THREADS - 1) / THREADS;
+    __shared__ uint32_t s_bnd[2][NW];
+    const uint32_t p0 = threadIdx.x * kPer;
+    uint64_t mine[kPer];
+    uint32_t gfirst[kPer], glast[kPer];
+    uint32_t run_first = 0u, run_last = 0xffffffffu;  // last group start at or before / first group end at or behind, inside this thread's span
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+      const uint32_t j = p0 + k;
+      mine[k] = j < wn ? s_in[j] : ~0ull;
+      const bool starts = j < wn && (j == 0 || (s_in[j - 1] >> gshift) != (mine[k] >> gshift));
+      if (starts) run_first = j + 1u;  // (+ 1: 0 = none in this span)
+      gfirst[k] = run_first;
+    }
+#pragma unroll
+    for (int k = (int)kPer - 1; k >= 0; --k) {
+      const uint32_t j = p0 + (uint32_t)k;
+      const bool ends = j < wn && (j + 1 == wn || (s_in[j + 1] >> gshift) != (mine[k] >> gshift));
+      if (ends) run_last = j;
+      glast[k] = run_last;
+    }
+    // carry in: the latest group start of the threads before, the earliest group end of the threads behind
+    const uint32_t incl_first = wave_scan_u32(run_first, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+    // (a scan from the right = a scan from the left over the mirrored lanes)
+    const uint32_t mirrored = (uint32_t)__shfl((int)run_last, 63 - lane);
+    const uint32_t incl_last_m = wave_scan_u32(mirrored, 0xffffffffu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+    const uint32_t incl_last = (uint32_t)__shfl((int)incl_last_m, 63 - lane);
+    if (lane == 63) s_bnd[0][wave] = incl_first;
+    if (lane == 0) s_bnd[1][wave] = incl_last;
+    __syncthreads();
+    uint32_t before_first = 0u, behind_last = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      if (w < wave) before_first = max(before_first, s_bnd[0][w]);
+      if (w > wave) behind_last = min(behind_last, s_bnd[1][w]);
+    }
+    const uint32_t lane_before = max(before_first, wave_shr1_u32(incl_first, 0u) * (lane ? 1u : 0u));
+    uint32_t lane_behind = (uint32_t)__shfl((int)incl_last, lane + 1 < 64 ? lane + 1 : 63);
+    lane_behind = min(behind_last, lane == 63 ? 0xffffffffu : lane_behind);
     bool too_long = false;
-    for (uint32_t j = threadIdx.x; j < wn; j += THREADS) {
-      const uint64_t k = s_in[j], g = k >> gshift, low = k & lmask;
-      uint32_t first = j, less = 0, steps = 0;
-      while (first > 0 && (s_in[first - 1] >> gshift) == g) {  // (the window starts and ends at group boundaries)
-        --first;
-        less += (s_in[first] & lmask) <= low ? 1u : 0u;  // earlier position: ties go first
-        if (++steps > 2 * kLocalGroupMax) { too_long = true; break; }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+      const uint32_t j = p0 + k;
+      if (j >= wn) continue;
+      const uint32_t first = (gfirst[k] ? gfirst[k] : lane_before) - 1u;  // (a window starts at a group start: never "none")
+      const uint32_t last = glast[k] != 0xffffffffu ? glast[k] : lane_behind;
+      const uint64_t low = mine[k] & lmask;
+      if (last - first >= 2u * kLocalGroupMax) { too_long = true; continue; }
+      uint32_t less = 0;
+      for (uint32_t q = first; q <= last; ++q) {
+        const uint64_t o = s_in[q] & lmask;
+        less += (o < low || (o == low && q < j)) ? 1u : 0u;
       }
-      for (uint32_t q = j + 1; q < wn && (s_in[q] >> gshift) == g; ++q) {
-        less += (s_in[q] & lmask) < low ? 1u : 0u;
-        if (++steps > 2 * kLocalGroupMax) { too_long = true; break; }
-      }
-      s_srt[first + less] = k;
+      s_srt[first + less] = mine[k];
     }
     if (__syncthreads_or(too_long ? 1 : 0)) {
       if (threadIdx.x == 0) { st->error = kErrLocal; publish_u64(leaf_status + tile, kGiveUp); }
