@@ -87,8 +87,8 @@ struct FrameState {
                                      // mode), 2 the point's colour word (packed mode with colour: no gather later)
   int32_t colour_in_key;             // 1: the low 24 key bits (ibits = 24) are the point's colour, no payload, no index
   int32_t local_bits;                // > 0 (experiment, PCC_SORT_LOCAL): the sort passes leave the lowest local_bits code bits alone and
-                                     // k_leaf_scan sorts every group of equal higher bits in LDS (and writes the keys to the other buffer)
-  int32_t keys_final;                // which key buffer holds the fully sorted keys behind k_leaf_scan: 0 = a, 1 = b
+                                     // k_leaf_scan sorts every group of equal higher bits in LDS (and writes the sorted colour words to idx_a)
+  int32_t keys_final;                // which key buffer the last sort pass wrote: 0 = a, 1 = b
   int32_t deep;                      // 1: two-word codes (depth > kMaxDepth): key = low 63 code bits, payload = 3: the high code bits
   int32_t payload2;                  // deep only, the second payload array: 0 nothing, 1 point index, 2 the point's colour word
   // cell ranks: the code that is SORTED may be shorter than the 3 * vbits_axis varying Morton bits.  A cloud that

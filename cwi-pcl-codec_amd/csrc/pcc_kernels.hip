@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->deep = deep ? 1 : 0;
       st->payload2 = !deep ? 0 : (need_index ? 1 : (do_color ? 2 : 0));
       st->local_bits = local_bits;
-      st->keys_final = (np & 1) ^ (local_bits ? 1 : 0);
+      st->keys_final = np & 1;  // (with local_bits the keys in that buffer are sorted by their higher bits only: k_leaf_tile reads none of them)
       st->npasses = err != kErrNone ? 0 : np;
       st->error = err;
     }
@@ -1601,7 +1601,7 @@ __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30)
 // looks back while the other scans -- for the rest)
 constexpr uint32_t kLocalGroupMax = 192;  // longest group of equal higher code bits the local fix-up takes on
 template <int THREADS, int ITEMS, bool DEEP = false, bool LOCAL = false>
-__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a, const uint64_t* buf_b, uint64_t* out_a, uint64_t* out_b,
+__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a, const uint64_t* buf_b, uint32_t* colour_out,
                                                             const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code, uint32_t* __restrict__ leaf_hi,
@@ -1627,9 +1627,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
   // ---- LOCAL (experiment): the passes sorted the code bits above `local_bits` only.  Keys with equal higher bits form a
   // group of consecutive positions; sorting every group by its low bits (ties by position) sorts the array, and moves no
   // key out of its group's positions.  A tile takes the complete groups that touch its positions [W0 - 1, W1) into LDS (the
-  // key before the tile is needed for the first head flag), ranks every key inside its group by walking the group -- a
-  // cube of 4 x 4 x 4 voxels holds a few dozen points of a surface --, and writes ITS positions of the result to the other
-  // key buffer; neighbouring tiles sort a shared boundary group each for itself, to the same order.
+  // key before the tile is needed for the first head flag), ranks every key inside its group -- a cube of 4 x 4 x 4 voxels
+  // holds a few dozen points of a surface --, and writes ITS positions of the neighbouring tiles sort a shared boundary group each for itself, to the same order.
   const int lbits = LOCAL ? st->local_bits : 0;
   __shared__ uint64_t s_in[LOCAL ? kSortTile + 2 * kLocalGroupMax + 2 : 1], s_srt[LOCAL ? kSortTile + 2 * kLocalGroupMax + 2 : 1];
   __shared__ uint32_t s_halo[2];
@@ -1739,8 +1738,10 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
       if (threadIdx.x == 0) { st->error = kErrLocal; publish_u64(leaf_status + tile, kGiveUp); }
       return;
     }
-    uint64_t* out = (st->npasses & 1) ? out_a : out_b;  // the buffer the last pass did not write
-    for (uint32_t i = W0 + threadIdx.x; i < W1; i += THREADS) out[i] = s_srt[i - win0];
+    // What k_leaf_tile reads of the sorted keys in this mode (bare keys: nobody needs a point index) is each point's colour:
+    // the low 24 key bits go out as 4-byte words (the sort's unused payload array); a geometry-only frame writes nothing.
+    if (st->colour_in_key)
+      for (uint32_t i = W0 + threadIdx.x; i < W1; i += THREADS) colour_out[i] = (uint32_t)s_srt[i - win0] & 0xffffffu;
   }
   // sorted codes whose high part is a cell rank (FrameState::code_low_bits) become Morton codes again here: nothing
   // downstream of this kernel sees a rank
@@ -2037,8 +2038,9 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   const uint32_t* pay2_sorted = (st->npasses & 1) ? idx2_b : idx2_a;
   index_of.idx = st->payload == 1 ? pay_sorted : ((DEEP && st->payload2 == 1) ? pay2_sorted : nullptr);
   index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
-  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : ((DEEP && st->payload2 == 2) ? pay2_sorted : nullptr);
-  const uint64_t* colour_keys = st->colour_in_key ? keys : nullptr;
+  const bool local_colours = !DEEP && st->local_bits > 0 && st->colour_in_key;  // (k_leaf_scan<LOCAL> wrote the sorted colour words to idx_a)
+  const uint32_t* colour_pay = local_colours ? idx_a : (st->payload == 2 ? pay_sorted : ((DEEP && st->payload2 == 2) ? pay2_sorted : nullptr));
+  const uint64_t* colour_keys = (st->colour_in_key && !local_colours) ? keys : nullptr;
   auto leaf_code_at = [&](uint32_t j) { CodeT c; code_make(c, leaf_code[j], DEEP ? leaf_hi[j] : 0u); return c; };
 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
@@ -2942,7 +2944,7 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
     PCC_STAMP("k_sort_pass");
   }
 #undef PCC_SORT_ARGS
-#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
+#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.idx_a, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
   if (many_tiles && local_scan) hipLaunchKernelGGL((k_leaf_scan<512, 8, false, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
   else if (many_tiles && deep) hipLaunchKernelGGL((k_leaf_scan<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
   else if (many_tiles) hipLaunchKernelGGL((k_leaf_scan<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
