@@ -102,7 +102,8 @@ struct pcc_ctx {
   uint32_t frame_seq = 0;     // sequence number of the last enqueued frame; stamps its chunk boxes
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
-  DevBuf<uint32_t> d_hist_rows, d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
+  DevBuf<uint16_t> d_hist_rows;
+  DevBuf<uint32_t> d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint32_t> d_idx2_a, d_idx2_b, d_leaf_hi;  // trees deeper than 21 levels only (two-word codes): allocated when one comes by
   bool deep_hint = false;                          // the frame before was one: enqueue the deep kernels straight away
   bool local_off = false;                          // a frame came by whose groups were too long for the local fix-up (PCC_SORT_LOCAL only)

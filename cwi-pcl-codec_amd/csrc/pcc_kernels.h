@@ -88,7 +88,7 @@ struct HotPathArgs {
   uint32_t* idx2_a;    // deep only: second payload of the sort (point index or colour word), ping-pong
   uint32_t* idx2_b;
   uint32_t* leaf_hi;   // deep only: high word of each leaf's code
-  uint32_t* hist_rows;  // [sort tiles][kMaxPasses][kMaxBins] digit counts from k_make_keys
+  uint16_t* hist_rows;  // [sort tiles or chunks][kMaxPasses][kMaxBins] digit counts (at most 4096 each) from the key makers
   uint32_t* digit_tot;  // [kMaxPasses][kMaxBins]
   uint32_t* tile_prefix0;  // [sort tiles][kMaxBins] exclusive tile prefix of the pass-0 digit counts
   uint8_t* sync_area;   // tickets | leaf scan status | sort status (sync_area_bytes), zeroed by k_boxes_events

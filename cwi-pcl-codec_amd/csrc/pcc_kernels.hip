@@ -379,7 +379,7 @@ struct FusedKeys {
   uint64_t* plan;        // kPlanGranules plan granules, then one granule per chunk
   uint64_t* keys;
   uint32_t* idx;
-  uint32_t* hist_rows;   // one row of kMaxPasses x kMaxBins digit counts per CHUNK in this mode
+  uint16_t* hist_rows;   // one row of kMaxPasses x kMaxBins digit counts per CHUNK in this mode (a count is at most 4096: 16 bits)
   double inv_res_pow2;
   uint32_t plan_spins;   // polls of the plan before a workgroup gives up and leaves its chunk to k_make_keys
   int do_color;
@@ -560,8 +560,8 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     fk.keys[i] = key;
   }
   __syncthreads();
-  uint32_t* row = fk.hist_rows + (size_t)c * kMaxPasses * kMaxBins;
-  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) row[k] = s_hist[k];
+  uint16_t* row = fk.hist_rows + (size_t)c * kMaxPasses * kMaxBins;
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) row[k] = (uint16_t)s_hist[k];
   if (threadIdx.x == 0) publish_u64(fk.plan + kPlanGranules + c, ((uint64_t)seq << 32) | (s_plan[kPlanWords + 1] ? 2u : 1u));
 }
 
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
 template <int kKeyThreads, int KEY_ITEMS>
 __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ idx2, uint32_t* __restrict__ hist_rows,
+                                                            uint32_t* __restrict__ idx, uint32_t* __restrict__ idx2, uint16_t* __restrict__ hist_rows,
                                                             const uint64_t* __restrict__ chunk_state, uint32_t seq, unsigned long long* span) {
   const KSpan kspan(span);
   constexpr int kKeyTile = kKeyThreads * KEY_ITEMS;
@@ -1155,8 +1155,8 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
     keys[i] = key;
   }
   __syncthreads();
-  uint32_t* row = hist_rows + (size_t)tile * kMaxPasses * kMaxBins;
-  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) row[k] = (&s_h[0][0])[k];
+  uint16_t* row = hist_rows + (size_t)tile * kMaxPasses * kMaxBins;  // (a tile has at most 4096 keys: a count fits 16 bits)
+  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) row[k] = (uint16_t)(&s_h[0][0])[k];
   }
 }
 
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
 constexpr uint32_t kDtCols = 16;
 template <uint32_t kDtThreads>
 __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows, uint32_t rows_per_tile,
-                                                       const uint32_t* __restrict__ hist_rows,
+                                                       const uint16_t* __restrict__ hist_rows,
                                                        uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0, unsigned long long* span) {
   const KSpan kspan(span);
   constexpr uint32_t kDtGroups = kDtThreads / kDtCols;
