@@ -113,6 +113,22 @@ def test_bench_script_runs_end_to_end_on_the_executor(emu_libs):
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
 
 
+def test_bench_script_with_two_ranks_on_the_executor(emu_libs):
+    """The N > 1 path of bench.py (one process per GPU under torch.distributed.run, barrier, maximum over the ranks, rank 0
+    prints the whole-job line) with both ranks on the executor and gloo carrying the collectives (PCC_BENCH_SHARE_GPU0=1)."""
+    import json
+    env = dict(os.environ, PCC_BENCH_SHARE_GPU0="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29581", os.path.join(EMU, "bench_on_executor.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-host-input"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3
+    assert line["config"]["frames_per_gpu"] == 3 and line["value"] > 0
+
+
 def test_product_library_has_no_cpu_fallback(pkg):
     """The library the product loads (libpcc_hip.so) refuses to work without a HIP device; the executor is only ever
     reached through an explicit PCC_LIB."""
