@@ -62,7 +62,7 @@ def parse():
 def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
     # no centroids in the bench workloads: the sort key is [code | colour] or the code alone, 8 bytes, no payload array
     col = 4 if with_color else 0
-    fused = os.environ.get("PCC_FUSED_KEYS", "1") != "0" and (n + 2047) // 2048 <= 1024
+    fused = os.environ.get("PCC_FUSED_KEYS", "0") != "0" and (n + 2047) // 2048 <= 1024
     if name == "k_boxes_events":           # fused mode: the streaming workgroups also write the keys (the cloud is read once)
         return (16 + col) * n + 8 * n if fused else 16 * n   # x,y,z(,w) (+ colour word) of every point (+ key out)
     if name == "k_make_keys":              # fused mode: only the chunk that holds the growth events is visited
@@ -108,6 +108,10 @@ def default_workers(world):
 
 def main():
     args = parse()
+    # before anything else: what is about to be measured?  Exits unless the gfx950 library is what the binding loads
+    # (PCC_LIB can point it at the CPU executor's build of the same sources, or at a developer build)
+    import __graft_entry__ as G
+    library = G.load_package().binding.require_product_library("bench.py")
     cgroup_throttled()  # first use here, long before the pipeline's threads exist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,8 +244,22 @@ def main():
                                        ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
     trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
-    entropy_mode_timed = pipe.last_entropy_mode()   # option "entropy_on_gpu" is -1: decided per call from a cost estimate
+    entropy_mode_timed = pipe.last_entropy_mode()   # (option "entropy_on_gpu": 0 host, the default; 1 GPU; -1 decided per call from a cost estimate)
     ktimes, profiled = pipe.kernel_times()
+    # fused front end (PCC_FUSED_KEYS=1, off by default): chunks of each context's LAST frame of the timed call whose wait for
+    # the plan ran out and that k_make_keys had to visit -- with frames in flight the grid is not resident as a whole
+    fused_fallback = None
+    if os.environ.get("PCC_FUSED_KEYS", "0") != "0":
+        import ctypes
+        lib_ = b.load_library()
+        lib_.pcc_debug_fused_chunks.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        fused_fallback = {"contexts": 0, "chunks": 0, "left_to_k_make_keys": 0}
+        for w in range(pipe.n_contexts):
+            o3 = (ctypes.c_uint32 * 3)()
+            if lib_.pcc_debug_fused_chunks(pipe.context(w).h, o3) == 0 and o3[2]:
+                fused_fallback["contexts"] += 1
+                fused_fallback["chunks"] += int(o3[1])
+                fused_fallback["left_to_k_make_keys"] += int(o3[1] - o3[0])
     for c in prof_ctxs:
         c.set_profiling(False)
     if dist is not None:
@@ -444,6 +462,10 @@ def main():
                               "host_frames_per_s_bound": (round(default_workers(world) / (stats["entropy_cpu_us"] * 1e-6), 0)
                                                           if stats["entropy_cpu_us"] > 0 and not entropy_mode_timed else None),
                               "gpu_stage_frames_per_s": round(gpu_only_fps, 0)},
+            # a call of few frames cannot be shorter than the frames one entropy thread codes one after the other
+            "short_call_floor_ms": round(-(-args.steps // max(pipe.workers, 1)) * stats["entropy_us"] / 1e3, 3),
+            "library": library,
+            "fused_fallback_chunks": fused_fallback,
             "cgroup_throttled_ms_in_timed_region": throttled_ms,
             "warmup_frames_run": warm + args.steps * int(os.environ.get("PCC_BENCH_SHAPE_WARMUP", "1")),
             "cpu_baseline": cpu_baseline,

@@ -119,6 +119,25 @@ class KernelTimes(C.Structure):
 
 _lib = None
 
+PRODUCT_VERSION = "pcc_hip 0.1 (gfx950)"
+
+
+def library_identity():
+    """What is loaded: {"file": basename, "version": pcc_version()}.  Goes into bench.py's line."""
+    lib = load_library()
+    return {"file": os.path.basename(LIB_PATH), "version": lib.pcc_version().decode()}
+
+
+def require_product_library(who):
+    """bench.py and smoke() measure / check the gfx950 library and nothing else: PCC_LIB can point the binding at the CPU
+    executor's build of the same sources (tests) or at a developer build -- numbers from those are not the product's.
+    PCC_ALLOW_NON_PRODUCT_LIB=1 (set by tests/emu/bench_on_executor.py and the A/B tools) lifts the refusal; the identity
+    is reported either way."""
+    ident = library_identity()
+    if ident["version"] != PRODUCT_VERSION and os.environ.get("PCC_ALLOW_NON_PRODUCT_LIB") != "1":
+        raise SystemExit("%s: refusing to run on %s (%s): not the gfx950 product library" % (who, ident["file"], ident["version"]))
+    return ident
+
 
 def load_library():
     """Load libpcc_hip.so; raises (never falls back) if it has not been built."""

@@ -377,7 +377,20 @@ struct pcc_upload_lane {
 
 extern "C" {
 
-const char* pcc_version(void) { return "pcc_hip 0.1 (gfx950)"; }
+// What this binary is: the product says gfx950; the same sources compiled for the CPU wave64 executor of tests/emu say so
+// too (bench.py and smoke() refuse a library that is not the gfx950 one: a line timed on the executor must not be
+// mistaken for a measurement), and so do the developer builds.
+const char* pcc_version(void) {
+#if defined(PCC_EMU)
+  return "pcc_emu 0.1 (CPU wave64 executor: test infrastructure, not the product)";
+#elif defined(PCC_WAVE_OPS_SHFL)
+  return "pcc_hip 0.1 (gfx950, shfl bisect build)";
+#elif defined(PCC_KTIME)
+  return "pcc_hip 0.1 (gfx950, ktime developer build)";
+#else
+  return "pcc_hip 0.1 (gfx950)";
+#endif
+}
 
 pcc_ctx* pcc_create(int device) {
   int count = 0;
@@ -583,9 +596,12 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   }
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   {
-    // PCC_FUSED_KEYS=0: the two-kernel form (k_boxes_events reads the coordinates, k_make_keys reads the cloud again);
+    // The two-kernel form (k_boxes_events reads the coordinates, k_make_keys reads the cloud again) is the default: it has
+    // run on the chip.  PCC_FUSED_KEYS=1: the streaming workgroups wait for workgroup 0's plan and write the keys themselves
+    // (the cloud is read once) -- off until it has been timed on an MI355X with ten frames in flight, where the grid is not
+    // resident as a whole and a late chunk idles on its CU for up to plan_spins before it falls back.
     // PCC_PLAN_SPINS: how long a streaming workgroup waits for the plan (test hook: 1 = every chunk falls back)
-    static const int fused_env = [] { const char* e = getenv("PCC_FUSED_KEYS"); return e ? atoi(e) : 1; }();
+    static const int fused_env = [] { const char* e = getenv("PCC_FUSED_KEYS"); return e ? atoi(e) : 0; }();
     static const int spins_env = [] { const char* e = getenv("PCC_PLAN_SPINS"); return e ? atoi(e) : 0; }();
     a.fused_keys = fused_env ? 1 : 0;
     a.plan = ctx->d_plan.p;

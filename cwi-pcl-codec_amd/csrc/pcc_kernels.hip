@@ -2896,8 +2896,15 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   // registers until workgroup 0 has published the sort plan, then write keys and digit counts themselves -- the cloud is
   // read once -- and k_make_keys only visits the chunks that were left alone (normally chunk 0, where the box grows).
   const bool deep = a.deep_launch != 0;  // the DEEP instantiations (two-word codes): a frame deeper than 21 levels came by
-  const bool local_scan = a.local_launch != 0 && !deep && s_tiles > kSortSmallGridTiles;  // local fix-up of the low code bits (experiment)
-  const bool bare_sort = a.bare_launch != 0 && !deep && s_tiles > kSortSmallGridTiles;  // payload-free sort passes (experiment)
+  static const int forced_shape = [] {  // developer knob: PCC_SORT_SHAPE=narrow|wide
+    const char* e = getenv("PCC_SORT_SHAPE");
+    return !e ? 0 : (!strcmp(e, "narrow") ? 1 : (!strcmp(e, "wide") ? 2 : 0));
+  }();
+  const bool many_tiles = forced_shape ? forced_shape == 1 : s_tiles > kSortSmallGridTiles;
+  // both experiments exist in the narrow (512 x 8) shape only: derived from the shape that is launched, so that what
+  // k_boxes_events is told about the sort is what the kernels after it do
+  const bool local_scan = a.local_launch != 0 && !deep && many_tiles;  // local fix-up of the low code bits (experiment)
+  const bool bare_sort = a.bare_launch != 0 && !deep && many_tiles;    // payload-free sort passes (experiment)
   const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks && !deep;
   FusedKeys fk{};
   if (fused) {
@@ -2925,14 +2932,11 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   // Few tiles (every tile has a CU to itself): 16 waves share a tile's latency-bound steps.  Many tiles: 8 waves with
   // twice the keys per thread need 62 KB of LDS instead of 87 KB, so two tiles share a CU and one loads or waits for
   // its predecessors while the other ranks and writes.
-  static const int forced_shape = [] {  // developer knob: PCC_SORT_SHAPE=narrow|wide
-    const char* e = getenv("PCC_SORT_SHAPE");
-    return !e ? 0 : (!strcmp(e, "narrow") ? 1 : (!strcmp(e, "wide") ? 2 : 0));
-  }();
-  const bool many_tiles = forced_shape ? forced_shape == 1 : s_tiles > kSortSmallGridTiles;
-  // PCC_SORT_XCD=0: one ticket counter for all workgroups of a pass (round 2's form); default: XCD-aware tickets, chunks of
-  // 16 tiles (one look-back group) when every XCD gets at least two chunks' worth of tiles
-  static const int xcd_env = [] { const char* e = getenv("PCC_SORT_XCD"); return e ? atoi(e) : 16; }();
+  // One ticket counter for all workgroups of a pass (round 2's form, the one that has run on the chip) is the default:
+  // a tile then only ever waits for tiles that have started.  PCC_SORT_XCD=16: XCD-aware tickets, chunks of 16 tiles (one
+  // look-back group) when every XCD gets at least two chunks' worth of tiles -- off until it has been timed on an MI355X
+  // with other streams' workgroups filling some XCDs (the lowest unstarted tile then waits for a workgroup on ITS XCD)
+  static const int xcd_env = [] { const char* e = getenv("PCC_SORT_XCD"); return e ? atoi(e) : 0; }();
   const int xcd_chunk = (xcd_env > 0 && s_tiles >= 32u) ? xcd_env : 0;
 #define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, xcd_chunk, span("k_sort_pass")
   for (int pass = 0; pass < passes; ++pass) {

@@ -71,11 +71,13 @@ struct pcc_pipeline {
   // Opt-in (pcc_pipeline_set_option "entropy_on_gpu"): the range coders run on the GPU, one wave per stream, in batches of
   // `gpu_batch` frames per entropy thread -- for hosts with fewer cores than the GPU stage can feed.
   bool entropy_on_gpu = false;   // what the job at hand uses (decided when the job starts)
-  // -1 (default): decided per call from a cost estimate -- the host coders need ~1.5 ns of one core per symbol, a flush of
-  // the device coder ~110 ns per symbol of its longest stream however many streams it holds: a long call on a host with
-  // few cores per GPU goes to the GPU, everything else stays on the host; 0 / 1: forced (option "entropy_on_gpu",
-  // PCC_PIPELINE_ENTROPY=host|gpu|auto)
-  int entropy_mode = -1;
+  // 0 (default): the host coders, whose cost on this path has been measured.  1: forced to the GPU.  -1 ("auto"): decided
+  // per call from a cost estimate -- the host coders need ~1.5 ns of one core per symbol, a flush of the device coder
+  // ~110 ns per symbol of its longest stream however many streams it holds: a long call on a host with few cores per GPU
+  // goes to the GPU.  Both constants are round-2 figures of one box; auto stays opt-in until they are calibrated where
+  // the pipeline runs (option "entropy_on_gpu", PCC_PIPELINE_ENTROPY=host|gpu|auto)
+  int entropy_mode = 0;
+  size_t pin_cores_taken = 0;  // of g_pin_cores_taken, given back when the pipeline is destroyed
   int gpu_batch = 256;
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
   int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
@@ -523,14 +525,20 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     int mode = (span >= 2 * (size_t)p->n_entropy) ? 2 : 0;  // 0 none, 1 cores, 2 groups
     if (e) mode = !strcmp(e, "cores") ? 1 : (!strcmp(e, "groups") ? 2 : 0);
     const size_t per = mode == 2 ? std::min<size_t>(8, std::max<size_t>(1, span / (size_t)std::max(p->n_entropy, 1))) : 1;
-    size_t off = pin_offset_hint > 0 ? (size_t)pin_offset_hint : 0;
-    if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) off = (size_t)std::max(atoi(o), 0);
-    else if (pin_span_hint == 0 && mode) off = rank_base + g_pin_cores_taken.fetch_add((size_t)p->n_entropy * per) % span;
+    // the range [base, base + span) of the allowed cores is this pipeline's (the caller's, or this rank's share); `start`
+    // is where inside it the first entropy thread goes -- behind the cores of earlier pipelines of this process, wrapping
+    // INSIDE the range (a second pipeline of one rank must not land on the next rank's cores)
+    size_t base = pin_offset_hint > 0 ? (size_t)pin_offset_hint : rank_base, start = 0;
+    if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) base = (size_t)std::max(atoi(o), 0);
+    else if (pin_span_hint == 0 && mode) {
+      p->pin_cores_taken = (size_t)p->n_entropy * per;
+      start = g_pin_cores_taken.fetch_add(p->pin_cores_taken) % span;
+    }
     if (mode && !cores.empty()) {
       for (int w = 0; w < p->n_entropy; ++w) {
         cpu_set_t set;
         CPU_ZERO(&set);
-        for (size_t k = 0; k < per; ++k) CPU_SET(cores[(off + ((size_t)w * per + k) % span) % cores.size()], &set);
+        for (size_t k = 0; k < per; ++k) CPU_SET(cores[(base + (start + (size_t)w * per + k) % span) % cores.size()], &set);
         (void)pthread_setaffinity_np(p->threads[(size_t)p->n_gpu + w].native_handle(), sizeof(set), &set);
       }
     }
@@ -551,6 +559,7 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   pcc_upload_lane_destroy(p->lane);
   for (pcc_stream* st : p->gpu_streams) pcc_stream_destroy(st);
   free(p->arena);
+  if (p->pin_cores_taken) g_pin_cores_taken.fetch_sub(p->pin_cores_taken);  // the next pipeline of this process may have them
   delete p;
 }
 
@@ -576,7 +585,11 @@ int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
   return PCC_OK;
 }
 
-int pcc_pipeline_last_entropy_mode(pcc_pipeline* p) { return p && p->entropy_on_gpu ? 1 : 0; }
+int pcc_pipeline_last_entropy_mode(pcc_pipeline* p) {
+  if (!p) return 0;
+  std::lock_guard<std::mutex> lk(p->mu);
+  return p->entropy_on_gpu ? 1 : 0;
+}
 int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }
 int pcc_pipeline_contexts(pcc_pipeline* p) { return p ? (int)p->ctxs.size() : 0; }
 

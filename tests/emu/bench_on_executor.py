@@ -10,6 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("PCC_LIB", os.path.join(ROOT, "tests", "emu", "_build", "libpcc_emu.so"))
+os.environ["PCC_ALLOW_NON_PRODUCT_LIB"] = "1"   # bench.py refuses anything but the gfx950 library otherwise; its line names the library
 import torch  # noqa: E402
 
 torch.cuda.is_available = lambda: True

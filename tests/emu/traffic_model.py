@@ -3,7 +3,7 @@
 a MODEL of the access pattern of the kernels as written, not a measurement:
 
     make -C tests/emu traffic
-    python tests/emu/traffic_model.py [workload] [frame]          # e.g. cfg2; PCC_FUSED_KEYS=0 PCC_LEAF_PROBES=uniform for round 2's form
+    python tests/emu/traffic_model.py [workload] [frame]          # e.g. cfg2; PCC_FUSED_KEYS=1 for the fused front end, PCC_LEAF_PROBES=uniform for round 2's probes
 
 requested = bytes the lanes asked for; first-touch = 128-byte lines touched for the first time in the launch by the workgroups
 of one XCD (workgroup b -> XCD b mod 8), times 128: what has to cross an XCD's L2 at least, with L2s of unlimited size that
@@ -46,7 +46,7 @@ for line in buf.value.decode().splitlines():
 N, L, B = len(pts), hot.n_leaves, hot.n_branches
 with_color = cfg["color_bits"] > 0
 alg = 32 * N + L * ((3 if with_color else 0) + 16) + B
-form = "fused keys %s, probes %s" % (os.environ.get("PCC_FUSED_KEYS", "1"), os.environ.get("PCC_LEAF_PROBES", "geometric"))
+form = "fused keys %s, probes %s" % (os.environ.get("PCC_FUSED_KEYS", "0"), os.environ.get("PCC_LEAF_PROBES", "geometric"))
 print("%s frame %d: N=%d L=%d B=%d D=%d   (%s)   algorithmic bytes of the path %.1f MB" % (wl, frame, N, L, B, hot.depth, form, alg / 1e6))
 print("%-18s %8s %14s %14s %16s %16s" % ("kernel", "launches", "requested read", "requested write", "first-touch read", "first-touch write"))
 for name, launches, v in rows:

@@ -29,12 +29,40 @@ def test_gpus_without_a_gpu_fails_loudly():
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
 
 
+def test_bench_and_smoke_refuse_the_executor_library():
+    """PCC_LIB can point the binding at the CPU executor's build of the product's sources (tests/emu) or at a developer
+    build: bench.py exits non-zero before it measures anything, and smoke() raises, unless the library that is loaded says
+    it is the gfx950 one -- a line produced on the executor must not be mistaken for a measurement.  (The refusal comes
+    before the check for a GPU, so it is testable here.)"""
+    emu = os.path.join(ROOT, "tests", "emu", "_build", "libpcc_emu.so")
+    if not os.path.exists(emu):
+        assert subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tests", "emu")]).returncode == 0
+    for lib in (emu, os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip_shfl.so")):
+        if not os.path.exists(lib):
+            continue
+        e = dict(os.environ, PCC_LIB=lib)
+        e.pop("PCC_ALLOW_NON_PRODUCT_LIB", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+        assert r.returncode != 0 and "not the gfx950 product library" in r.stderr and "{" not in r.stdout, (r.stdout, r.stderr)
+        r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as G; G.smoke()"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+        assert r.returncode != 0 and "not the gfx950 product library" in r.stderr and "smoke ok" not in r.stdout, (r.stdout, r.stderr)
+    # the product library itself says what it is
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip.so"))
+    lib.pcc_version.restype = ctypes.c_char_p
+    assert lib.pcc_version() == b"pcc_hip 0.1 (gfx950)"
+    lib = ctypes.CDLL(emu)
+    lib.pcc_version.restype = ctypes.c_char_p
+    assert lib.pcc_version().startswith(b"pcc_emu")
+
+
 @pytest.mark.gpu
 def test_one_line_with_roofline_host_input_and_cpu_baseline():
     d = _run(["--steps", "64", "--warmup", "4", "--cpu-frames", "2", "--host-frames", "32"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "host_input"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "host_input", "library", "short_call_floor_ms"):
         assert k in d, k
+    assert d["library"] == {"file": "libpcc_hip.so", "version": "pcc_hip 0.1 (gfx950)"}
     assert d["n_gpus"] == 1 and d["steps"] == 64 and d["value"] > 0 and d["unit"] == "Mpoints/s" and d["vs_baseline"] is None
     r = d["roofline"]
     assert r["kernel"] == "k_sort_pass" and r["bound"] == "hbm" and r["peak"] == 8000.0

@@ -92,7 +92,7 @@ def test_fused_keys_read_the_cloud_once_in_the_traffic_model(emu_libs):
                 mb += float(f[6])   # first-touch read, MB
         return mb
     cloud_mb = 100_000 * 32 / 1e6
-    fused, two = front({}), front({"PCC_FUSED_KEYS": "0"})
+    fused, two = front({"PCC_FUSED_KEYS": "1"}), front({})
     assert fused < 1.2 * cloud_mb and two > 1.9 * cloud_mb, (fused, two)
 
 
@@ -109,6 +109,9 @@ def test_bench_script_runs_end_to_end_on_the_executor(emu_libs):
         assert key in line, key
     assert line["roofline"]["kernel"] == "k_sort_pass" and line["roofline"]["bound"] == "hbm"
     assert line["entropy_stage"]["ran_on"] in ("host", "gpu")
+    # the line says what it was produced on: this one, the executor (bench.py refuses it unless it is started through bench_on_executor.py)
+    assert line["library"]["file"] == "libpcc_emu.so" and line["library"]["version"].startswith("pcc_emu")
+    assert line["short_call_floor_ms"] >= 0
     assert "e2e_from_host_packed_16B_mpoints_per_s" in line["host_input"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
 

@@ -104,7 +104,7 @@ def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
         pipe.set_option("entropy_on_gpu", 0)
         assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         assert pipe.last_entropy_mode() == 0
-        # -1 (the default): decided per call from a cost estimate; a short call of small frames stays on the host
+        # -1 (auto; the default is 0, the host): decided per call from a cost estimate; a short call of small frames stays on the host
         pipe.set_option("entropy_on_gpu", -1)
         assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         assert pipe.last_entropy_mode() == 0
