@@ -134,7 +134,7 @@ def require_product_library(who):
     PCC_ALLOW_NON_PRODUCT_LIB=1 (set by tests/emu/bench_on_executor.py and the A/B tools) lifts the refusal; the identity
     is reported either way."""
     ident = library_identity()
-    if ident["version"] != PRODUCT_VERSION and os.environ.get("PCC_ALLOW_NON_PRODUCT_LIB") != "1":
+    if (ident["version"] != PRODUCT_VERSION or ident["file"] != "libpcc_hip.so") and os.environ.get("PCC_ALLOW_NON_PRODUCT_LIB") != "1":
         raise SystemExit("%s: refusing to run on %s (%s): not the gfx950 product library" % (who, ident["file"], ident["version"]))
     return ident
 

@@ -472,6 +472,7 @@ int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "copy_image")) ctx->copy_image = value != 0;
   else if (!strcmp(name, "pack_upload")) ctx->pack_upload = value != 0;
   else if (!strcmp(name, "profile_events")) ctx->profile_events = value != 0;
+  else if (!strcmp(name, "rc_device_lanes")) set_range_encode_lanes(value);  // (process-wide) the device range coder: one lane per stream instead of one wave
   else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
 }
@@ -1421,7 +1422,7 @@ struct pcc_entropy_batch {
   size_t in_used = 0;
   DevBuf<uint8_t> d_in, d_out, d_packed;
   DevBuf<RcJob> d_jobs;
-  DevBuf<uint32_t> d_lens, d_offs;
+  DevBuf<uint32_t> d_lens, d_offs, d_hists;
   PinnedBuf<uint32_t> h_lens;
   PinnedBuf<uint8_t> h_packed;
   std::vector<Bytes> streams;    // the finished bitstreams of the last flush
@@ -1456,7 +1457,7 @@ void pcc_entropy_batch_destroy(pcc_entropy_batch* b) {
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
   b->h_in.release(); b->d_in.release(); b->d_out.release(); b->d_packed.release(); b->d_jobs.release(); b->d_lens.release();
-  b->d_offs.release(); b->h_lens.release(); b->h_packed.release();
+  b->d_offs.release(); b->d_hists.release(); b->h_lens.release(); b->h_packed.release();
   pcc_destroy(b->ctx);
   delete b;
 }
@@ -1563,12 +1564,13 @@ static int entropy_batch_flush_frames(pcc_entropy_batch* b, pcc_bitstream* out, 
   PCC_HIP(b->d_lens.ensure(nj));
   PCC_HIP(b->d_offs.ensure(nj));
   PCC_HIP(b->d_jobs.ensure(nj));
+  if (range_encode_lanes()) PCC_HIP(b->d_hists.ensure((size_t)nj * 256));
   PCC_HIP(b->h_lens.ensure(nj));
   for (uint32_t k = 0; k < nj; ++k) { jobs[k].out = b->d_out.p + out_off[k]; jobs[k].out_len = b->d_lens.p + k; }
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
   PCC_HIP(hipMemcpyAsync(b->d_in.p, b->h_in.p, b->in_used, hipMemcpyHostToDevice, ctx->stream));
   PCC_HIP(hipMemcpyAsync(b->d_jobs.p, jobs.data(), (size_t)nj * sizeof(RcJob), hipMemcpyHostToDevice, ctx->stream));
-  launch_range_encode(b->d_jobs.p, nj, ctx->stream);
+  launch_range_encode(b->d_jobs.p, nj, range_encode_lanes() ? b->d_hists.p : nullptr, ctx->stream);
   PCC_HIP(hipGetLastError());
   PCC_HIP(hipMemcpyAsync(b->h_lens.p, b->d_lens.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
   { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
@@ -1637,7 +1639,9 @@ int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* i
   const size_t len_off = at;
   at += ((size_t)n_streams * sizeof(uint32_t) + 63) & ~(size_t)63;
   const size_t job_off = at;
-  at += (size_t)n_streams * sizeof(RcJob);
+  at += ((size_t)n_streams * sizeof(RcJob) + 63) & ~(size_t)63;
+  const size_t hist_off = at;   // (the lane-per-stream form counts the symbols of every stream here first)
+  if (range_encode_lanes()) at += (size_t)n_streams * 256 * sizeof(uint32_t);
   PCC_HIP(ctx->d_rc.ensure(at));
   std::vector<RcJob> jobs((size_t)n_streams);
   for (int i = 0; i < n_streams; ++i) {
@@ -1652,7 +1656,8 @@ int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* i
   (void)in_bytes;
   PCC_HIP(hipMemcpyAsync(ctx->d_rc.p + job_off, jobs.data(), jobs.size() * sizeof(RcJob), hipMemcpyHostToDevice, ctx->stream));
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
-  launch_range_encode(reinterpret_cast<const RcJob*>(ctx->d_rc.p + job_off), (uint32_t)n_streams, ctx->stream);
+  launch_range_encode(reinterpret_cast<const RcJob*>(ctx->d_rc.p + job_off), (uint32_t)n_streams,
+                      range_encode_lanes() ? reinterpret_cast<uint32_t*>(ctx->d_rc.p + hist_off) : nullptr, ctx->stream);
   PCC_HIP(hipGetLastError());
   PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
   std::vector<uint32_t> lens((size_t)n_streams);

@@ -347,7 +347,7 @@ constexpr int kPlanWords = kPlanEpochs + 1;
 // for the workgroups whose chunk holds points of earlier epochs (the chunk with the growth events)
 constexpr int kPlanEpochBase = 64, kPlanEpochWords = 10;
 constexpr int kPlanGranules = 512;  // the per-chunk granules start here
-static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords <= 64 && kPlanEpochBase + kPlanEpochWords * kMaxEpochs <= kPlanGranules &&
+static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords + 3 <= 64 && kPlanEpochBase + kPlanEpochWords * kMaxEpochs <= kPlanGranules &&
               kPlanGranules == (int)kPlanGranulesHost, "one wave sweeps the plan");
 
 __device__ __forceinline__ void publish_box(uint64_t* dst, const ChunkBox& b, uint32_t seq) {
@@ -447,7 +447,7 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
   if (!FUSED) return;
 
   // ---- fused mode: wait for the plan (bounded), then keys and digit counts of this chunk ----
-  uint32_t* s_plan = reinterpret_cast<uint32_t*>(s_f) + 64;   // [kPlanWords] + {got it, a key missed the window}
+  uint32_t* s_plan = reinterpret_cast<uint32_t*>(s_f) + 64;   // [kPlanWords] + {got it, a key missed the window, got the epoch table}
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_f) + 128;  // [np][kMaxBins]
   if (wave_id() == 0) {
     const int l = lane_id();
@@ -518,10 +518,12 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
         }
         all_there = got;
       }
-      if (l == 0) s_plan[kPlanWords] = all_there ? 1u : 0u;
+      // (a word of its own: the other waves may still be reading s_plan[kPlanWords] above -- no barrier lies between their
+      //  read and this write; found by the executor's happens-before checker, tests/emu/race.cpp)
+      if (l == 0) s_plan[kPlanWords + 2] = all_there ? 1u : 0u;
     }
     __syncthreads();
-    if (!s_plan[kPlanWords]) return;  // (the table did not arrive in time: k_make_keys does this chunk)
+    if (!s_plan[kPlanWords + 2]) return;  // (the table did not arrive in time: k_make_keys does this chunk)
   }
   for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) s_hist[k] = 0u;
   __syncthreads();

@@ -12,6 +12,8 @@
 //                  on other threads of the pool (at least two)
 #include <hip/hip_runtime.h>
 
+#include "race.h"
+
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -229,6 +231,8 @@ void ask_for_a_thread();
 void run_workgroup(Worker* w) {
   const int T = w->nthreads, nw = (T + 63) / 64;
   int sleepy_sweeps = 0;
+  const bool racing = race::on();   // the happens-before checker (race.cpp) wants to know which lane runs and how many barriers it has passed
+  race::Where& where = race::tl_where;
   for (int i = 0; i < T; ++i) prepare_lane(w, i);
   uint64_t rnd = shuffle_seed() ? shuffle_seed() ^ ((uint64_t)w->block_linear * 0x9E3779B97F4A7C15ull) : 0ull;
   int wave_order[kMaxThreads / 64], lane_order[64];
@@ -249,12 +253,14 @@ void run_workgroup(Worker* w) {
           Lane& l = w->lanes[f + i];
           if (l.state != kRunnable) continue;
           w->cur = f + i;
+          if (racing) where.lane = f + i;
           threadIdx.x = (uint32_t)(f + i) % blockDim.x;
           threadIdx.y = ((uint32_t)(f + i) / blockDim.x) % blockDim.y;
           threadIdx.z = (uint32_t)(f + i) / (blockDim.x * blockDim.y);
           emu_switch(&w->sched_sp, l.sp);
         }
         w->cur = -1;
+        if (racing) where.lane = -1;
         uint64_t coll = 0;
         bool sleepers = false;
         for (int i = 0; i < cnt; ++i) {
@@ -291,6 +297,7 @@ void run_workgroup(Worker* w) {
         l.result = kind == kSyncAnd ? all : kind == kSyncOr ? any : kind == kSyncCount ? count : 0;
         l.state = kRunnable;
       }
+      if (racing) ++where.bepoch;
       continue;
     }
     if (slept) {
@@ -448,7 +455,15 @@ struct Pool {
         blockDim = {b.x, b.y, b.z};
         gridDim = {g.x, g.y, g.z};
         blockIdx.x = bi % g.x; blockIdx.y = (bi / g.x) % g.y; blockIdx.z = bi / (g.x * g.y);
-        run_workgroup(w);
+        if (race::on()) {
+          race::Where& where = race::tl_where;
+          where.wg = bi; where.lane = -1; where.bepoch = 0; where.kname = w->kname;
+          race::workgroup_begin();
+          run_workgroup(w);
+          race::workgroup_end();
+        } else {
+          run_workgroup(w);
+        }
         ++mine;
       }
       {
@@ -483,6 +498,7 @@ struct Pool {
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return busy == 0; });  // (a worker that woke up late for the launch before)
     if (traffic().on) traffic().begin();
+    if (race::on()) race::launch_begin(name, g.x * g.y * g.z);
     job = &l; kname = name; grid = g; block = b;
     total = g.x * g.y * g.z;
     next.store(0);
@@ -493,6 +509,7 @@ struct Pool {
     job = nullptr;
     tokens = 0;
     if (traffic().on) traffic().end(name);
+    if (race::on()) race::launch_end();
   }
 };
 Pool& pool() {
@@ -598,15 +615,63 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
 }
 namespace emu { void* traffic_alloc(size_t bytes); bool traffic_owns(void* p); void traffic_touch(uintptr_t a, size_t n, bool store); }
 // the access callbacks of the instrumented build (see "traffic model" above)
+// (the same callbacks feed the happens-before checker of race.cpp when PCC_EMU_RACE=1: the return address is the access)
+static inline void emu_touch(uintptr_t a, size_t n, bool store, void* pc) {
+  if (emu::race::on()) emu::race::access(a, n, store, pc);
+  else emu::traffic_touch(a, n, store);
+}
 #define PCC_EMU_CB(N) \
-  extern "C" void __asan_load##N##_noabort(uintptr_t a) { emu::traffic_touch(a, N, false); } \
-  extern "C" void __asan_store##N##_noabort(uintptr_t a) { emu::traffic_touch(a, N, true); }
+  extern "C" void __asan_load##N##_noabort(uintptr_t a) { emu_touch(a, N, false, __builtin_return_address(0)); } \
+  extern "C" void __asan_store##N##_noabort(uintptr_t a) { emu_touch(a, N, true, __builtin_return_address(0)); }
 PCC_EMU_CB(1) PCC_EMU_CB(2) PCC_EMU_CB(4) PCC_EMU_CB(8) PCC_EMU_CB(16)
-extern "C" void __asan_loadN_noabort(uintptr_t a, size_t n) { emu::traffic_touch(a, n, false); }
-extern "C" void __asan_storeN_noabort(uintptr_t a, size_t n) { emu::traffic_touch(a, n, true); }
+extern "C" void __asan_loadN_noabort(uintptr_t a, size_t n) { emu_touch(a, n, false, __builtin_return_address(0)); }
+extern "C" void __asan_storeN_noabort(uintptr_t a, size_t n) { emu_touch(a, n, true, __builtin_return_address(0)); }
 extern "C" void __asan_handle_no_return() {}
+// The `race` build is instrumented by gcc's -fsanitize=thread pass instead (the address sanitizer's pass leaves direct
+// accesses to thread-local variables alone -- every scalar __shared__ variable -- and this one does not): the same idea,
+// these are its callbacks.  libtsan is NOT linked: the checker is race.cpp.  The atomics below are the ones inside the
+// hooks of hip_runtime.h (already booked by the hook; a bare one from a running lane is booked here as agent scope).
+#define PCC_TSAN_CB(N) \
+  extern "C" void __tsan_read##N(void* a) { emu_touch((uintptr_t)a, N, false, __builtin_return_address(0)); } \
+  extern "C" void __tsan_write##N(void* a) { emu_touch((uintptr_t)a, N, true, __builtin_return_address(0)); } \
+  extern "C" void __tsan_unaligned_read##N(void* a) { emu_touch((uintptr_t)a, N, false, __builtin_return_address(0)); } \
+  extern "C" void __tsan_unaligned_write##N(void* a) { emu_touch((uintptr_t)a, N, true, __builtin_return_address(0)); }
+PCC_TSAN_CB(1) PCC_TSAN_CB(2) PCC_TSAN_CB(4) PCC_TSAN_CB(8) PCC_TSAN_CB(16)
+extern "C" void __tsan_read_range(void* a, size_t n) { emu_touch((uintptr_t)a, n, false, __builtin_return_address(0)); }
+extern "C" void __tsan_write_range(void* a, size_t n) { emu_touch((uintptr_t)a, n, true, __builtin_return_address(0)); }
+extern "C" void __tsan_init() {}
+extern "C" void __tsan_func_entry(void*) {}
+extern "C" void __tsan_func_exit() {}
+extern "C" void __tsan_vptr_update(void**, void*) {}
+extern "C" void __tsan_vptr_read(void**) {}
+namespace {
+struct BareAtomic {   // an atomic builtin that did not come through a hook of hip_runtime.h
+  BareAtomic(const volatile void* p, size_t n, int order, int kind, void* pc) { emu::race::atomic_begin_bare((const void*)p, n, order, kind, pc); }
+  ~BareAtomic() { emu::race::atomic_end_bare(); }
+};
+}
+#define PCC_TSAN_ATOMIC(BITS, T) \
+  extern "C" T __tsan_atomic##BITS##_load(const volatile T* p, int mo) { BareAtomic g(p, sizeof(T), mo, 0, __builtin_return_address(0)); return __atomic_load_n(p, __ATOMIC_SEQ_CST); } \
+  extern "C" void __tsan_atomic##BITS##_store(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 1, __builtin_return_address(0)); __atomic_store_n(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_exchange(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_fetch_add(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_fetch_sub(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_fetch_and(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_fetch_or(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_fetch_xor(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_fetch_xor(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_fetch_nand(volatile T* p, T v, int mo) { BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_fetch_nand(p, v, __ATOMIC_SEQ_CST); } \
+  extern "C" int __tsan_atomic##BITS##_compare_exchange_strong(volatile T* p, T* expect, T v, int mo, int) { \
+    BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_compare_exchange_n(p, expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); } \
+  extern "C" int __tsan_atomic##BITS##_compare_exchange_weak(volatile T* p, T* expect, T v, int mo, int) { \
+    BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); return __atomic_compare_exchange_n(p, expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); } \
+  extern "C" T __tsan_atomic##BITS##_compare_exchange_val(volatile T* p, T expect, T v, int mo, int) { \
+    BareAtomic g(p, sizeof(T), mo, 2, __builtin_return_address(0)); __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expect; }
+PCC_TSAN_ATOMIC(8, uint8_t) PCC_TSAN_ATOMIC(16, uint16_t) PCC_TSAN_ATOMIC(32, uint32_t) PCC_TSAN_ATOMIC(64, uint64_t)
+extern "C" void __tsan_atomic_thread_fence(int mo) { if (emu::race::on()) emu::race::fence_bare(mo); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+extern "C" void __tsan_atomic_signal_fence(int) {}
 
 hipError_t hipMalloc(void** p, size_t bytes) {
+  if (void* t = emu::race::arena_alloc(bytes ? bytes : 256)) { memset(t, 0xA5, bytes); *p = t; return hipSuccess; }
   if (void* t = emu::traffic_alloc(bytes ? bytes : 256)) { memset(t, 0xA5, bytes); *p = t; return hipSuccess; }
   void* q = nullptr;
   if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
@@ -615,14 +680,15 @@ hipError_t hipMalloc(void** p, size_t bytes) {
   *p = q;
   return hipSuccess;
 }
-hipError_t hipFree(void* p) { if (!emu::traffic_owns(p)) free(p); return hipSuccess; }  // (the traffic arena is never reused)
+hipError_t hipFree(void* p) { if (!emu::traffic_owns(p) && !emu::race::arena_owns(p)) free(p); return hipSuccess; }  // (the arenas are never reused)
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+  if (void* t = emu::race::arena_alloc(bytes ? bytes : 256)) { *p = t; return hipSuccess; }  // pinned memory the kernels write has a shadow too
   void* q = nullptr;
   if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
   *p = q;
   return hipSuccess;
 }
-hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void* p) { if (!emu::race::arena_owns(p)) free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {

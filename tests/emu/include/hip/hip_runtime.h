@@ -114,7 +114,9 @@ static constexpr int warpSize = 64;
 #define __builtin_amdgcn_s_sleep(n) emu::sleep(n)
 #define __builtin_amdgcn_s_getreg(imm) emu::getreg(imm)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()
+#ifndef PCC_EMU_RACE
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+#endif
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 #define wall_clock64() emu::wall_clock()
 #define clock64() ((long long)emu::wall_clock())
@@ -124,10 +126,39 @@ static constexpr int warpSize = 64;
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
+#ifndef PCC_EMU_RACE
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or(p, v, order)
+#define EMU_ATOMIC(p, kind) do { } while (0)
+#else
+// The `race` build (tests/emu/race.cpp): every atomic tells the happens-before checker its address, memory order and
+// scope before it executes (the checker books it as an atomic access and does the release half of the bookkeeping) and
+// after it (the acquire half); the instrumented load / store inside is then not counted a second time.
+namespace emu {
+namespace race {
+void atomic_begin(const void* p, size_t n, int order, int scope, int kind, void* pc);
+void atomic_end();
+void fence(int order, const char* scope);
+}
+struct RaceAtomic {
+  __attribute__((noinline)) RaceAtomic(const void* p, size_t n, int order, int scope, int kind) { race::atomic_begin(p, n, order, scope, kind, __builtin_return_address(0)); }
+  __attribute__((noinline)) ~RaceAtomic() { race::atomic_end(); }
+};
+template <typename T> static inline T race_load(const T* p, int order, int scope) { RaceAtomic g(p, sizeof(T), order, scope, 0); return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+template <typename T, typename V> static inline void race_store(T* p, V v, int order, int scope) { RaceAtomic g(p, sizeof(T), order, scope, 1); __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
+template <typename T, typename V> static inline T race_fetch_add(T* p, V v, int order, int scope) { RaceAtomic g(p, sizeof(T), order, scope, 2); return __atomic_fetch_add(p, (T)v, __ATOMIC_SEQ_CST); }
+template <typename T, typename V> static inline T race_fetch_or(T* p, V v, int order, int scope) { RaceAtomic g(p, sizeof(T), order, scope, 2); return __atomic_fetch_or(p, (T)v, __ATOMIC_SEQ_CST); }
+}  // namespace emu
+#define __hip_atomic_load(p, order, scope) emu::race_load(p, order, scope)
+#define __hip_atomic_store(p, v, order, scope) emu::race_store(p, v, order, scope)
+#define __hip_atomic_fetch_add(p, v, order, scope) emu::race_fetch_add(p, v, order, scope)
+#define __hip_atomic_fetch_or(p, v, order, scope) emu::race_fetch_or(p, v, order, scope)
+#define __builtin_amdgcn_fence(order, scope) emu::race::fence(order, scope)   /* (the executor's memory is sequentially consistent: nothing else to do) */
+// atomicAdd and friends: relaxed, agent scope (what HIP's definitions are); kind 2 = read-modify-write
+#define EMU_ATOMIC(p, kind) emu::RaceAtomic emu_guard_(p, sizeof(*(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT, kind)
+#endif
 
 template <typename T>
 static inline T emu_shfl(T v, int a, int width, int mode) {
@@ -145,8 +176,9 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
 template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) { return emu_shfl(v, (int)d, width, 3); }
 
 // atomics (workgroups are OS threads: these have to be real ones)
-template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicAdd(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline float atomicAdd(float* p, float v) {
+  EMU_ATOMIC(p, 2);
   uint32_t* q = reinterpret_cast<uint32_t*>(p);
   uint32_t o = __atomic_load_n(q, __ATOMIC_RELAXED);
   for (;;) {
@@ -159,6 +191,7 @@ static inline float atomicAdd(float* p, float v) {
   }
 }
 static inline double atomicAdd(double* p, double v) {
+  EMU_ATOMIC(p, 2);
   uint64_t* q = reinterpret_cast<uint64_t*>(p);
   uint64_t o = __atomic_load_n(q, __ATOMIC_RELAXED);
   for (;;) {
@@ -170,30 +203,33 @@ static inline double atomicAdd(double* p, double v) {
     if (__atomic_compare_exchange_n(q, &o, w, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return old;
   }
 }
-template <typename T> static inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
-template <typename T> static inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
-template <typename T> static inline T atomicAnd(T* p, T v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
-template <typename T> static inline T atomicXor(T* p, T v) { return __atomic_fetch_xor(p, v, __ATOMIC_RELAXED); }
-template <typename T> static inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicSub(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicOr(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicAnd(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicXor(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_fetch_xor(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicExch(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 template <typename T> static inline T atomicCAS(T* p, T expect, T v) {
+  EMU_ATOMIC(p, 2);
   __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
   return expect;
 }
 template <typename T> static inline T atomicMin(T* p, T v) {
+  EMU_ATOMIC(p, 2);
   T old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
 template <typename T> static inline T atomicMax(T* p, T v) {
+  EMU_ATOMIC(p, 2);
   T old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
 // the mixed-signedness calls HIP's overload set accepts
-static inline unsigned atomicAdd(unsigned* p, int v) { return __atomic_fetch_add(p, (unsigned)v, __ATOMIC_RELAXED); }
-static inline unsigned long long atomicOr(unsigned long long* p, uint64_t v) { return __atomic_fetch_or(p, (unsigned long long)v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, int v) { EMU_ATOMIC(p, 2); return __atomic_fetch_add(p, (unsigned)v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicOr(unsigned long long* p, uint64_t v) { EMU_ATOMIC(p, 2); return __atomic_fetch_or(p, (unsigned long long)v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicMin(unsigned long long* p, uint64_t v) { return atomicMin<unsigned long long>(p, (unsigned long long)v); }
-static inline unsigned atomicOr(unsigned* p, int v) { return __atomic_fetch_or(p, (unsigned)v, __ATOMIC_RELAXED); }
+static inline unsigned atomicOr(unsigned* p, int v) { EMU_ATOMIC(p, 2); return __atomic_fetch_or(p, (unsigned)v, __ATOMIC_RELAXED); }
 
 // bit operations with the device's results for zero
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

@@ -6,6 +6,7 @@ so what is checked is exactly the host code: header, range coder, JPEG, stream a
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -22,6 +23,36 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), name
     assert b"gfx950" in lib.pcc_version()
+
+
+def test_known_good_round2_library_loads_beside_head(pkg):
+    """tools/known_good/build.sh: the library of the last commit whose parity suite ran green on an MI355X (round 2), built
+    from that commit's sources, with HEAD's whole C ABI (two later entry points come from a compat file) -- so that one GPU
+    session can time and digest-check it beside HEAD.  Here: it loads, exports every declared symbol, and its host-side
+    range coder and JPEG writer give HEAD's bytes.  bench.py / smoke() refuse it (it is not HEAD's product library)."""
+    import subprocess
+    path = os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip_r02.so")
+    if not os.path.exists(path):
+        if not os.path.isdir(os.path.join(ROOT, ".git")):
+            pytest.skip("no git history here: the round-2 library cannot be rebuilt")
+        assert subprocess.run(["bash", os.path.join(ROOT, "tools", "known_good", "build.sh")]).returncode == 0
+    old, new = C.CDLL(path), pkg.binding.load_library()
+    for name in pkg.binding.EXPORTS:
+        assert hasattr(old, name), name
+    rng = np.random.default_rng(2)
+    data = np.minimum(rng.geometric(0.05, 50_000), 255).astype(np.uint8)
+    outs = []
+    for lib in (old, new):
+        lib.pcc_host_range_encode.restype = C.c_size_t
+        lib.pcc_host_range_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        buf = np.zeros(len(data) * 2 + 2048, dtype=np.uint8)
+        n = lib.pcc_host_range_encode(data.ctypes.data, len(data), buf.ctypes.data, len(buf))
+        outs.append(buf[:n].tobytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    e = dict(os.environ, PCC_LIB=path)
+    e.pop("PCC_ALLOW_NON_PRODUCT_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert r.returncode != 0 and "not the gfx950 product library" in r.stderr
 
 
 def test_struct_layouts_match_header(pkg, oracle):

@@ -1,4 +1,6 @@
-"""The static range coder on the GPU (one wave per stream, csrc/pcc_rc_device.hip) against the host coder: same bytes."""
+"""The static range coder on the GPU (csrc/pcc_rc_device.hip) against the host coder: same bytes -- in both of its forms,
+one wave per stream (the default: it has run on the chip) and one LANE per stream (option "rc_device_lanes": 64 streams per
+wave, the coder state in vector registers, the tables in lane-private LDS columns)."""
 import importlib
 
 import numpy as np
@@ -25,9 +27,19 @@ def _streams():
     return out
 
 
-def test_device_range_coder_equals_host_coder(pkg, ctx):
+@pytest.fixture(params=[0, 1], ids=["wave_per_stream", "lane_per_stream"])
+def lanes(request, ctx):
+    ctx.set_option("rc_device_lanes", request.param)   # process-wide
+    yield request.param
+    ctx.set_option("rc_device_lanes", 0)
+
+
+def test_device_range_coder_equals_host_coder(pkg, ctx, lanes):
     b = pkg.binding
     streams = _streams()
+    if lanes:   # every tail length behind the 16-byte groups, streams of one wave ending at different times
+        rng = np.random.default_rng(11)
+        streams += [rng.integers(0, 16, 200 + k, dtype=np.uint8).tobytes() for k in range(0, 70)]
     got, ms = ctx.device_range_encode(streams)
     for s, g in zip(streams, got):
         assert g == b.host_range_encode(s), len(s)
@@ -36,7 +48,7 @@ def test_device_range_coder_equals_host_coder(pkg, ctx):
     assert ms > 0
 
 
-def test_device_range_coder_many_streams_at_once(pkg, ctx):
+def test_device_range_coder_many_streams_at_once(pkg, ctx, lanes):
     b = pkg.binding
     rng = np.random.default_rng(9)
     streams = [rng.integers(0, 1 + k % 7, 1000 + 37 * k, dtype=np.uint8).tobytes() for k in range(300)]
@@ -46,7 +58,8 @@ def test_device_range_coder_many_streams_at_once(pkg, ctx):
 
 
 @pytest.mark.gpu
-def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
+@pytest.mark.parametrize("lanes", [0, 1], ids=["wave_per_stream", "lane_per_stream"])
+def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle, lanes):
     """pcc_entropy_batch: the entropy stage of many frames with the range coders on the GPU -- every coding mode, with and
     without centroids, geometry only, a three-point frame; byte-identical to the oracle's bitstreams.  Then the frame
     pipeline in that mode (pcc_pipeline_set_option "entropy_on_gpu")."""
@@ -55,6 +68,7 @@ def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
     b = pkg.binding
     lib = b.load_library()
     ctx = b.Context(0)
+    ctx.set_option("rc_device_lanes", lanes)
     batch = lib.pcc_entropy_batch_create(0, 64)
     assert batch
     cases = [dict(octree_bits=8, color_coding_type=1, jpeg_quality=85), dict(octree_bits=8, color_coding_type=0, color_bits=6, keep_centroid=1),
@@ -124,3 +138,6 @@ def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
         assert all(len(got[k][0]) == len(got[k % 3][0]) for k in range(len(many)))
     finally:
         pipe.close()
+        c2 = b.Context(0)
+        c2.set_option("rc_device_lanes", 0)
+        c2.close()
