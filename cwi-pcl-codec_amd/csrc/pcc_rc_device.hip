@@ -291,13 +291,16 @@ void launch_pack_streams(const RcJob* dev_jobs, const uint32_t* dev_offsets, uin
 }
 
 // 0: one wave per stream (the form that has run on the chip); 1: one lane per stream
-static std::atomic<int> g_rc_lanes{[] { const char* e = getenv("PCC_RC_DEVICE"); return (e && !strcmp(e, "lanes")) ? 1 : 0; }()};
-void set_range_encode_lanes(int on) { g_rc_lanes.store(on ? 1 : 0); }
-int range_encode_lanes() { return g_rc_lanes.load(); }
+static std::atomic<int>& rc_lanes() {
+  static std::atomic<int> v{[] { const char* e = getenv("PCC_RC_DEVICE"); return (e && !strcmp(e, "lanes")) ? 1 : 0; }()};
+  return v;
+}
+void set_range_encode_lanes(int on) { rc_lanes().store(on ? 1 : 0); }
+int range_encode_lanes() { return rc_lanes().load(); }
 
 void launch_range_encode(const RcJob* dev_jobs, uint32_t n_jobs, uint32_t* dev_hists, hipStream_t stream) {
   if (!n_jobs) return;
-  if (g_rc_lanes.load() && dev_hists) {
+  if (rc_lanes().load() && dev_hists) {
     hipLaunchKernelGGL(k_stream_histograms, dim3(n_jobs), dim3(256), 0, stream, dev_jobs, n_jobs, dev_hists);
     hipLaunchKernelGGL(k_range_encode_lanes, dim3((n_jobs + 63u) / 64u), dim3(64), 0, stream, dev_jobs, n_jobs, dev_hists);
   } else {

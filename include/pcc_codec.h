@@ -129,6 +129,9 @@ pcc_ctx *pcc_create(int device);                 /* replaces `new OctreePointClo
 pcc_ctx *pcc_create_host(void);
 void pcc_destroy(pcc_ctx *ctx);
 const char *pcc_last_error(pcc_ctx *ctx);
+/* What this binary is: "pcc_hip 0.1 (gfx950)" for the product library and nothing else -- the same sources compiled for the
+ * CPU executor of tests/emu answer "pcc_emu ...", developer builds name themselves.  bench.py and smoke() refuse anything but
+ * the product string (a line timed on another build must not be mistaken for a measurement). */
 const char *pcc_version(void);
 
 /* ---- encodePointCloud (codec.h:174-175, impl.hpp:80-213) ----
@@ -234,7 +237,9 @@ int pcc_set_profiling(pcc_ctx *ctx, int enabled);
  *                 for inspection when jpeg_on_gpu is 1).
  *   "profile_events" (default 1): with pcc_set_profiling, also record HIP events between the launches
  *                 (pcc_get_kernel_times); 0 leaves only the launch spans on the GPU clock, so that the launches run
- *                 back to back as they do unprofiled. */
+ *                 back to back as they do unprofiled.
+ *   "rc_device_lanes" (default 0; process-wide): the device range coder (pcc_device_range_encode, pcc_entropy_batch_*) codes
+ *                 one stream per LANE, 64 per wave, instead of one per wave -- same bytes; opt-in until it has been timed. */
 int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 
 /* ---- a sequence of frames on one GPU (the app's frame loop, eval.hpp:818-835) ----
@@ -250,9 +255,9 @@ void pcc_pipeline_destroy(pcc_pipeline *p);
 /* pipeline knobs (no output byte changes), to be set between calls:
  *   "entropy_on_gpu" 1: the range coders of the entropy stage run on the GPU (pcc_entropy_batch), the entropy threads
  *                 only copy, stitch JPEG rows and assemble -- for hosts with fewer cores than the GPU stage can feed; a flush
- *                 takes ~0.1 s whatever its size.  0: always on the host.  -1 (default; PCC_PIPELINE_ENTROPY=host|gpu|auto):
+ *                 takes ~0.1 s whatever its size.  0 (default): always on the host.  -1 (PCC_PIPELINE_ENTROPY=host|gpu|auto):
  *                 decided per call from a cost estimate (frames, symbols per frame, entropy threads): long calls on hosts
- *                 with few cores per GPU go to the GPU, everything else stays on the host.
+ *                 with few cores per GPU go to the GPU -- opt-in until its two cost constants are calibrated on the box.
  *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread.
  *   "pack_upload" (default 0): frames from host memory are packed to 16 bytes per point before they cross PCIe. */
 int pcc_pipeline_set_option(pcc_pipeline *p, const char *name, int value);

@@ -627,6 +627,8 @@ PCC_EMU_CB(1) PCC_EMU_CB(2) PCC_EMU_CB(4) PCC_EMU_CB(8) PCC_EMU_CB(16)
 extern "C" void __asan_loadN_noabort(uintptr_t a, size_t n) { emu_touch(a, n, false, __builtin_return_address(0)); }
 extern "C" void __asan_storeN_noabort(uintptr_t a, size_t n) { emu_touch(a, n, true, __builtin_return_address(0)); }
 extern "C" void __asan_handle_no_return() {}
+extern "C" void __asan_before_dynamic_init(const char*) {}
+extern "C" void __asan_after_dynamic_init() {}
 // The `race` build is instrumented by gcc's -fsanitize=thread pass instead (the address sanitizer's pass leaves direct
 // accesses to thread-local variables alone -- every scalar __shared__ variable -- and this one does not): the same idea,
 // these are its callbacks.  libtsan is NOT linked: the checker is race.cpp.  The atomics below are the ones inside the
