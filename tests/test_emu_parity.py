@@ -76,6 +76,20 @@ def test_the_xcd_register_is_only_a_hint(emu_libs, xcc):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
 
 
+def test_the_default_forms_need_no_resident_grid(emu_libs):
+    """With other frames' kernels on the GPU a launch's grid is not resident as a whole.  The default forms make progress
+    however few of their workgroups run at a time: tile ids are tickets of ONE counter per pass (a tile only ever waits for tiles
+    that have started) and no streaming workgroup waits for a plan.  Here: at most 10 workgroups of a launch at a time (the
+    executor grows its pool to PCC_EMU_MAX_THREADS and no further), 245-tile launches of the headline frame, the oracle's
+    bytes.  (The opt-in XCD-aware tickets do NOT have this property -- PCC_SORT_XCD=16 under the same limit spins until its
+    bound: a workgroup takes its own XCD's next tile, which can lie far beyond the lowest tile nobody has started, and the
+    workgroups that could start that one are not dispatched while the resident ones spin; that is why it is off by default.)"""
+    env = dict(os.environ, PCC_LIB=emu_libs[0], PCC_EMU_WORKERS="8", PCC_EMU_MAX_THREADS="10")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "900", "tests/test_gpu_parity.py",
+                        "-k", "cfg2_1m_depth10_surface or cfg1_100k"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+
+
 def test_fused_keys_read_the_cloud_once_in_the_traffic_model(emu_libs):
     """The executor's traffic model (outline access instrumentation; first-touch lines per XCD and launch): with fused keys the
     kernels in front of the sort touch the cloud's lines once, in the two-kernel form twice."""
