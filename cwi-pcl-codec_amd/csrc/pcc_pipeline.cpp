@@ -591,6 +591,18 @@ int pcc_pipeline_last_entropy_mode(pcc_pipeline* p) {
   return p->entropy_on_gpu ? 1 : 0;
 }
 int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }
+// developer aid (not part of include/pcc_codec.h): the CPUs entropy thread `worker` may run on, lowest first; returns how many
+// there are (at most `cap` are written), -1 for a bad argument
+int pcc_debug_pipeline_cpus(pcc_pipeline* p, int worker, int* out, int cap) {
+  if (!p || worker < 0 || worker >= p->n_entropy || (cap > 0 && !out)) return -1;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (pthread_getaffinity_np(p->threads[(size_t)p->n_gpu + (size_t)worker].native_handle(), sizeof(set), &set) != 0) return -1;
+  int n = 0;
+  for (int c = 0; c < CPU_SETSIZE; ++c)
+    if (CPU_ISSET(c, &set)) { if (n < cap) out[n] = c; ++n; }
+  return n;
+}
 int pcc_pipeline_contexts(pcc_pipeline* p) { return p ? (int)p->ctxs.size() : 0; }
 
 pcc_ctx* pcc_pipeline_context(pcc_pipeline* p, int index) {

@@ -713,6 +713,61 @@ def test_two_pipelines_behind_the_multi_gpu_entry_point(pkg, oracle):
         multi.close()
 
 
+def test_pipelines_of_a_rank_pin_inside_the_ranks_share_of_the_cores():
+    """One process per GPU on one host (LOCAL_RANK 1 of LOCAL_WORLD_SIZE 2): the entropy threads of every pipeline of the rank
+    get core groups inside the rank's half of the allowed cores -- a second pipeline starts behind the first and WRAPS INSIDE
+    that half (it used to wrap over all cores, onto the other rank's) -- and a destroyed pipeline gives its cores back.
+    A child process: the bookkeeping is per process."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys
+        sys.path.insert(0, %r)
+        import __graft_entry__ as G
+        b = G.load_package().binding
+        lib = b.load_library()
+        lib.pcc_debug_pipeline_cpus.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        def cpus(pipe):
+            out = set()
+            for w in range(pipe.workers):
+                buf = (C.c_int * 1024)()
+                n = lib.pcc_debug_pipeline_cpus(pipe.h, w, buf, 1024)
+                assert n > 0
+                out |= set(buf[:min(n, 1024)])
+            return out
+        allowed = sorted(os.sched_getaffinity(0))
+        cores = []
+        for c in allowed:   # one logical CPU per physical core: the lowest allowed sibling
+            try:
+                first = int(open("/sys/devices/system/cpu/cpu%%d/topology/thread_siblings_list" %% c).read().replace("-", ",").split(",")[0])
+            except OSError:
+                first = c
+            if first == c or first not in allowed:
+                cores.append(c)
+        span = max(len(cores) // 2, 1)
+        mine = set(cores[span:2 * span])
+        a = b.Pipeline(0, 1)
+        ca = cpus(a)
+        if len(ca) == len(allowed) or span < 2:
+            print("SKIP: too few cores to pin on (%%d)" %% len(cores)); sys.exit(0)
+        bb = b.Pipeline(0, 1)
+        cb = cpus(bb)
+        assert ca <= mine and cb <= mine, (sorted(ca), sorted(cb), sorted(mine))
+        if span >= 2 * len(ca):
+            assert not (ca & cb), (sorted(ca), sorted(cb))
+        a.close(); bb.close()
+        c3 = b.Pipeline(0, 1)
+        assert cpus(c3) == ca, (sorted(cpus(c3)), sorted(ca))     # the cores came back
+        c3.close()
+        print("OK", sorted(ca), sorted(cb))
+    """ % root)
+    env = dict(os.environ, LOCAL_RANK="1", LOCAL_WORLD_SIZE="2")
+    for k in ("PCC_PIPELINE_PIN", "PCC_PIPELINE_PIN_SPAN", "PCC_PIPELINE_PIN_OFFSET"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ("OK" in r.stdout or "SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_host_frames_through_one_context(pkg, oracle):
     """pcc_hotpath_launch_host with and without an upload lane, pageable and pinned memory, an empty cloud."""
     b = pkg.binding
