@@ -61,7 +61,7 @@ def test_the_shfl_build_agrees(emu_libs):
     """The bisecting build (-DPCC_WAVE_OPS_SHFL: wave scans and lane reads through __shfl, block-wide replay) gives the
     same bytes: micro cases, every colour mode, the 48-case random sweep, cfg1."""
     rc, passed, tail = run_gpu_tests(emu_libs[1], ["tests/test_gpu_parity.py"], NOT_ON_THE_EXECUTOR + LONG,
-                                     ["-k", "not cfg2 and not cfg3 and not pipeline and not headline and not short_calls and not two_kernel_form"])
+                                     ["-k", "not cfg2 and not cfg3 and not pipeline and not headline and not short_calls"])
     assert rc == 0, tail
     assert passed >= 100, tail
 

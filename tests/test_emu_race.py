@@ -112,7 +112,7 @@ def test_the_kernels_have_no_unordered_hand_off(race_build):
     targets = ["tests", "--deselect", "tests/test_bench_contract.py", "--deselect", "tests/test_delta_gpu.py::test_cfg5_at_its_stated_size",
                "--deselect", "tests/test_gpu_parity.py::test_cfg4_reduced_parity_and_full_size_properties",
                "--deselect", "tests/test_gpu_parity.py::test_cpp_pipeline_bench_runs"]   # (its own 300 s limit is too short for the instrumented build)
-    r, seen, reports = run_gpu_tests_under_the_checker(race_build, log, targets, None if full else QUICK + " and not two_kernel_form")
+    r, seen, reports = run_gpu_tests_under_the_checker(race_build, log, targets, None if full else QUICK + " and not optional_forms_of")
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert seen and sum(int(s[2]) for s in seen) > 10_000_000 and sum(int(s[4]) for s in seen) > 10_000_000, seen
     bad = unjustified(race_build, reports)

@@ -437,27 +437,6 @@ def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypa
         assert seen_fused > 100 and seen_fallback == 0   # every chunk, the ones that hold earlier epochs included (epoch table in the plan)
 
 
-@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "1"}, {"PCC_FUSED_KEYS": "1", "PCC_PLAN_SPINS": "1"}, {"PCC_LEAF_PROBES": "uniform"}, {"PCC_SORT_XCD": "16"},
-                                 {"PCC_SORT_XCD": "3"}, {"PCC_SORT_BARE": "1"}, {"PCC_SORT_LOCAL": "1"}, {"PCC_SORT_LOCAL": "1", "PCC_SORT_SHAPE": "wide"}])
-def test_two_kernel_form_and_plan_timeouts_give_the_same_bytes(env):
-    """The same clouds with fused mode switched on (the default is the two-kernel form), with every wait for the plan running
-    out (all chunks fall back to k_make_keys), and with the parent search of k_leaf_tile on evenly spaced first probes (round
-    2's layout; the default spaces them geometrically back from the tile), and with the sort passes' tiles handed out in
-    XCD-aware chunks of sixteen or three tiles (the default is one ticket counter, round 2's form), and with the payload-free sort passes enqueued first (an
-    experiment: frames whose keys carry a payload are sent back once), and with the local fix-up of the low code bits in the
-    leaf scan (an experiment that saves a sort pass: three passes for the headline frame; a frame with a group of equal
-    high bits too long for it is sent back once; with the wide kernel shape forced, which the experiment does not exist in, it
-    must quietly stay off): child processes, because the switches are read once."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points or cfg3_capture or cfg2_1m_depth10_surface or crowded_voxels"],
-                       cwd=root, env=e, capture_output=True, text=True, timeout=1800)
-    # with the mode off / all chunks timing out the fused-chunk counters of the first test do not hold: it is told so
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 def test_crowded_voxels_beside_a_surface(pkg, oracle, ctx):
     """Thousands of points inside one 4 x 4 x 4-voxel cube next to an ordinary surface (more than one sort tile of them): the
     group of equal high code bits is far longer than the local fix-up of PCC_SORT_LOCAL takes on (the frame is then sent

@@ -1,6 +1,7 @@
-"""The static range coder on the GPU (csrc/pcc_rc_device.hip) against the host coder: same bytes -- in both of its forms,
-one wave per stream (the default: it has run on the chip) and one LANE per stream (option "rc_device_lanes": 64 streams per
-wave, the coder state in vector registers, the tables in lane-private LDS columns)."""
+"""The static range coder on the GPU (csrc/pcc_rc_device.hip) against the host coder: same bytes.  Here its default form, one
+wave per stream (it has run on the chip); the opt-in form with one LANE per stream (option "rc_device_lanes": 64 streams per
+wave, the coder state in vector registers, the tables in lane-private LDS columns) runs the same checks in
+tests/test_zz_optional_forms.py."""
 import importlib
 
 import numpy as np
@@ -27,19 +28,9 @@ def _streams():
     return out
 
 
-@pytest.fixture(params=[0, 1], ids=["wave_per_stream", "lane_per_stream"])
-def lanes(request, ctx):
-    ctx.set_option("rc_device_lanes", request.param)   # process-wide
-    yield request.param
-    ctx.set_option("rc_device_lanes", 0)
-
-
-def test_device_range_coder_equals_host_coder(pkg, ctx, lanes):
+def test_device_range_coder_equals_host_coder(pkg, ctx):
     b = pkg.binding
     streams = _streams()
-    if lanes:   # every tail length behind the 16-byte groups, streams of one wave ending at different times
-        rng = np.random.default_rng(11)
-        streams += [rng.integers(0, 16, 200 + k, dtype=np.uint8).tobytes() for k in range(0, 70)]
     got, ms = ctx.device_range_encode(streams)
     for s, g in zip(streams, got):
         assert g == b.host_range_encode(s), len(s)
@@ -48,7 +39,7 @@ def test_device_range_coder_equals_host_coder(pkg, ctx, lanes):
     assert ms > 0
 
 
-def test_device_range_coder_many_streams_at_once(pkg, ctx, lanes):
+def test_device_range_coder_many_streams_at_once(pkg, ctx):
     b = pkg.binding
     rng = np.random.default_rng(9)
     streams = [rng.integers(0, 1 + k % 7, 1000 + 37 * k, dtype=np.uint8).tobytes() for k in range(300)]
@@ -58,8 +49,11 @@ def test_device_range_coder_many_streams_at_once(pkg, ctx, lanes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", [0, 1], ids=["wave_per_stream", "lane_per_stream"])
-def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle, lanes):
+def test_entropy_batch_on_the_gpu_gives_the_host_stages_bitstreams(pkg, oracle):
+    entropy_batch_and_pipeline(pkg, oracle, 0)
+
+
+def entropy_batch_and_pipeline(pkg, oracle, lanes):
     """pcc_entropy_batch: the entropy stage of many frames with the range coders on the GPU -- every coding mode, with and
     without centroids, geometry only, a three-point frame; byte-identical to the oracle's bitstreams.  Then the frame
     pipeline in that mode (pcc_pipeline_set_option "entropy_on_gpu")."""

@@ -24,13 +24,13 @@ if want parity; then
   if ! grep -q " passed" $OUT/pytest_gpu.log || grep -q " failed\| error" $OUT/pytest_gpu.log; then
     SUBSET="tests/test_gpu_parity.py tests/test_codec_golden.py"
     for SW in "PCC_LEAF_PROBES=uniform" "PCC_LEAF_ROWS=linear" "PCC_LEAF_PROBES=uniform PCC_LEAF_ROWS=linear"; do
-      env $SW python -m pytest $SUBSET -m gpu -x -q -k "not two_kernel_form" > "$OUT/pytest_gpu_${SW// /_}.log" 2>&1
+      env $SW python -m pytest $SUBSET -m gpu -x -q > "$OUT/pytest_gpu_${SW// /_}.log" 2>&1
       echo "with $SW: $(tail -1 "$OUT/pytest_gpu_${SW// /_}.log")"
     done
-    [ -f $SHFL ] && { PCC_LIB=$SHFL python -m pytest $SUBSET -m gpu -x -q -k "not two_kernel_form" > $OUT/pytest_gpu_shfl.log 2>&1; echo "shfl build: $(tail -1 $OUT/pytest_gpu_shfl.log)"; }
+    [ -f $SHFL ] && { PCC_LIB=$SHFL python -m pytest $SUBSET -m gpu -x -q > $OUT/pytest_gpu_shfl.log 2>&1; echo "shfl build: $(tail -1 $OUT/pytest_gpu_shfl.log)"; }
     # the round-2 library under HEAD's tests, without -x: what it never had (trees deeper than 21 levels, LINES on the GPU) fails, the rest says
     # whether the box and the tests are sound
-    [ -f $R02 ] && { PCC_LIB=$R02 python -m pytest $SUBSET -m gpu -q -k "not two_kernel_form and not 22_to_31" > $OUT/pytest_gpu_r02lib.log 2>&1; echo "round-2 library: $(tail -1 $OUT/pytest_gpu_r02lib.log)"; }
+    [ -f $R02 ] && { PCC_LIB=$R02 python -m pytest $SUBSET -m gpu -q -k "not 22_to_31" > $OUT/pytest_gpu_r02lib.log 2>&1; echo "round-2 library: $(tail -1 $OUT/pytest_gpu_r02lib.log)"; }
   fi
 fi
 
