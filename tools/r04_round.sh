@@ -68,6 +68,6 @@ if want prof; then
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-input --steps 256 > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err)
   DB=$(find $OUT/prof -name '*.db' | head -1)
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/bench_kernel_stats.txt && cat $OUT/bench_kernel_stats.txt
-  python tools/rc_device_speed.py > $OUT/rc_device_speed.txt 2>&1; tail -5 $OUT/rc_device_speed.txt
+  python tools/rc_device_speed.py > $OUT/rc_device_speed.txt 2>&1; tail -16 $OUT/rc_device_speed.txt   # both forms of the device range coder
   find $OUT -name '*.db' -size +20M -delete
 fi

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Speed of the GPU range coder (one wave per stream) on the occupancy stream of the cfg2 frame: latency of one stream,
-aggregate streams/s with many streams side by side.  Run on the GPU box."""
+"""Speed of the GPU range coder on the occupancy stream of the cfg2 frame: latency of one stream, aggregate streams/s with many
+streams side by side -- for both forms: one wave per stream (default) and one lane per stream (option "rc_device_lanes").
+Run on the GPU box.  RC_SPEED_BIG=1 adds 4096 streams (4 GB of coded streams on the host)."""
 import os
 import sys
 
@@ -19,14 +20,20 @@ def main():
     hot = ctx.hotpath_finish()
     occ = hot.occupancy.tobytes()
     want = B.host_range_encode(occ)
-    for k in (1, 16, 64, 256, 1024, 2048):
-        best = 1e9
-        for _ in range(2):
-            got, ms = ctx.device_range_encode([occ] * k)
-            best = min(best, ms)
-        assert got[0] == want and got[-1] == want
-        print("%5d streams of %d symbols: kernel %.2f ms -> %.1f ns per symbol per stream, %.0f streams/s" % (
-            k, len(occ), best, best * 1e6 / len(occ), k / best * 1e3))
+    sizes = (1, 16, 64, 256, 1024, 2048) + ((4096,) if os.environ.get("RC_SPEED_BIG") == "1" else ())
+    for lanes in (0, 1):
+        ctx.set_option("rc_device_lanes", lanes)
+        print("== one %s per stream" % ("LANE" if lanes else "wave"))
+        for k in sizes:
+            best = 1e9
+            for _ in range(2):
+                got, ms = ctx.device_range_encode([occ] * k)
+                best = min(best, ms)
+            assert got[0] == want and got[-1] == want and all(len(g) == len(want) for g in got)
+            print("%5d streams of %d symbols: kernel %.2f ms -> %.1f ns per symbol per stream, %.0f streams/s, %d waves" % (
+                k, len(occ), best, best * 1e6 / len(occ), k / best * 1e3, (k + 63) // 64 if lanes else k))
+            del got
+    ctx.set_option("rc_device_lanes", 0)
 
 
 if __name__ == "__main__":
