@@ -107,6 +107,8 @@ struct pcc_ctx {
   DevBuf<uint32_t> d_idx2_a, d_idx2_b, d_leaf_hi;  // trees deeper than 21 levels only (two-word codes): allocated when one comes by
   bool deep_hint = false;                          // the frame before was one: enqueue the deep kernels straight away
   bool local_off = false;                          // a frame came by whose groups were too long for the local fix-up (PCC_SORT_LOCAL only)
+  int force_pairs = 0;                             // test hooks (pcc_set_option): which key layout the sort is given
+  bool no_cell_ranks = false;
   bool payload_hint = false;                       // the frame before had a payload in its sort (PCC_SORT_BARE only)
   DevBuf<uint8_t> d_leaf_t, d_bgr, d_centroid, d_image, d_sync;
   // the per-MCU-row Huffman records and, right behind them, the occupancy stream: what the host stage needs of a
@@ -472,6 +474,8 @@ int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "copy_image")) ctx->copy_image = value != 0;
   else if (!strcmp(name, "pack_upload")) ctx->pack_upload = value != 0;
   else if (!strcmp(name, "profile_events")) ctx->profile_events = value != 0;
+  else if (!strcmp(name, "force_pairs")) ctx->force_pairs = value;          // test hooks: see launch_frame
+  else if (!strcmp(name, "no_cell_ranks")) ctx->no_cell_ranks = value != 0;
   else if (!strcmp(name, "rc_device_lanes")) set_range_encode_lanes(value);  // (process-wide) the device range coder: one lane per stream instead of one wave
   else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
@@ -587,14 +591,12 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
     static const bool local_env = [] { const char* e = getenv("PCC_SORT_LOCAL"); return e && e[0] == '1'; }();
     a.local_launch = (local_env && !ctx->local_off && !a.deep_launch && !stop_after_leaf_scan) ? 1 : 0;
   }
-  {
-    const char* fp = getenv("PCC_FORCE_PAIRS");  // test hook: exercise the pair sort on small frames
-    a.force_pairs = (fp && fp[0] == '1') ? 1 : 0;
-    // '2': keep the point index in the key although nothing needs it (the packed [code | index] + colour payload sort)
-    a.need_index = (a.lp.do_centroid || stop_after_leaf_scan || (fp && fp[0] == '2')) ? 1 : 0;
-    const char* nr = getenv("PCC_NO_CELL_RANKS");  // test hook: the full varying Morton code is sorted
-    a.no_cell_ranks = (nr && nr[0] == '1') ? 1 : 0;
-  }
+  // test hooks (pcc_set_option "force_pairs" / "no_cell_ranks"; nothing reads the environment per frame):
+  // force_pairs 1: the pair sort on small frames; 2: keep the point index in the key although nothing needs it (the packed
+  // [code | index] + colour payload sort); no_cell_ranks 1: the full varying Morton code is sorted
+  a.force_pairs = ctx->force_pairs == 1 ? 1 : 0;
+  a.need_index = (a.lp.do_centroid || stop_after_leaf_scan || ctx->force_pairs == 2) ? 1 : 0;
+  a.no_cell_ranks = ctx->no_cell_ranks ? 1 : 0;
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
   {
     // The two-kernel form (k_boxes_events reads the coordinates, k_make_keys reads the cloud again) is the default: it has

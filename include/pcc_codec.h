@@ -238,6 +238,9 @@ int pcc_set_profiling(pcc_ctx *ctx, int enabled);
  *   "profile_events" (default 1): with pcc_set_profiling, also record HIP events between the launches
  *                 (pcc_get_kernel_times); 0 leaves only the launch spans on the GPU clock, so that the launches run
  *                 back to back as they do unprofiled.
+ *   "force_pairs", "no_cell_ranks" (default 0): test hooks -- which key layout the sort is given (1: (code, index) pairs on
+ *                 small frames; 2: the point index kept in the key although nothing reads it) / the full varying Morton
+ *                 code sorted instead of cell ranks.  Same bytes either way.
  *   "rc_device_lanes" (default 0; process-wide): the device range coder (pcc_device_range_encode, pcc_entropy_batch_*) codes
  *                 one stream per LANE, 64 per wave, instead of one per wave -- same bytes; opt-in until it has been timed. */
 int pcc_set_option(pcc_ctx *ctx, const char *name, int value);

@@ -356,10 +356,10 @@ def test_codec_class_round_trip(pkg, oracle):
     assert abs(psnr(got, enc_bgr) - psnr(exp, enc_bgr)) <= 0.01
 
 
-def test_pair_sort_mode_matches_packed_mode(pkg, oracle, monkeypatch):
+def test_pair_sort_mode_matches_packed_mode(pkg, oracle):
     """Frames whose code + index bits exceed 64 sort (u64 code, u32 index) pairs; force that path on a small frame."""
-    monkeypatch.setenv("PCC_FORCE_PAIRS", "1")
     c = pkg.binding.Context(0)
+    c.set_option("force_pairs", 1)
     try:
         rng = np.random.default_rng(77)
         xyz = rng.uniform(0.1, 0.9, (70000, 3)).astype(np.float32)
@@ -376,9 +376,9 @@ def test_pair_sort_mode_matches_packed_mode(pkg, oracle, monkeypatch):
         c.close()
 
 
-def test_indexed_keys_match_bare_keys(pkg, oracle, monkeypatch):
+def test_indexed_keys_match_bare_keys(pkg, oracle):
     """Without centroids nothing reads the point index of a sorted element, so the sort keys are [code | colour] or the
-    code alone (8 B per key and pass); PCC_FORCE_PAIRS=2 keeps the [code | index] key + colour payload sort that frames
+    code alone (8 B per key and pass); option "force_pairs" = 2 keeps the [code | index] key + colour payload sort that frames
     with centroids use, on frames that would not need it.  Both ways give the oracle's bytes."""
     rng = np.random.default_rng(78)
     xyz = rng.uniform(0.1, 0.9, (150000, 3)).astype(np.float32)
@@ -386,9 +386,9 @@ def test_indexed_keys_match_bare_keys(pkg, oracle, monkeypatch):
     xyz = np.repeat(xyz, 2, axis=0)[rng.permutation(300000)]
     cases = (dict(octree_bits=9, color_coding_type=1), dict(octree_bits=8, color_coding_type=0), dict(octree_bits=10, color_coding_type=2),
              dict(octree_bits=9, color_bits=0), dict(octree_bits=11, color_coding_type=0, color_bits=5))
-    for mode in ("0", "2"):
-        monkeypatch.setenv("PCC_FORCE_PAIRS", mode)
+    for mode in (0, 2):
         c = pkg.binding.Context(0)
+        c.set_option("force_pairs", mode)
         try:
             for kw in cases:
                 assert_matches_oracle(pkg, oracle, c, cloud(pkg, xyz), **kw)
@@ -452,7 +452,7 @@ def test_crowded_voxels_beside_a_surface(pkg, oracle, ctx):
 def test_cell_ranks_save_a_sort_pass_and_change_nothing(pkg, oracle, monkeypatch):
     """A capture-like cloud (1024-voxel lattice) that straddles a high power-of-two boundary of its adaptive box varies in
     13 key bits per axis: 39 code bits, five sort passes.  The sorted code carries the rank of the 2^m-cell instead of the
-    high bits (FrameState::code_low_bits): four passes, the same bytes.  PCC_NO_CELL_RANKS=1 sorts the full code."""
+    high bits (FrameState::code_low_bits): four passes, the same bytes.  Option "no_cell_ranks" sorts the full code."""
     import ctypes as C
     b = pkg.binding
     lib = b.load_library()
@@ -462,8 +462,8 @@ def test_cell_ranks_save_a_sort_pass_and_change_nothing(pkg, oracle, monkeypatch
     clouds = [pts, cloud(pkg, (rng.uniform(0.0, 1.0, (60_000, 3)) * 0.23 + 0.38).astype(np.float32))]
     plans = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("PCC_NO_CELL_RANKS", mode)
         c = b.Context(0)
+        c.set_option("no_cell_ranks", int(mode))
         try:
             for k, p in enumerate(clouds):
                 for kw in (dict(octree_bits=10, color_coding_type=1), dict(octree_bits=10, color_coding_type=0, keep_centroid=1), dict(octree_bits=11, color_bits=0)):
