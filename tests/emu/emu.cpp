@@ -513,7 +513,11 @@ struct Pool {
   }
 };
 Pool& pool() {
-  static Pool* p = new Pool();  // never destroyed: the workers live as long as the process
+  // never destroyed: the workers live as long as the process.  (call_once rather than a function-local static: the `tsan`
+  // build runs this uninstrumented file under a ThreadSanitizer that sees pthread_once but not an inline guard check)
+  static Pool* p = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] { p = new Pool(); });
   return *p;
 }
 void ask_for_a_thread() { pool().more_threads_please(); }
@@ -633,6 +637,7 @@ extern "C" void __asan_after_dynamic_init() {}
 // accesses to thread-local variables alone -- every scalar __shared__ variable -- and this one does not): the same idea,
 // these are its callbacks.  libtsan is NOT linked: the checker is race.cpp.  The atomics below are the ones inside the
 // hooks of hip_runtime.h (already booked by the hook; a bare one from a running lane is booked here as agent scope).
+#ifndef PCC_EMU_REAL_TSAN   // (the `tsan` build of the Makefile links the real ThreadSanitizer for the HOST sources: its symbols, not these)
 #define PCC_TSAN_CB(N) \
   extern "C" void __tsan_read##N(void* a) { emu_touch((uintptr_t)a, N, false, __builtin_return_address(0)); } \
   extern "C" void __tsan_write##N(void* a) { emu_touch((uintptr_t)a, N, true, __builtin_return_address(0)); } \
@@ -671,6 +676,7 @@ struct BareAtomic {   // an atomic builtin that did not come through a hook of h
 PCC_TSAN_ATOMIC(8, uint8_t) PCC_TSAN_ATOMIC(16, uint16_t) PCC_TSAN_ATOMIC(32, uint32_t) PCC_TSAN_ATOMIC(64, uint64_t)
 extern "C" void __tsan_atomic_thread_fence(int mo) { if (emu::race::on()) emu::race::fence_bare(mo); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 extern "C" void __tsan_atomic_signal_fence(int) {}
+#endif  // PCC_EMU_REAL_TSAN
 
 hipError_t hipMalloc(void** p, size_t bytes) {
   if (void* t = emu::race::arena_alloc(bytes ? bytes : 256)) { memset(t, 0xA5, bytes); *p = t; return hipSuccess; }

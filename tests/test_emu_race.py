@@ -154,3 +154,29 @@ def test_a_seeded_plain_hand_off_is_caught(race_build, seed):
     assert plain in r.stdout and ("atomic load" if seed == "store" else "atomic write") in r.stdout
     # the hand-off of the sort plan from workgroup 0 to the streaming workgroups (fused mode) is among them
     assert r.stdout.count("k_boxes_events  [global") >= 3
+
+
+def test_the_host_pipeline_is_clean_under_threadsanitizer():
+    """The other half of "races": the pipeline's host threads.  pcc_pipeline.cpp / pcc_api.cpp / pcc_host_codec.cpp are compiled
+    with clang's -fsanitize=thread (the ROCm LLVM's: its runtime intercepts pthread_cond_clockwait; gcc 11's does not and drowns
+    the run in false reports), the kernels run on the executor, and a pipeline codes host frames, device frames, with the entropy
+    stage on the host and on the GPU, and behind the multi-GPU entry point -- every bitstream against the oracle, no report."""
+    import glob
+    import shutil
+    clang = os.environ.get("TSAN_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ with a ThreadSanitizer runtime here")
+    subprocess.run(["make", "-s", "-j8", "-C", EMU, "tsan"], check=True)
+    out = OUT + "_tsan"
+    runtime = open(os.path.join(out, "runtime.txt")).read().strip()
+    if not os.path.exists(runtime):
+        pytest.skip("clang's shared ThreadSanitizer runtime is not installed")
+    logs = os.path.join(out, "tsan_log")
+    for f in glob.glob(logs + ".*"):
+        os.remove(f)
+    env = dict(os.environ, LD_PRELOAD=runtime, PCC_LIB=os.path.join(out, "libpcc_emu_tsan.so"),
+               TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 log_path=" + logs)
+    r = subprocess.run([sys.executable, os.path.join(EMU, "tsan_pipeline.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "pipeline under ThreadSanitizer: done" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    reports = "".join(open(f).read() for f in glob.glob(logs + ".*"))
+    assert "WARNING: ThreadSanitizer" not in reports, reports[:6000]
