@@ -1754,7 +1754,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
     if (threadIdx.x < 64) s_cell_abs[threadIdx.x] = st->cell_abs[threadIdx.x];
     __syncthreads();
   }
-  const uint64_t lowmask = (1ull << cm3) - 1ull;
+  const uint64_t lowmask = ranked ? (1ull << cm3) - 1ull : ~0ull;  // (an unranked frame's cm3 can be 64 or more: no shift by it)
   auto unrank = [&](uint64_t c) { return ranked ? ((s_cell_abs[(c >> cm3) & 63u] << cm3) | (c & lowmask)) : c; };
   // Every wave owns 512 consecutive sorted keys, read as 8 rows of 64 (coalesced); element (r, lane)
   // is key wbase + 64 r + lane, so scan order is row-major inside the wave, then wave-major.
@@ -1921,8 +1921,9 @@ __device__ __forceinline__ void jpeg_fdct_1d(int& d0, int& d1, int& d2, int& d3,
   const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
   const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
   constexpr int DN = PASS1 ? 11 : 15;
-  d0 = PASS1 ? ((t10 + t11) << 2) : jpeg_descale(t10 + t11, 2);
-  d4 = PASS1 ? ((t10 - t11) << 2) : jpeg_descale(t10 - t11, 2);
+  // (jfdctint's "<< PASS1_BITS", on the unsigned representation: a left shift of a negative int is undefined before C++20)
+  d0 = PASS1 ? (int)((unsigned)(t10 + t11) << 2) : jpeg_descale(t10 + t11, 2);
+  d4 = PASS1 ? (int)((unsigned)(t10 - t11) << 2) : jpeg_descale(t10 - t11, 2);
   int z1 = (t12 + t13) * 4433;
   d2 = jpeg_descale(z1 + t13 * 6270, DN);
   d6 = jpeg_descale(z1 + t12 * (-15137), DN);

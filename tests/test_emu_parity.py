@@ -90,6 +90,33 @@ def test_the_default_forms_need_no_resident_grid(emu_libs):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
 
 
+def test_no_undefined_behaviour_in_the_kernel_sources():
+    """g++ (the executor) and clang (hipcc) are free to make different things of undefined behaviour -- an oversized shift, a
+    signed overflow -- so "green on the executor" only carries over for code that has none.  The kernel and host sources
+    compiled with -fsanitize=undefined, the parity tests of the default forms (and the device range coders, quality, outliers)
+    on that build: no report.  (Round 4 found two this way, both with identical gfx950 code before and after the fix: jfdctint's
+    `<< PASS1_BITS` of negative ints, and a 64-bit shift by 69 whose result was only used when the count was small.)"""
+    import glob
+    out = os.path.join(EMU, "_build_ubsan")
+    subprocess.run(["make", "-s", "-j8", "-C", EMU, "OUT=_build_ubsan", "OPT=-O1 -fsanitize=undefined -fno-sanitize=vptr,alignment"], check=True)
+    lib = os.path.join(out, "libpcc_emu.so")
+    rt = subprocess.run(["g++", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt):
+        pytest.skip("no libubsan here")
+    logs = os.path.join(out, "ubsan_log")
+    for f in glob.glob(logs + ".*"):
+        os.remove(f)
+    env = dict(os.environ, PCC_LIB=lib, LD_PRELOAD=rt + " " + lib, UBSAN_OPTIONS="log_path=" + logs)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "1500", "-n", "4",
+                        "tests/test_gpu_parity.py", "tests/test_rc_device.py", "tests/test_zz_optional_forms.py", "tests/test_quality.py", "tests/test_outliers.py",
+                        "-k", "cfg1_100k or appendix_f or nan_points or growth or test_modes_bitstream or pair_sort or cfg2_1m_depth10_surface or 22-kw0 or 29-kw3 "
+                              "or jpeg_lines_on_gpu or gpu_decode_equals or cell_ranks or random_sweep or range_coder or quality or outlier"],
+                       cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    reports = "".join(open(f).read() for f in glob.glob(logs + ".*"))
+    assert "runtime error" not in reports, reports[:4000]
+
+
 def test_fused_keys_read_the_cloud_once_in_the_traffic_model(emu_libs):
     """The executor's traffic model (outline access instrumentation; first-touch lines per XCD and launch): with fused keys the
     kernels in front of the sort touch the cloud's lines once, in the two-kernel form twice."""
