@@ -458,6 +458,11 @@ struct Pool {
         if (race::on()) {
           race::Where& where = race::tl_where;
           where.wg = bi; where.lane = -1; where.bepoch = 0; where.kname = w->kname;
+          if (!where.own_lo) {   // the four index variables lie side by side in this file's thread-local block
+            char* v[4] = {(char*)&threadIdx, (char*)&blockIdx, (char*)&blockDim, (char*)&gridDim};
+            where.own_lo = *std::min_element(v, v + 4);
+            where.own_hi = *std::max_element(v, v + 4) + sizeof(emu::Idx3);
+          }
           race::workgroup_begin();
           run_workgroup(w);
           race::workgroup_end();

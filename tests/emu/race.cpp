@@ -21,6 +21,10 @@
 //     two accesses of the same bytes by two different WAVES of the workgroup, at least one a write, not both atomics, with
 //     no workgroup barrier between them -- the missing __syncthreads(), which the executor's fixed wave order hides.
 //     (Lanes of one wave are in program order: never reported.)
+//   LDS, uninitialised
+//     a read of LDS bytes that no lane of the workgroup has written since the workgroup started.  On the chip LDS holds
+//     whatever the workgroup before left there; here it holds what the OS thread's previous workgroup left (or zeroes the
+//     first time) -- a kernel that relies on either is wrong on both, and only by luck visibly so.
 //
 // Any pattern a per-XCD store buffer would break (a plain store read by another XCD's workgroup before the launch ends)
 // is by definition a report of the first kind, so "zero reports" covers what a visibility model would show as wrong
@@ -84,11 +88,12 @@ struct WgState {
   std::unordered_map<uint64_t, std::array<Cell, 4>> lds_split;
 };
 
-struct Acc { uint32_t wg, epoch, bw, pc, mask; bool write, atomic; };
+struct Acc { uint32_t wg, epoch, bw, pc, mask; bool write, atomic, check_init; };
 
 struct Report {
   std::string kernel;
   bool lds;
+  bool uninit;
   uint32_t pc_now, pc_then;
   bool now_write, now_atomic, then_write, then_atomic;
   uint32_t wg_now, wave_now, wg_then, wave_then;
@@ -174,15 +179,15 @@ bool ordered(const Rec& r, const Acc& a, const WgState* st) {
   return it != st->vc.end() && it->second >= r.epoch;
 }
 
-void report(const Rec& then, bool then_write, const Acc& now, bool lds, uint64_t offset) {
+void report(const Rec& then, bool then_write, const Acc& now, bool lds, uint64_t offset, bool uninit = false) {
   Global& G = g();
   std::lock_guard<std::mutex> lk(G.rep_mu);
-  const std::array<uint64_t, 3> key{{(uint64_t)now.pc << 32 | then.pc, (uint64_t)lds, std::hash<std::string>()(G.kernel)}};
+  const std::array<uint64_t, 3> key{{(uint64_t)now.pc << 32 | then.pc, (uint64_t)lds | (uninit ? 2u : 0u), std::hash<std::string>()(G.kernel)}};
   auto it = G.reports.find(key);
   if (it != G.reports.end()) { ++it->second.count; return; }
   if (G.reports.size() >= 4096) return;
   Report r{};
-  r.kernel = G.kernel; r.lds = lds; r.pc_now = now.pc; r.pc_then = then.pc;
+  r.kernel = G.kernel; r.lds = lds; r.uninit = uninit; r.pc_now = now.pc; r.pc_then = then.pc;
   r.now_write = now.write; r.now_atomic = now.atomic; r.then_write = then_write; r.then_atomic = atomic_(then);
   r.wg_now = now.wg; r.wave_now = now.bw & 31u; r.wg_then = wg1(then) - 1u; r.wave_then = then.bw & 31u;
   r.offset = offset; r.count = 1;
@@ -202,6 +207,9 @@ void report(const Rec& then, bool then_write, const Acc& now, bool lds, uint64_t
 void one_cell(Cell& c, const Acc& a, uint32_t record_mask, const WgState* st, bool lds, uint64_t offset) {
   for (const Rec& w : c.w)
     if (wg1(w) && (bytes(w) & a.mask) && !(atomic_(w) && a.atomic) && !ordered(w, a, st)) report(w, true, a, lds, offset);
+  // LDS: bytes nobody in this workgroup has written yet (w[1]'s bytes are among w[0]'s; an atomic read-modify-write of
+  // such bytes reads them too)
+  if (lds && a.check_init && (a.mask & ~bytes(c.w[0])) != 0u) report(Rec{}, false, a, true, offset, true);
   if (a.write) {
     for (Rec& r : c.r)
       if (wg1(r) && (bytes(r) & a.mask) && !(atomic_(r) && a.atomic) && !ordered(r, a, st)) report(r, false, a, lds, offset);
@@ -257,7 +265,7 @@ void granule(Cell& c, uint32_t stamp, const Acc& a, SplitMap& sm, uint64_t key, 
   }
 }
 
-void touch(uintptr_t addr, size_t n, bool write, bool atomic, void* pc) {
+void touch(uintptr_t addr, size_t n, bool write, bool atomic, void* pc, bool reads = true) {
   Global& G = g();
   Where& w = tl_where;
   WgState* st = (WgState*)w.wgstate;
@@ -270,6 +278,9 @@ void touch(uintptr_t addr, size_t n, bool write, bool atomic, void* pc) {
   Acc a{};
   a.wg = w.wg; a.epoch = st->clock; a.bw = (w.bepoch << 5) | ((uint32_t)w.lane >> 6); a.write = write; a.atomic = atomic;
   a.pc = (uint32_t)((uintptr_t)pc - G.lib_base);
+  // reads (and the read half of a read-modify-write) of LDS want the bytes written before -- but not the executor's own
+  // thread-local variables in the same block (threadIdx & co: written by the scheduler, which is not instrumented)
+  a.check_init = lds && reads && !(addr >= (uintptr_t)w.own_lo && addr < (uintptr_t)w.own_hi);
   const uintptr_t base = global ? (uintptr_t)G.lo : (uintptr_t)w.lds_lo;
   const uint64_t first = (addr - base) >> 2, last = (addr + n - 1 - base) >> 2;
   for (uint64_t gi = first; gi <= last; ++gi) {
@@ -369,7 +380,7 @@ void access(uintptr_t addr, size_t n, bool store, void* pc) {
   Where& w = tl_where;
   if (w.lane < 0 || !w.wgstate) return;   // host code (or the checker is off)
   if (((WgState*)w.wgstate)->suppress) return;
-  touch(addr, n, store, false, pc);
+  touch(addr, n, store, false, pc, !store);
 }
 
 void atomic_begin(const void* p, size_t n, int order, int scope, int kind, void* pc) {
@@ -382,7 +393,7 @@ void atomic_begin(const void* p, size_t n, int order, int scope, int kind, void*
   // in global memory only agent scope (or wider) is atomic between workgroups; in LDS workgroup scope is all there is
   const bool agent = scope >= kScopeAgent;
   const bool counts_as_atomic = global ? agent : scope >= kScopeWorkgroup;
-  touch(addr, n, kind != 0, counts_as_atomic, pc);
+  touch(addr, n, kind != 0, counts_as_atomic, pc, kind != 1);   // (a plain atomic store reads nothing)
   st->suppress = true;
   st->at_addr = addr; st->at_order = order; st->at_kind = kind; st->at_agent = agent; st->at_global = global;
   if (!global || !agent || kind == 0) return;
@@ -454,7 +465,7 @@ extern "C" size_t pcc_emu_race_report(char* out, size_t cap) {
   for (auto& kv : G.reports) {
     const Report& r = kv.second;
     char line[512];
-    snprintf(line, sizeof(line), "%s %s %llu | %c %c 0x%x %u %u | %c %c 0x%x %u %u | %llu | %llu %llu %llu\n", r.kernel.c_str(), r.lds ? "lds" : "global",
+    snprintf(line, sizeof(line), "%s %s %llu | %c %c 0x%x %u %u | %c %c 0x%x %u %u | %llu | %llu %llu %llu\n", r.kernel.c_str(), r.uninit ? "lds-uninitialised" : (r.lds ? "lds" : "global"),
              (unsigned long long)r.offset, r.now_write ? 'W' : 'R', r.now_atomic ? 'a' : 'p', r.pc_now, r.wg_now, r.wave_now, r.then_write ? 'W' : 'R',
              r.then_atomic ? 'a' : 'p', r.pc_then, r.wg_then, r.wave_then, (unsigned long long)r.count, (unsigned long long)r.alloc_index,
              (unsigned long long)r.alloc_off, (unsigned long long)r.alloc_size);

@@ -15,6 +15,8 @@ struct Where {
   void* wgstate = nullptr;   // the checker's per-workgroup state
   char* lds_lo = nullptr;    // this OS thread's block of thread-local storage of the library = the LDS of the workgroup
   char* lds_hi = nullptr;
+  char* own_lo = nullptr;    // the executor's own thread-local variables that kernels read (threadIdx ... gridDim): not LDS
+  char* own_hi = nullptr;
   void* lds_shadow = nullptr;
   uint32_t lds_stamp = 0;
 };

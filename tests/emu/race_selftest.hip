@@ -118,6 +118,15 @@ __global__ void k_lds(uint32_t* out, int with_barrier, int atomics) {
   if (t >= 64) out[blockIdx.x * 64 + t - 64] = s_v[t - 64];  // wave 1 reads (every workgroup has an LDS of its own)
 }
 
+// ---- LDS read before anybody in the workgroup has written it
+__global__ void k_lds_uninitialised(uint32_t* out, int init) {
+  __shared__ uint32_t s_u[64];
+  const uint32_t t = threadIdx.x;
+  if (init) s_u[t] = t;
+  __syncthreads();
+  out[blockIdx.x * 64 + t] = s_u[63 - t];
+}
+
 // ---- global memory, wave to wave inside a workgroup
 __global__ void k_global_in_workgroup(uint32_t* buf, uint32_t* out, int with_barrier) {
   const uint32_t t = threadIdx.x;
@@ -163,6 +172,10 @@ int main() {
   printf("lds_atomics_with_barrier %d\n", reports());
   hipLaunchKernelGGL(k_lds, dim3(2), dim3(128), 0, nullptr, out, 0, 1);
   printf("lds_atomics_missing_barrier %d\n", reports());
+  hipLaunchKernelGGL(k_lds_uninitialised, dim3(2), dim3(64), 0, nullptr, out, 1);
+  printf("lds_written_before_read %d\n", reports());
+  hipLaunchKernelGGL(k_lds_uninitialised, dim3(2), dim3(64), 0, nullptr, out, 0);
+  printf("lds_read_uninitialised %d\n", reports());
   hipLaunchKernelGGL(k_global_in_workgroup, dim3(1), dim3(128), 0, nullptr, data, out, 1);
   printf("global_in_workgroup_with_barrier %d\n", reports());
   hipLaunchKernelGGL(k_global_in_workgroup, dim3(1), dim3(128), 0, nullptr, data, out, 0);

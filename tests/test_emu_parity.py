@@ -93,12 +93,12 @@ def test_the_default_forms_need_no_resident_grid(emu_libs):
 def test_no_undefined_behaviour_in_the_kernel_sources():
     """g++ (the executor) and clang (hipcc) are free to make different things of undefined behaviour -- an oversized shift, a
     signed overflow -- so "green on the executor" only carries over for code that has none.  The kernel and host sources
-    compiled with -fsanitize=undefined, the parity tests of the default forms (and the device range coders, quality, outliers)
+    compiled with -fsanitize=undefined,float-cast-overflow (misaligned vector accesses and doubles outside the range of the integer they are converted to included), the parity tests of the default forms (and the device range coders, quality, outliers)
     on that build: no report.  (Round 4 found two this way, both with identical gfx950 code before and after the fix: jfdctint's
     `<< PASS1_BITS` of negative ints, and a 64-bit shift by 69 whose result was only used when the count was small.)"""
     import glob
     out = os.path.join(EMU, "_build_ubsan")
-    subprocess.run(["make", "-s", "-j8", "-C", EMU, "OUT=_build_ubsan", "OPT=-O1 -fsanitize=undefined -fno-sanitize=vptr,alignment"], check=True)
+    subprocess.run(["make", "-s", "-j8", "-C", EMU, "OUT=_build_ubsan", "OPT=-O1 -fsanitize=undefined,float-cast-overflow -fno-sanitize=vptr"], check=True)
     lib = os.path.join(out, "libpcc_emu.so")
     rt = subprocess.run(["g++", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
     if not os.path.isabs(rt):

@@ -36,9 +36,10 @@ def test_the_checker_reports_known_races_and_nothing_else(race_build):
     assert r.returncode == 0, r.stderr[-2000:]
     got = {l.split()[0]: int(l.split()[1]) for l in r.stdout.splitlines() if l.strip()}
     clean = ["release_acquire", "agent_fences", "self_describing_words", "rmw_release_chain", "disjoint_bytes_of_a_dword", "across_launches",
-             "lds_with_barrier", "lds_atomics_with_barrier", "global_in_workgroup_with_barrier"]
+             "lds_with_barrier", "lds_atomics_with_barrier", "global_in_workgroup_with_barrier", "lds_written_before_read"]
     racy = {"plain_flag": 2, "relaxed_flag_plain_data": 1, "workgroup_scope_atomics": 2, "workgroup_scope_fences": 1, "rmw_relaxed_chain": 2,
-            "same_byte_two_workgroups": 1, "lds_missing_barrier": 1, "lds_atomics_missing_barrier": 1, "global_in_workgroup_missing_barrier": 1}
+            "same_byte_two_workgroups": 1, "lds_missing_barrier": 1, "lds_atomics_missing_barrier": 1, "global_in_workgroup_missing_barrier": 1,
+            "lds_read_uninitialised": 1}
     assert set(got) == set(clean) | set(racy), got
     for k in clean:
         assert got[k] == 0, (k, got)
