@@ -90,6 +90,25 @@ def test_the_default_forms_need_no_resident_grid(emu_libs):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
 
 
+def test_the_executor_built_by_the_device_compilers_front_end_agrees():
+    """The same sources through the ROCm LLVM's clang++ at -O3 (the front end and optimiser that also compile the device code;
+    only the back end differs) instead of g++: what that compiler makes of aliasing, inlining and undefined corners is what
+    hipcc makes of them.  The parity tests of the default forms, the decoders and the device range coders on that build.
+    (The whole `-m gpu` suite passes on it too: 195 tests when last run.)"""
+    clang = os.environ.get("EMU_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm clang++ here")
+    subprocess.run(["make", "-s", "-j8", "-C", EMU, "CXX=" + clang, "OUT=_build_clang", "OPT=-O3",
+                    "DEFS=-Wno-unknown-warning-option -Wno-unused-command-line-argument -Wno-gnu-inline-cpp-without-extern"], check=True)
+    rc, passed, tail = run_gpu_tests(os.path.join(EMU, "_build_clang", "libpcc_emu.so"),
+                                     ["tests/test_gpu_parity.py", "tests/test_rc_device.py", "tests/test_zz_optional_forms.py", "tests/test_codec_golden.py"],
+                                     NOT_ON_THE_EXECUTOR + LONG,
+                                     ["-k", "cfg1_100k or appendix_f or nan_points or growth or test_modes_bitstream or pair_sort or cfg2_1m_depth10 or 22_to_31 or "
+                                            "jpeg_lines_on_gpu or gpu_decode or cell_ranks or random_sweep or range_coder or golden"])
+    assert rc == 0, tail
+    assert passed >= 60, tail
+
+
 def test_no_undefined_behaviour_in_the_kernel_sources():
     """g++ (the executor) and clang (hipcc) are free to make different things of undefined behaviour -- an oversized shift, a
     signed overflow -- so "green on the executor" only carries over for code that has none.  The kernel and host sources
