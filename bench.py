@@ -326,12 +326,13 @@ def main():
         dom_bytes = kernel_algorithmic_bytes(dominant, n_points, L, B, with_color, image_bytes)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         sum_spans = float(sum(span_frame_ms.values()))
-        traffic = None
+        traffic = traffic_taken = None   # (PMC counters need their own rocprofv3 passes: the figure comes from a file, and says from when)
         try:
             with open(args.traffic_json or os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)) as fh:
                 tj = json.load(fh)
             if tj.get("workload") == args.workload:
                 traffic = tj.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
+                traffic_taken = tj.get("taken", "a separate rocprofv3 --pmc run (tools/pmc_run.sh)") if traffic is not None else None
         except (OSError, ValueError):
             pass
         # inside the timed region several frames share the GPU: what the same kernel takes there (HIP events on ONE
@@ -340,7 +341,7 @@ def main():
         shared = {k: v[0] / v[1] for k, v in ktimes.items() if v[1] and not k.startswith("begin")}
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_taken": traffic_taken,
             "kernel_avg_ms": round(dom_ms, 5), "kernel_bytes_per_launch": int(dom_bytes),
             "kernel_launches_per_frame": round(launches[dominant], 2),
             "kernel_span_ms": round(span_ms, 5),

@@ -34,7 +34,14 @@ for name in sorted(set(fetch) | set(write)):
     wm = sum(w[len(w) // 4:]) / max(1, len(w[len(w) // 4:])) if w else 0.0
     kernels[name] = {"fetch_size_kb_raw": round(fm, 2), "write_size_kb_raw": round(wm, 2),
                      "hbm_bytes_per_launch": int(fm * 1024 * 2 + wm * 1024), "launches_sampled": len(f)}
-res = {"workload": workload, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/gpu_latency.py; "
+import subprocess  # noqa: E402
+import time  # noqa: E402
+try:
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cwi-pcl-codec_amd", "libpcc_hip.so")
+    built = time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime(os.path.getmtime(lib)))
+except OSError:
+    built = "?"
+res = {"workload": workload, "taken": "%s, on the library built %s" % (time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()), built), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/gpu_latency.py; "
        "bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 correction of MI355X_MICROARCH.md)", "kernels": kernels}
 json.dump(res, open(os.path.join(out_dir, "hbm_traffic_%s.json" % workload), "w"), indent=1)
 print(json.dumps(res, indent=1))
