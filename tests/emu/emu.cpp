@@ -29,6 +29,11 @@
 
 thread_local emu::Idx3 threadIdx, blockIdx, blockDim, gridDim;
 
+// AddressSanitizer builds of the executor (make OUT=_build_asan OPT="-O1 -fsanitize=address"): the lanes' stacks are mapped and
+// unmapped here, and a region that still carries the redzone poison of frames that once lived on it must not be handed back
+// to the process like that (the next owner of the addresses would be reported for touching "stack redzones")
+extern "C" void __asan_unpoison_memory_region(void const volatile*, size_t) __attribute__((weak));
+
 namespace emu {
 namespace {
 
@@ -103,6 +108,7 @@ void lane_entry() {
 
 void prepare_lane(Worker* w, int i) {
   char* top = w->stacks + (size_t)(i + 1) * kStackBytes;
+  if (__asan_unpoison_memory_region) __asan_unpoison_memory_region(top - kStackBytes, kStackBytes);  // (a lane that ended inside frames left their redzones)
   uintptr_t sp = (uintptr_t)top & ~(uintptr_t)15;
   // layout popped by emu_switch: r15 r14 r13 r12 rbx rbp, then the return address; after `ret` rsp % 16 must be 8
   sp -= 8;  // alignment slot: entry sees rsp % 16 == 8
@@ -416,7 +422,10 @@ struct Pool {
     size_t stack_lanes = 0;  // the lanes' stacks: address space for as many as the largest workgroup this thread has run
     auto stacks_for = [&](size_t lanes) {
       if (lanes <= stack_lanes) return;
-      if (w->stacks) munmap(w->stacks, kStackBytes * stack_lanes);
+      if (w->stacks) {
+        if (__asan_unpoison_memory_region) __asan_unpoison_memory_region(w->stacks, kStackBytes * stack_lanes);
+        munmap(w->stacks, kStackBytes * stack_lanes);
+      }
       w->stacks = (char*)mmap(nullptr, kStackBytes * lanes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
       if (w->stacks == MAP_FAILED) { perror("wave64 executor: mmap of the lanes' stacks"); abort(); }
       stack_lanes = lanes;

