@@ -441,7 +441,8 @@ def main():
                                    (args.workload, n_points, "sphere-shell" if cfg["gen"] == "sphere" else "uniform-volume",
                                     cfg["octree_bits"],
                                     "colour JPEG snake q%d" % cfg["jpeg_quality"] if with_color else "geometry only"),
-                       "frames_per_gpu": args.steps, "host_threads_per_gpu": pipe.workers, "L": int(L), "B": int(B),
+                       "frames_per_gpu": args.steps, "host_threads_per_gpu": pipe.workers,
+                       "frames_per_coder_call": int(os.environ.get("PCC_PIPELINE_BATCH", "4")), "L": int(L), "B": int(B),
                        "depth": int(depth), "bitstream_bytes": int(nbytes),
                        "sharding": "frame f -> gpu f mod N, no collectives"},
             "gpu_only_mpoints_per_s": round(gpu_only_fps * n_points / 1e6, 1),

@@ -1036,9 +1036,9 @@ int pcc_entropy_encode(pcc_ctx* ctx, const pcc_hot_result* hot, const pcc_params
 int pcc_entropy_encode_many(int n, pcc_ctx* const ctx[], const pcc_hot_result* const hot[], const pcc_params* const prm[],
                             pcc_bitstream* const out[]) {
   if (n < 1 || n > PCC_MAX_FRAMES_AT_ONCE || !ctx || !hot || !prm || !out) return PCC_ERR_ARG;
-  Bytes* o[PCC_MAX_FRAMES_AT_ONCE];
-  uint64_t* pf[PCC_MAX_FRAMES_AT_ONCE];
-  double* t[PCC_MAX_FRAMES_AT_ONCE];
+  Bytes* o[PCC_MAX_FRAMES_AT_ONCE] = {};
+  uint64_t* pf[PCC_MAX_FRAMES_AT_ONCE] = {};
+  double* t[PCC_MAX_FRAMES_AT_ONCE] = {};
   for (int i = 0; i < n; ++i) {
     if (!ctx[i] || !hot[i] || !prm[i] || !out[i]) return PCC_ERR_ARG;
     for (int k = 0; k < i; ++k)

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <system_error>
 #include <thread>
 #include <cstdio>
@@ -271,7 +272,125 @@ void rc_run4(RcStream* sb, size_t i0, size_t i1) {
     PCC_RC_STORE(0, &sb[0]) PCC_RC_STORE(1, &sb[1]) PCC_RC_STORE(2, &sb[2]) PCC_RC_STORE(3, &sb[3])
   }
 }
+// ---- five to sixteen streams: one stream per 32-bit lane of AVX-512 registers --------------------------------------------
+// The scalar loops above stop gaining at four or five streams (measured: 2.29 ns per symbol and stream with four, 2.15 with
+// six to eight: the multiplier and the store port are full).  The same arithmetic on sixteen streams at once in vector
+// registers: the table entry start | width << 16 of each lane's symbol by one gather out of a 16 KB table block, range / total
+// as the multiply-high by the 64-bit reciprocal done on the even and the odd lanes (32 x 32 -> 64 multiplies), the settled
+// bytes of all lanes found by one vplzcntd and written by two scatters of the byte-swapped `low` (four bytes are stored, k of
+// them count, as in the scalar step), the rare range underflow lane by lane in PCL's own loop.  Same bytes by construction:
+// every lane computes exactly the scalar step (tests/test_host_stage.py holds all widths against each other).
+// tools/ubench/rc_many.cpp: 1.35-1.40 ns per symbol and stream on the build container's Xeon (AVX-512 on two ports) against
+// 2.29 for four scalar streams; not yet timed on the GPU box's EPYC.
+struct alignas(64) RcWide {
+  uint32_t tab[16 * 256];
+  uint32_t ml[16], mh[16], low[16], range[16];
+  uint64_t inp[16], outp[16];
+};
+#define PCC_T512 __attribute__((target("avx512f,avx512cd,avx512bw,avx512dq,avx512vl")))
+// symbols [i0, i1) of the lanes in `live`; (i1 - i0) % 4 == 0 and every live lane's stream holds i1 symbols at least
+PCC_T512 void rc_run_wide(RcWide& L, __mmask16 live, size_t i0, size_t i1) {
+  const __mmask8 live_lo = (__mmask8)live, live_hi = (__mmask8)(live >> 8);
+  const __m512i lane256 = _mm512_mullo_epi32(_mm512_set_epi32(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0), _mm512_set1_epi32(256));
+  const __m512i ML = _mm512_load_si512(L.ml), MH = _mm512_load_si512(L.mh);
+  const __m512i MLo = _mm512_srli_epi64(ML, 32), MHo = _mm512_srli_epi64(MH, 32);
+  const __m512i himask = _mm512_set1_epi64((long long)0xffffffff00000000ull);
+  const __m512i bsw = _mm512_set4_epi32(0x0c0d0e0f, 0x08090a0b, 0x04050607, 0x00010203);
+  const __m512i kbot = _mm512_set1_epi32((int)kBottom);
+  __m512i low = _mm512_load_si512(L.low), range = _mm512_load_si512(L.range);
+  const __m512i in0 = _mm512_load_si512(L.inp), in1 = _mm512_load_si512(L.inp + 8);
+  __m512i p0 = _mm512_load_si512(L.outp), p1 = _mm512_load_si512(L.outp + 8);
+  for (size_t i = i0; i < i1; i += 4) {
+    const __m512i off = _mm512_set1_epi64((long long)i);
+    const __m256i w0 = _mm512_mask_i64gather_epi32(_mm256_setzero_si256(), live_lo, _mm512_add_epi64(in0, off), nullptr, 1);
+    const __m256i w1 = _mm512_mask_i64gather_epi32(_mm256_setzero_si256(), live_hi, _mm512_add_epi64(in1, off), nullptr, 1);
+    __m512i word = _mm512_inserti64x4(_mm512_castsi256_si512(w0), w1, 1);  // four symbols of every lane
+    for (int j = 0; j < 4; ++j) {
+      const __m512i sym = _mm512_and_si512(word, _mm512_set1_epi32(0xff));
+      word = _mm512_srli_epi32(word, 8);
+      const __m512i fw = _mm512_i32gather_epi32(_mm512_add_epi32(sym, lane256), L.tab, 4);
+      const __m512i f = _mm512_and_si512(fw, _mm512_set1_epi32(0xffff)), w = _mm512_srli_epi32(fw, 16);
+      // q = range / total = mulhi64(magic, range): even lanes and odd lanes apart, the quotient of an odd lane lands in place
+      const __m512i ro = _mm512_srli_epi64(range, 32);
+      const __m512i ae = _mm512_srli_epi64(_mm512_mul_epu32(range, ML), 32), ao = _mm512_srli_epi64(_mm512_mul_epu32(ro, MLo), 32);
+      const __m512i be = _mm512_add_epi64(_mm512_mul_epu32(range, MH), ae), bo = _mm512_add_epi64(_mm512_mul_epu32(ro, MHo), ao);
+      const __m512i q = _mm512_or_si512(_mm512_srli_epi64(be, 32), _mm512_and_si512(bo, himask));
+      low = _mm512_add_epi32(low, _mm512_mullo_epi32(f, q));
+      range = _mm512_mullo_epi32(q, w);
+      const __m512i x = _mm512_xor_si512(low, _mm512_add_epi32(low, range));
+      const __m512i lz = _mm512_lzcnt_epi32(x);  // x != 0 because range != 0
+      const __m512i k8 = _mm512_and_si512(lz, _mm512_set1_epi32(0x18)), k = _mm512_srli_epi32(lz, 3);
+      const __m512i bytes = _mm512_shuffle_epi8(low, bsw);
+      _mm512_mask_i64scatter_epi32(nullptr, live_lo, p0, _mm512_castsi512_si256(bytes), 1);
+      _mm512_mask_i64scatter_epi32(nullptr, live_hi, p1, _mm512_extracti64x4_epi64(bytes, 1), 1);
+      p0 = _mm512_add_epi64(p0, _mm512_cvtepu32_epi64(_mm512_castsi512_si256(k)));
+      p1 = _mm512_add_epi64(p1, _mm512_cvtepu32_epi64(_mm512_extracti64x4_epi64(k, 1)));
+      low = _mm512_sllv_epi32(low, k8);
+      range = _mm512_sllv_epi32(range, k8);
+      const __mmask16 under = _mm512_mask_cmplt_epu32_mask(live, range, kbot);
+      if (__builtin_expect(under != 0, 0)) {  // rare: the lanes concerned go through PCL's loop one by one
+        alignas(64) uint32_t lo_[16], ra_[16];
+        alignas(64) uint64_t pp[16];
+        _mm512_store_si512(lo_, low); _mm512_store_si512(ra_, range); _mm512_store_si512(pp, p0); _mm512_store_si512(pp + 8, p1);
+        for (unsigned m = under; m; m &= m - 1) {
+          const int l = __builtin_ctz(m);
+          uint32_t lw = lo_[l], rg = (0u - lo_[l]) & (kBottom - 1);
+          uint8_t* p = reinterpret_cast<uint8_t*>(pp[l]);
+          for (;;) {
+            *p++ = (uint8_t)(lw >> 24);
+            rg <<= 8;
+            lw <<= 8;
+            if ((lw ^ (lw + rg)) >= kTop) {
+              if (rg >= kBottom) break;
+              rg = (0u - lw) & (kBottom - 1);
+            }
+          }
+          lo_[l] = lw; ra_[l] = rg; pp[l] = reinterpret_cast<uint64_t>(p);
+        }
+        low = _mm512_load_si512(lo_); range = _mm512_load_si512(ra_); p0 = _mm512_load_si512(pp); p1 = _mm512_load_si512(pp + 8);
+      }
+    }
+  }
+  _mm512_store_si512(L.low, low); _mm512_store_si512(L.range, range); _mm512_store_si512(L.outp, p0); _mm512_store_si512(L.outp + 8, p1);
+}
+// symbols [i0, i1) of streams sb[0 .. live): blocks of kRcBlock through the vector loop, what is left (fewer than four symbols
+// per stream) through the scalar one
+void rc_run_many_wide(RcStream* sb, int live, size_t i0, size_t i1, RcWide& L) {
+  const __mmask16 mask = (__mmask16)((1u << live) - 1u);
+  for (int l = 0; l < 16; ++l) {
+    const RcStream& s = sb[l < live ? l : 0];
+    for (int y = 0; y < 256; ++y) L.tab[l * 256 + y] = (uint32_t)s.fw[y] | ((uint32_t)(s.fw[y] >> 32) << 16);  // start, width < 2^16
+    L.ml[l] = (uint32_t)s.magic; L.mh[l] = (uint32_t)(s.magic >> 32);
+    L.inp[l] = reinterpret_cast<uint64_t>(s.in);
+  }
+  const size_t vec_end = i0 + ((i1 - i0) & ~(size_t)3);
+  for (size_t b = i0; b < vec_end; b += kRcBlock) {
+    const size_t e = std::min(b + kRcBlock, vec_end);
+    for (int l = 0; l < 16; ++l) {
+      RcStream& s = sb[l < live ? l : 0];
+      if (l < live) s.ensure(kRcBlockBytes);
+      L.low[l] = s.low; L.range[l] = l < live ? s.range : ~0u;   // (a lane that is switched off keeps a harmless state)
+      L.outp[l] = reinterpret_cast<uint64_t>(s.payload() + s.pos);
+    }
+    rc_run_wide(L, mask, b, e);
+    for (int l = 0; l < live; ++l) {
+      sb[l].low = L.low[l]; sb[l].range = L.range[l];
+      sb[l].pos = (size_t)(reinterpret_cast<uint8_t*>(L.outp[l]) - sb[l].payload());
+    }
+  }
+  for (int l = 0; l < live && vec_end < i1; ++l) rc_run1(sb + l, vec_end, i1);
+}
 }  // namespace
+
+bool StaticRangeCoder::wide_available() {
+  static const bool ok = [] {
+    const char* e = getenv("PCC_RC_WIDE");
+    if (e && e[0] == '0') return false;
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && __builtin_cpu_supports("avx512bw") &&
+           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
+  }();
+  return ok;
+}
 
 void StaticRangeCoder::encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[],
                                    const uint32_t* const counts[]) {
@@ -283,10 +402,26 @@ void StaticRangeCoder::encode_many(int count, const uint8_t* const in[], const s
   std::stable_sort(idx, idx + count, [&](int x, int y) { return n[x] > n[y]; });
   for (int k = 0; k < count; ++k) st[k].begin(in[idx[k]], n[idx[k]], *out[idx[k]], counts ? counts[idx[k]] : nullptr);
   size_t done = 0;
+  std::unique_ptr<RcWide> wide;
   for (int live = count; live > 0; --live) {
     const size_t upto = st[live - 1].n;  // the shortest stream still running ends here
     if (upto > done) {
-      if (live == 4) rc_run4(st, done, upto);
+      if (live > kInterleave) {
+        // (a vector step costs the same however many of its sixteen lanes are in use: below ten streams two or three scalar
+        //  loops of four are the faster way)
+        if (live >= 10 && wide_available()) {
+          if (!wide) wide.reset(new RcWide());
+          rc_run_many_wide(st, live, done, upto, *wide);
+        } else {  // no AVX-512 here: scalar loops of four streams (and what is left), one group after the other
+          for (int g = 0; g < live; g += kInterleave) {
+            const int m = std::min(kInterleave, live - g);
+            if (m == 4) rc_run4(st + g, done, upto);
+            else if (m == 3) rc_run3(st + g, done, upto);
+            else if (m == 2) rc_run2(st + g, done, upto);
+            else rc_run1(st + g, done, upto);
+          }
+        }
+      } else if (live == 4) rc_run4(st, done, upto);
       else if (live == 3) rc_run3(st, done, upto);
       else if (live == 2) rc_run2(st, done, upto);
       else rc_run1(st, done, upto);
@@ -1353,7 +1488,7 @@ void colour_stream_source(const pcc_hot_result& hot, const pcc_params& prm, Byte
   colour_payload(hot, prm, payload, src, src_len);
 }
 
-// Up to four frames at a time: every range-coder stage codes the streams of all frames in one loop
+// Up to sixteen frames at a time (four by default): every range-coder stage codes the streams of all frames in one call
 // (StaticRangeCoder::encode_many): same bytes, a fraction of the time per frame.
 void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_params* const prm[], Bytes* const out[],
                            uint64_t* const perf[], double* const times_us[]) {
@@ -1387,11 +1522,11 @@ void entropy_encode_frames(int n, const pcc_hot_result* const hot[], const pcc_p
   // One or two frames leave coder slots free (four streams share a loop, and one coder alone uses a fraction of a
   // core): their colour streams ride along with their occupancy streams instead of waiting for them -- a lone frame's
   // stage 3.3 -> 2.9 ms.  The colour stream is coded into a buffer of its own and appended where it belongs.
-  const bool ride_along = 2 * n <= kMax;
+  const bool ride_along = 2 * n <= StaticRangeCoder::kInterleave;
   Bytes payload[kMax], colour_rc[kMax];
-  uint64_t colour_got[kMax] = {0, 0, 0, 0};
-  size_t colour_len[kMax] = {0, 0, 0, 0};
-  const uint8_t* colour_src[kMax] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t colour_got[kMax] = {};
+  size_t colour_len[kMax] = {};
+  const uint8_t* colour_src[kMax] = {};
   Clock::time_point t0 = Clock::now();
   if (ride_along) {
     for (int i = 0; i < n; ++i)

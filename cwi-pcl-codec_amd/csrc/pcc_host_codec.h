@@ -33,8 +33,12 @@ class StaticRangeCoder {
   // appends 1028-byte table + payload + 4 flush bytes to `out`; returns bytes appended
   static size_t encode(const uint8_t* in, size_t n, Bytes& out);
   // up to kMaxStreams independent streams coded in one loop (same bytes as separate encode() calls; see the
-  // .cpp); the output vectors must be distinct; got[i] = bytes appended to *out[i]
-  static constexpr int kMaxStreams = 4;
+  // .cpp); the output vectors must be distinct; got[i] = bytes appended to *out[i].  Up to kInterleave streams share a
+  // scalar loop; five to sixteen go through the lanes of AVX-512 registers where the CPU has them (wide_available()),
+  // else through scalar loops of four, one group after the other.
+  static constexpr int kMaxStreams = 16;
+  static constexpr int kInterleave = 4;
+  static bool wide_available();   // AVX-512 F/CD/BW/DQ/VL on this CPU and not switched off (PCC_RC_WIDE=0)
   // counts[i]: the 256-bin histogram of in[i] if it is known already, else null (counts itself may be null)
   static void encode_many(int count, const uint8_t* const in[], const size_t n[], Bytes* const out[], size_t got[],
                           const uint32_t* const counts[] = nullptr);

@@ -80,7 +80,10 @@ struct pcc_pipeline {
   size_t pin_cores_taken = 0;  // of g_pin_cores_taken, given back when the pipeline is destroyed
   int gpu_batch = 256;
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
-  int batch = PCC_MAX_FRAMES_AT_ONCE;  // most frames an entropy thread codes in one loop
+  // most frames an entropy thread codes in one call: four share a scalar loop (the default, measured on the GPU box);
+  // PCC_PIPELINE_BATCH=16: sixteen through AVX-512 lanes (1.47 against 2.00 ns per symbol and stream on the build container's
+  // Xeon, tools/ubench/rc_many.cpp; not yet timed on the GPU box's EPYC) -- every entropy thread then holds up to sixteen contexts
+  int batch = 4;
   // developer aid (PCC_PIPELINE_TRACE=1): when each frame of a call left the GPU stage, when its coder loop started and ended,
   // how many frames shared the loop (microseconds since the call started; printed to stderr for calls of up to 64 frames)
   struct FrameTrace { double launched = 0, gpu_done = 0, ent_start = 0, ent_end = 0, stored = 0; int batch = 0, thread = -1; };

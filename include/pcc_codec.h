@@ -188,8 +188,9 @@ int pcc_entropy_encode(pcc_ctx *ctx_for_output, const pcc_hot_result *hot, const
 
 /* The same for several frames at once (different contexts): the serial range-coder loops of the frames are
  * interleaved in one loop, which costs a fraction of the time per frame (each symbol is a chain of dependent
- * operations that leaves most of a core idle).  Bytes identical to separate pcc_entropy_encode calls. */
-#define PCC_MAX_FRAMES_AT_ONCE 4
+ * operations that leaves most of a core idle).  Bytes identical to separate pcc_entropy_encode calls.  Up to four frames share
+ * a scalar loop; ten to sixteen go through AVX-512 lanes where the host CPU has them (else through scalar loops of four). */
+#define PCC_MAX_FRAMES_AT_ONCE 16
 int pcc_entropy_encode_many(int n, pcc_ctx *const ctx[], const pcc_hot_result *const hot[], const pcc_params *const prm[],
                             pcc_bitstream *const out[]);
 int pcc_entropy_encode2(pcc_ctx *ctx_a, const pcc_hot_result *hot_a, const pcc_params *prm_a, pcc_bitstream *out_a,
@@ -411,10 +412,11 @@ const char *pcc_entropy_batch_last_error(pcc_entropy_batch *b);
  * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */
 size_t pcc_host_range_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap);
 size_t pcc_host_range_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t n);
-/* The same coder for up to four independent vectors in ONE loop -- how the entropy stage codes the streams of the frames
- * it holds (a lone coder is a chain of dependent operations and leaves most of a core idle).  Every out[i] gets exactly the
- * bytes pcc_host_range_encode gives for in[i]; out_len[i] = encoded size, 0 if out_cap[i] is too small.  Returns PCC_OK,
- * or PCC_ERR_ARG for count outside 1..4. */
+/* The same coder for up to sixteen independent vectors in ONE call -- how the entropy stage codes the streams of the frames
+ * it holds (a lone coder is a chain of dependent operations and leaves most of a core idle): up to four share a scalar loop,
+ * ten and more go through the lanes of AVX-512 registers where the CPU has them.  Every out[i] gets exactly the bytes
+ * pcc_host_range_encode gives for in[i]; out_len[i] = encoded size, 0 if out_cap[i] is too small.  Returns PCC_OK, or
+ * PCC_ERR_ARG for count outside 1..16. */
 int pcc_host_range_encode_many(int count, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
                                const size_t *out_cap, size_t *out_len);
 /* JPEGWriter::writeJPEG / JPEGReader::readJPEG (jpeg_io.hpp:211-330 / 90-192), RGB, 4:2:0 */

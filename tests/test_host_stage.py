@@ -114,7 +114,52 @@ def test_range_coders_sharing_a_loop_match_oracle(pkg, oracle, lengths):
 
 def test_range_encode_many_refuses_bad_counts(pkg):
     with pytest.raises(pkg.binding.PccError):
-        pkg.binding.host_range_encode_many([b"ab"] * 5)
+        pkg.binding.host_range_encode_many([b"ab"] * 17)
+
+
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_five_to_sixteen_range_coders_in_one_call_match_the_oracle(pkg, oracle, wide):
+    """Ten and more vectors go through the lanes of AVX-512 registers where the CPU has them (one stream per 32-bit lane, the
+    same arithmetic per lane; PCC_RC_WIDE=0 or a CPU without AVX-512: scalar loops of four, one group after the other), five
+    to nine through scalar loops of four.  Every count from 5 to 16, ragged lengths (the vector loop hands over to narrower
+    loops as streams end, and takes its symbols four at a time), tables that need the 2^16 rescale, streams skewed enough for
+    the range-underflow branch, empty and one-symbol vectors: each vector as the oracle codes it alone.  A child process,
+    because the switch is read once."""
+    import subprocess, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import __graft_entry__ as G
+        from oracle import oracle as O
+        b = G.load_package().binding
+        rng = np.random.default_rng(2026)
+        def vector(kind, n):
+            if kind == 0:      # occupancy-like
+                bits = rng.integers(0, 8, (n, 3)); keep = rng.random((n, 3)) < np.array([1.0, 0.45, 0.15])
+                return np.bitwise_or.reduce(np.where(keep, 1 << bits, 0), axis=1).astype(np.uint8).tobytes()
+            if kind == 1:      # very skewed: the underflow branch
+                return np.where(rng.integers(0, 1000, n) < 995, 255, rng.integers(0, 256, n)).astype(np.uint8).tobytes()
+            if kind == 2:
+                return np.minimum(rng.geometric(0.08, n), 255).astype(np.uint8).tobytes()
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        checked = 0
+        for count in range(5, 17):
+            for trial in range(2):
+                if trial == 0:   # about equal lengths, like the frames of a sequence
+                    lens = [60_000 + int(rng.integers(0, 4_000)) for _ in range(count)]
+                else:            # ragged, with degenerate ones
+                    lens = [int(x) for x in rng.choice([0, 1, 3, 5, 257, 1_023, 4_099, 70_001, 20_000, 33_333], count)]
+                vs = [vector((k + trial) %% 4, n) for k, n in enumerate(lens)]
+                got = b.host_range_encode_many(vs)
+                for v, g in zip(vs, got):
+                    assert g == O.rc_encode(v), (count, trial, len(v))
+                    checked += 1
+        print("OK", checked)
+    """ % ROOT)
+    env = dict(os.environ, PCC_RC_WIDE=wide)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_jpeg_matches_libjpeg_turbo_golden(pkg):
@@ -243,6 +288,27 @@ def test_four_frames_at_once_give_the_same_bytes(pkg, oracle):
         hr, keep = _hot_from_oracle(pkg, r)
         hrs.append(hr); prms.append(b.make_params(**kw)); wants.append(r); keeps.append(keep)
     for n in (3, 4):
+        got = b.Context.entropy_encode_many(hosts[:n], hrs[:n], prms[:n])
+        for i in range(n):
+            assert got[i][0] == wants[i].bitstream and got[i][1] == wants[i].perf, (n, i)
+
+
+def test_sixteen_frames_at_once_give_the_same_bytes(pkg, oracle):
+    """pcc_entropy_encode_many with 9, 12 and 16 frames (PCC_MAX_FRAMES_AT_ONCE): the occupancy streams of ten and more
+    frames go through the vector coder where the CPU has AVX-512, the colour and centroid streams of the frames that have them
+    through whatever their count selects -- the oracle's bitstreams and performance counters."""
+    b = pkg.binding
+    hosts = [b.Context(None) for _ in range(16)]
+    hrs, prms, wants, keeps = [], [], [], []
+    for i in range(16):
+        mode, cen = [(1, 0), (0, 1), (1, 1), (2, 0), (3, 1)][i % 5]
+        pts = pkg.synthetic.sphere_shell(1500 + 900 * i, 0x91 + i)
+        kw = dict(octree_bits=5 + (i % 3), color_bits=0 if i == 7 else (6 if mode == 0 else 8), color_coding_type=mode, keep_centroid=cen,
+                  jpeg_quality=50 + 3 * i, frame_id=20 + i)
+        r = oracle.encode_intra(pts, oracle.make_params(**kw))
+        hr, keep = _hot_from_oracle(pkg, r)
+        hrs.append(hr); prms.append(b.make_params(**kw)); wants.append(r); keeps.append(keep)
+    for n in (9, 12, 16):
         got = b.Context.entropy_encode_many(hosts[:n], hrs[:n], prms[:n])
         for i in range(n):
             assert got[i][0] == wants[i].bitstream and got[i][1] == wants[i].perf, (n, i)

@@ -5,6 +5,8 @@ on the chip cannot stop the tests of the default forms from being run and counte
   * the hot path's optional forms (fused front end and its fallback, XCD-aware sort tickets, the two sort experiments, round
     2's probe layout): child processes, because the switches are read once per process
   * the device range coder with one LANE per stream (option "rc_device_lanes"; the default is one wave per stream)
+  * the pipeline's entropy threads coding sixteen frames per call instead of four (PCC_PIPELINE_BATCH=16: the host range coder's
+    AVX-512 path)
 """
 import os
 import subprocess
@@ -68,3 +70,39 @@ def test_lane_per_stream_range_coder_many_streams_at_once(pkg, lanes_ctx):
 def test_lane_per_stream_range_coder_in_the_entropy_batch_and_the_pipeline(pkg, oracle, lanes_ctx):
     import test_rc_device as T
     T.entropy_batch_and_pipeline(pkg, oracle, 1)
+
+
+def test_pipeline_with_sixteen_frames_per_coder_call(pkg):
+    """PCC_PIPELINE_BATCH=16: an entropy thread takes up to sixteen ready frames and codes their streams in one call (ten and
+    more through the AVX-512 lanes of the host range coder where the CPU has them).  Forty frames of different sizes, one of them
+    dropped, on two entropy threads: the oracle's bitstreams, from host memory and from device memory.  A child process (the
+    batch size is read when the pipeline is made)."""
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import __graft_entry__ as G
+        from oracle import oracle as O
+        pkg = G.load_package(); b, syn = pkg.binding, pkg.synthetic
+        sizes = [3_000 + 700 * (i %% 9) + 40 * i for i in range(40)]
+        frames = [syn.sphere_shell(n, 0x900 + i) for i, n in enumerate(sizes)]
+        frames[11]["x"] = np.nan   # dropped
+        kw = dict(octree_bits=7, jpeg_quality=70)
+        ref, fid = [], 3
+        for f in frames:
+            r = O.encode_intra(f, O.make_params(frame_id=fid, **kw), keep=False)
+            ref.append(b"" if r is None else r.bitstream); fid += 0 if r is None else 1
+        pipe = b.Pipeline(0, workers=2)
+        try:
+            assert pipe.n_contexts >= 2 * 16
+            for rep in range(2):
+                got = pipe.encode_host(frames, b.make_params(frame_id=3, **kw))
+                assert [g[0] for g in got] == ref
+        finally:
+            pipe.close()
+        print("OK")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCC_PIPELINE_BATCH="16"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

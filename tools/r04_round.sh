@@ -51,6 +51,12 @@ if want ab; then
   ab ab_sortbare PCC_SORT_BARE 1 - cfg2             # payload-free sort passes, three tiles per CU
   [ -f $SHFL ] && ab ab_shfl PCC_LIB $PWD/cwi-pcl-codec_amd/libpcc_hip.so $SHFL cfg2
   [ -f $R02 ] && ab ab_r02lib PCC_LIB $PWD/cwi-pcl-codec_amd/libpcc_hip.so $R02 cfg2     # HEAD against the last library that ran on the chip
+  # the host coder with sixteen frames per call (AVX-512 lanes) against four (scalar loop): value and host CPU per frame
+  for BATCH in 4 16; do
+    PCC_PIPELINE_BATCH=$BATCH python bench.py --steps 1024 --warmup 8 --no-cpu-baseline --no-host-input > $OUT/bench_batch_$BATCH.json 2> $OUT/bench_batch_$BATCH.err
+    echo "frames per coder call $BATCH: $(python -c "import json,sys; d=json.load(open('$OUT/bench_batch_$BATCH.json')); print(d['value'], d['host_cpu_ms_per_frame'], d['entropy_stage'])" 2>&1)"
+  done
+  (cd tools/ubench && g++ -O3 -march=x86-64-v3 -I../../cwi-pcl-codec_amd/csrc -I../../include rc_many.cpp ../../cwi-pcl-codec_amd/csrc/pcc_host_codec.o -o rc_many && ./rc_many && PCC_RC_WIDE=0 ./rc_many | tail -4) > $OUT/rc_many.txt 2>&1; tail -24 $OUT/rc_many.txt
   # where the entropy stage of a long call should run on this box: host (default), GPU, the cost estimate
   for M in host gpu auto; do
     PCC_PIPELINE_ENTROPY=$M python bench.py --steps 1024 --warmup 8 --no-cpu-baseline --no-host-input > $OUT/bench_entropy_$M.json 2> $OUT/bench_entropy_$M.err
