@@ -18,7 +18,7 @@ SHFL=$PWD/cwi-pcl-codec_amd/libpcc_hip_shfl.so
 want() { [ "$STAGE" = all ] || [ "$STAGE" = "$1" ]; }
 
 if want parity; then
-  python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+  python -m pytest tests -m gpu -x -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
   tail -3 $OUT/pytest_gpu.log
   python -c "import __graft_entry__ as G; G.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
   if ! grep -q " passed" $OUT/pytest_gpu.log || grep -q " failed\| error" $OUT/pytest_gpu.log; then
