@@ -69,6 +69,7 @@ struct Lane {
   void* sp;
   int state;
   int kind;
+  int site;    // the source line through which the lane came to the meeting point it waits at
   uint64_t a0, a1;  // operands
   int c0, c1, c2, c3;  // constants of the operation (must agree over the wave)
   uint64_t result;
@@ -121,10 +122,11 @@ void prepare_lane(Worker* w, int i) {
 }
 
 // called on a lane's stack: hand control back to the scheduler of the workgroup
-inline uint64_t yield_lane(int state, int kind, uint64_t a0, uint64_t a1, int c0 = 0, int c1 = 0, int c2 = 0, int c3 = 0) {
+inline uint64_t yield_lane(int site, int state, int kind, uint64_t a0, uint64_t a1, int c0 = 0, int c1 = 0, int c2 = 0, int c3 = 0) {
   Worker* w = tl_worker;
   if (!w || w->cur < 0) die("device operation outside a kernel");
   Lane& l = w->lanes[w->cur];
+  l.site = site;
   l.state = state; l.kind = kind; l.a0 = a0; l.a1 = a1; l.c0 = c0; l.c1 = c1; l.c2 = c2; l.c3 = c3;
   emu_switch(&l.sp, w->sched_sp);
   return tl_worker->lanes[tl_worker->cur].result;
@@ -157,6 +159,14 @@ void run_collective(Worker* w, int wave_first, uint64_t active) {
   const int kind = L[first].kind;
   for (int i = 0; i < 64; ++i)
     if ((active >> i) & 1) {
+      // On the chip lanes of a wave that stand at two different instructions never execute them together: each call site runs
+      // with the lanes that are there.  Here all waiting lanes would be served as one operation -- so lanes of one wave meeting
+      // at different call sites is something the executor cannot stand in for, and says so instead of computing something.
+      if (L[i].site != L[first].site) {
+        fprintf(stderr, "wave64 executor: lanes %d and %d of a wave wait at cross-lane operations of two different source lines (%d, %d)\n", first, i,
+                L[first].site, L[i].site);
+        die("cross-lane operation reached by lanes of one wave through different source lines");
+      }
       if (L[i].kind != kind || L[i].c0 != L[first].c0 || L[i].c1 != L[first].c1 || L[i].c2 != L[first].c2 || L[i].c3 != L[first].c3) {
         fprintf(stderr, "wave64 executor: lanes %d and %d of a wave are at different cross-lane operations (%d/%x vs %d/%x)\n", first, i, kind,
                 L[first].c0, L[i].kind, L[i].c0);
@@ -290,6 +300,14 @@ void run_workgroup(Worker* w) {
     if (n_done == T) return;
     if (n_done + n_barrier == T) {
       int kind = 0, all = 1, any = 0, count = 0;
+      for (int wv = 0; wv < nw; ++wv) {  // (a wave executes s_barrier once, whatever its lanes do: its lanes must wait at ONE __syncthreads())
+        int site = 0;
+        for (int i = wv * 64; i < std::min(T, wv * 64 + 64); ++i) {
+          if (w->lanes[i].state != kBarrier) continue;
+          if (!site) site = w->lanes[i].site;
+          else if (site != w->lanes[i].site) die("the lanes of one wave wait at two different __syncthreads()");
+        }
+      }
       for (int i = 0; i < T; ++i) {
         Lane& l = w->lanes[i];
         if (l.state != kBarrier) continue;
@@ -557,19 +575,19 @@ void* traffic_alloc(size_t bytes) { return traffic().on ? traffic().alloc(bytes)
 bool traffic_owns(void* p) { return traffic().on && (char*)p >= traffic().lo && (char*)p < traffic().hi; }
 void traffic_touch(uintptr_t a, size_t n, bool store) { traffic_access(a, n, store); }
 
-uint64_t ballot(int pred) { return yield_lane(kCollective, kBallot, (uint64_t)(pred != 0), 0); }
-int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  return (int)(uint32_t)yield_lane(kCollective, kDpp, (uint32_t)old, (uint32_t)src, ctrl, row_mask, bank_mask, bound_ctrl ? 1 : 0);
+uint64_t ballot(int pred, int site) { return yield_lane(site, kCollective, kBallot, (uint64_t)(pred != 0), 0); }
+int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, int site) {
+  return (int)(uint32_t)yield_lane(site, kCollective, kDpp, (uint32_t)old, (uint32_t)src, ctrl, row_mask, bank_mask, bound_ctrl ? 1 : 0);
 }
-uint32_t readlane(uint32_t v, int lane) { return (uint32_t)yield_lane(kCollective, kReadlane, v, 0, lane); }
-uint32_t readfirstlane(uint32_t v) { return (uint32_t)yield_lane(kCollective, kReadfirst, v, 0); }
-uint64_t shfl64(uint64_t v, int a, int width, int mode) { return yield_lane(kCollective, kShfl, v, (uint64_t)(int64_t)a, width, mode); }
-void wave_barrier() { (void)yield_lane(kCollective, kWaveBarrier, 0, 0); }
-void syncthreads() { (void)yield_lane(kBarrier, kSync, 1, 0); }
-int syncthreads_and(int pred) { return (int)yield_lane(kBarrier, kSyncAnd, pred != 0, 0); }
-int syncthreads_or(int pred) { return (int)yield_lane(kBarrier, kSyncOr, pred != 0, 0); }
-int syncthreads_count(int pred) { return (int)yield_lane(kBarrier, kSyncCount, pred != 0, 0); }
-void sleep(int) { (void)yield_lane(kSleep, 0, 0, 0); }
+uint32_t readlane(uint32_t v, int lane, int site) { return (uint32_t)yield_lane(site, kCollective, kReadlane, v, 0, lane); }
+uint32_t readfirstlane(uint32_t v, int site) { return (uint32_t)yield_lane(site, kCollective, kReadfirst, v, 0); }
+uint64_t shfl64(uint64_t v, int a, int width, int mode, int site) { return yield_lane(site, kCollective, kShfl, v, (uint64_t)(int64_t)a, width, mode); }
+void wave_barrier(int site) { (void)yield_lane(site, kCollective, kWaveBarrier, 0, 0); }
+void syncthreads(int site) { (void)yield_lane(site, kBarrier, kSync, 1, 0); }
+int syncthreads_and(int pred, int site) { return (int)yield_lane(site, kBarrier, kSyncAnd, pred != 0, 0); }
+int syncthreads_or(int pred, int site) { return (int)yield_lane(site, kBarrier, kSyncOr, pred != 0, 0); }
+int syncthreads_count(int pred, int site) { return (int)yield_lane(site, kBarrier, kSyncCount, pred != 0, 0); }
+void sleep(int) { (void)yield_lane(0, kSleep, 0, 0, 0); }
 // HW_REG_XCC_ID: workgroup b on XCD b mod 8, as observed on the chip.  PCC_EMU_XCC=<n>: every workgroup claims XCD n;
 // PCC_EMU_XCC=rand: a pseudo-random one -- the kernels may use the register as a hint only, and must give the same bytes
 int getreg(int imm) {

@@ -62,16 +62,22 @@ static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 namespace emu {
 struct Idx3 { uint32_t x, y, z; };
 // cross-lane operations: every active lane of the wave calls the same one; the wave's scheduler computes the results
-uint64_t ballot(int pred);
-int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);
-uint32_t readlane(uint32_t v, int lane);
-uint32_t readfirstlane(uint32_t v);
-uint64_t shfl64(uint64_t v, int src_lane, int width, int mode);  // mode 0: idx, 1: xor, 2: up, 3: down
-void wave_barrier();
-void syncthreads();
-int syncthreads_and(int pred);
-int syncthreads_or(int pred);
-int syncthreads_count(int pred);
+// `site` = the source line of the call (__builtin_LINE() as a default argument is evaluated where the call is written): the lanes
+// of a wave that meet at a cross-lane operation, and the lanes of a wave that wait at a barrier, must have come there through the
+// same line -- on the chip lanes at two different instructions never execute them together (each runs with the lanes that are
+// there), which the executor, serving all waiting lanes as one operation, could not reproduce.  (The line, not the return
+// address: the host compiler may clone a loop body, e.g. for a loop-invariant `lane == 0`, which a GPU compiler must not do
+// around convergent operations.)
+uint64_t ballot(int pred, int site = __builtin_LINE());
+int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, int site = __builtin_LINE());
+uint32_t readlane(uint32_t v, int lane, int site = __builtin_LINE());
+uint32_t readfirstlane(uint32_t v, int site = __builtin_LINE());
+uint64_t shfl64(uint64_t v, int src_lane, int width, int mode, int site);  // mode 0: idx, 1: xor, 2: up, 3: down
+void wave_barrier(int site = __builtin_LINE());
+void syncthreads(int site = __builtin_LINE());
+int syncthreads_and(int pred, int site = __builtin_LINE());
+int syncthreads_or(int pred, int site = __builtin_LINE());
+int syncthreads_count(int pred, int site = __builtin_LINE());
 void sleep(int n);
 int getreg(int imm);  // HW_REG_XCC_ID (id 20): workgroup b "runs on XCD" b mod 8, as observed on the chip; others: 0
 unsigned long long wall_clock();
@@ -161,19 +167,19 @@ template <typename T, typename V> static inline T race_fetch_or(T* p, V v, int o
 #endif
 
 template <typename T>
-static inline T emu_shfl(T v, int a, int width, int mode) {
+static inline T emu_shfl(T v, int a, int width, int mode, int site) {
   static_assert(sizeof(T) <= 8, "shuffle of at most 64 bits");
   uint64_t raw = 0;
   memcpy(&raw, &v, sizeof(T));
-  raw = emu::shfl64(raw, a, width, mode);
+  raw = emu::shfl64(raw, a, width, mode, site);
   T out;
   memcpy(&out, &raw, sizeof(T));
   return out;
 }
-template <typename T> static inline T __shfl(T v, int src, int width = 64) { return emu_shfl(v, src, width, 0); }
-template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { return emu_shfl(v, mask, width, 1); }
-template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) { return emu_shfl(v, (int)d, width, 2); }
-template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) { return emu_shfl(v, (int)d, width, 3); }
+template <typename T> static inline T __shfl(T v, int src, int width = 64, int site = __builtin_LINE()) { return emu_shfl(v, src, width, 0, site); }
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64, int site = __builtin_LINE()) { return emu_shfl(v, mask, width, 1, site); }
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64, int site = __builtin_LINE()) { return emu_shfl(v, (int)d, width, 2, site); }
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64, int site = __builtin_LINE()) { return emu_shfl(v, (int)d, width, 3, site); }
 
 // atomics (workgroups are OS threads: these have to be real ones)
 template <typename T> static inline T atomicAdd(T* p, T v) { EMU_ATOMIC(p, 2); return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

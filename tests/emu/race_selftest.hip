@@ -135,6 +135,22 @@ __global__ void k_global_in_workgroup(uint32_t* buf, uint32_t* out, int with_bar
   if (t >= 64) out[t - 64] = buf[t - 64];
 }
 
+// ---- what the executor refuses to stand in for (it aborts): lanes of ONE wave at cross-lane operations, or at barriers, of two
+//      different source lines -- the chip runs each line with the lanes that are there, the executor would serve them as one
+__global__ void k_divergent_ballot(uint32_t* out) {
+  uint64_t m;
+  if (threadIdx.x & 1u) m = __ballot(1);
+  else
+    m = __ballot(1);
+  out[threadIdx.x] = (uint32_t)m;
+}
+__global__ void k_divergent_barrier(uint32_t* out) {
+  if (threadIdx.x < 32u) __syncthreads();
+  else
+    __syncthreads();
+  out[threadIdx.x] = 1u;
+}
+
 static int reports() {
   static char text[1 << 16];
   const int n = (int)pcc_emu_race_report(text, sizeof(text));
@@ -142,11 +158,13 @@ static int reports() {
   return n;
 }
 
-int main() {
+int main(int argc, char** argv) {
   uint32_t *data, *flag, *out;
   hipMalloc(&data, 4096);
   hipMalloc(&flag, 256);
   hipMalloc(&out, 4096);
+  if (argc > 1 && !strcmp(argv[1], "divergent_ballot")) { hipLaunchKernelGGL(k_divergent_ballot, dim3(1), dim3(64), 0, nullptr, out); printf("survived\n"); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "divergent_barrier")) { hipLaunchKernelGGL(k_divergent_barrier, dim3(1), dim3(64), 0, nullptr, out); printf("survived\n"); return 0; }
   const char* names[] = {"plain_flag", "relaxed_flag_plain_data", "release_acquire", "agent_fences", "workgroup_scope_atomics", "workgroup_scope_fences",
                          "self_describing_words", "rmw_release_chain", "rmw_relaxed_chain"};
   for (int mode = 0; mode <= kRmwChainRelaxed; ++mode) {

@@ -47,6 +47,17 @@ def test_the_checker_reports_known_races_and_nothing_else(race_build):
         assert got[k] >= at_least, (k, got)
 
 
+@pytest.mark.parametrize("case", ["divergent_ballot", "divergent_barrier"])
+def test_the_executor_refuses_what_it_cannot_stand_in_for(race_build, case):
+    """Lanes of ONE wave that meet at cross-lane operations -- or wait at __syncthreads() -- of two different source lines: the
+    chip executes each line with the lanes that are there (and counts one s_barrier per wave and line), the executor would
+    serve all waiting lanes as one operation.  It aborts instead of computing something the chip would not; the whole `-m gpu`
+    suite runs without meeting that (196 tests)."""
+    r = subprocess.run([os.path.join(OUT, "race_selftest"), case], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "survived" not in r.stdout
+    assert ("different source lines" in r.stderr) or ("two different __syncthreads" in r.stderr), r.stderr[-1000:]
+
+
 def run_gpu_tests_under_the_checker(lib, log, targets, select=None, env=None, workers=4):
     if os.path.exists(log):
         os.remove(log)
