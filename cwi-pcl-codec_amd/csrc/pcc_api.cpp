@@ -1566,13 +1566,14 @@ static int entropy_batch_flush_frames(pcc_entropy_batch* b, pcc_bitstream* out, 
   PCC_HIP(b->d_lens.ensure(nj));
   PCC_HIP(b->d_offs.ensure(nj));
   PCC_HIP(b->d_jobs.ensure(nj));
-  if (range_encode_lanes()) PCC_HIP(b->d_hists.ensure((size_t)nj * 256));
+  const bool lanes = range_encode_lanes() != 0;  // (read once: the option is process-wide and may be flipped by another thread)
+  if (lanes) PCC_HIP(b->d_hists.ensure((size_t)nj * 256));
   PCC_HIP(b->h_lens.ensure(nj));
   for (uint32_t k = 0; k < nj; ++k) { jobs[k].out = b->d_out.p + out_off[k]; jobs[k].out_len = b->d_lens.p + k; }
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
   PCC_HIP(hipMemcpyAsync(b->d_in.p, b->h_in.p, b->in_used, hipMemcpyHostToDevice, ctx->stream));
   PCC_HIP(hipMemcpyAsync(b->d_jobs.p, jobs.data(), (size_t)nj * sizeof(RcJob), hipMemcpyHostToDevice, ctx->stream));
-  launch_range_encode(b->d_jobs.p, nj, range_encode_lanes() ? b->d_hists.p : nullptr, ctx->stream);
+  launch_range_encode(b->d_jobs.p, nj, lanes ? b->d_hists.p : nullptr, ctx->stream);
   PCC_HIP(hipGetLastError());
   PCC_HIP(hipMemcpyAsync(b->h_lens.p, b->d_lens.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
   { const int wrc = wait_stream(ctx); if (wrc != PCC_OK) return wrc; }
@@ -1643,7 +1644,8 @@ int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* i
   const size_t job_off = at;
   at += ((size_t)n_streams * sizeof(RcJob) + 63) & ~(size_t)63;
   const size_t hist_off = at;   // (the lane-per-stream form counts the symbols of every stream here first)
-  if (range_encode_lanes()) at += (size_t)n_streams * 256 * sizeof(uint32_t);
+  const bool lanes = range_encode_lanes() != 0;
+  if (lanes) at += (size_t)n_streams * 256 * sizeof(uint32_t);
   PCC_HIP(ctx->d_rc.ensure(at));
   std::vector<RcJob> jobs((size_t)n_streams);
   for (int i = 0; i < n_streams; ++i) {
@@ -1659,7 +1661,7 @@ int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* i
   PCC_HIP(hipMemcpyAsync(ctx->d_rc.p + job_off, jobs.data(), jobs.size() * sizeof(RcJob), hipMemcpyHostToDevice, ctx->stream));
   PCC_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
   launch_range_encode(reinterpret_cast<const RcJob*>(ctx->d_rc.p + job_off), (uint32_t)n_streams,
-                      range_encode_lanes() ? reinterpret_cast<uint32_t*>(ctx->d_rc.p + hist_off) : nullptr, ctx->stream);
+                      lanes ? reinterpret_cast<uint32_t*>(ctx->d_rc.p + hist_off) : nullptr, ctx->stream);
   PCC_HIP(hipGetLastError());
   PCC_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
   std::vector<uint32_t> lens((size_t)n_streams);
