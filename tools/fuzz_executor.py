@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""A long random campaign of the hot path against the oracle, on the CPU executor (no GPU needed) -- what the 48 cases of
+tests/test_gpu_parity.py::test_random_sweep do, for as long as one likes and with seeds nobody has looked at: random sizes,
+shapes, point orders, non-finite points, resolutions (powers of two and not), colour modes, centroids; encode (every byte of
+the hot path's products and the bitstream) and GPU-assisted decode.  Any seed that fails is printed and can be replayed with
+`--seed N`.
+
+    make -C tests/emu CXX=/opt/rocm/lib/llvm/bin/clang++ OUT=_build_clang OPT=-O3      # the fastest build of the executor
+    PCC_LIB=tests/emu/_build_clang/libpcc_emu.so python tools/fuzz_executor.py --minutes 30 --first 1000 [--stride 8 --offset k]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+if "PCC_LIB" not in os.environ:
+    raise SystemExit("set PCC_LIB to a build of the executor (this is not a measurement and not for the product library)")
+import numpy as np  # noqa: E402
+
+import __graft_entry__ as G  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+import test_gpu_parity as T  # noqa: E402
+
+
+def one(pkg, ctx, seed):
+    pts, kw = T._random_case(pkg, seed)
+    want = O.encode_intra(pts, O.make_params(**kw))
+    b = pkg.binding
+    if want is None or want.depth > 31:
+        try:
+            ctx.encode_intra_host(pts, b.make_params(**kw))
+        except b.PccError:
+            return "refused"
+        raise AssertionError("a frame the oracle drops / cannot code was accepted")
+    T.assert_matches_oracle(pkg, O, ctx, pts, **kw)
+    ref = O.decode_intra(want.bitstream).points
+    got, info = ctx.decode_intra(want.bitstream, on_gpu=True)
+    assert info["consumed"] == len(want.bitstream) and got.tobytes() == ref.tobytes(), "decoder"
+    return "ok"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--first", type=int, default=1000, help="first seed (the test suite uses 0..47)")
+    ap.add_argument("--stride", type=int, default=1)
+    ap.add_argument("--offset", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=None, help="replay one seed")
+    a = ap.parse_args()
+    pkg = G.load_package()
+    ctx = pkg.binding.Context(0)
+    if a.seed is not None:
+        print(a.seed, one(pkg, ctx, a.seed))
+        return
+    t_end = time.time() + 60.0 * a.minutes
+    seed, done, bad = a.first + a.offset, 0, []
+    while time.time() < t_end:
+        try:
+            one(pkg, ctx, seed)
+        except Exception as e:  # noqa: BLE001 -- every failure is a finding
+            bad.append(seed)
+            print("FAILED seed %d: %s: %s" % (seed, type(e).__name__, str(e)[:300]), flush=True)
+            ctx.close()
+            ctx = pkg.binding.Context(0)
+        done += 1
+        seed += a.stride
+    print("seeds %d..%d step %d: %d cases, %d failed %s" % (a.first + a.offset, seed - a.stride, a.stride, done, len(bad), bad), flush=True)
+
+
+if __name__ == "__main__":
+    main()
