@@ -1646,6 +1646,13 @@ struct Reader {
 }  // namespace
 
 
+// How many symbols `coded` bytes of a range-coded vector can hold at most: a symbol costs at least -log2((65535 - 255) / 65535)
+// = 0.0056 bits (the table total stays below 2^16 and every absent symbol still has count 1), i.e. fewer than 1424 symbols per
+// byte.  A count in a frame header beyond that is a corrupt or hostile stream -- refused before anything is allocated for it.
+// (Round 3's guard allowed 64 symbols per byte; a frame of coincident points -- 64 k voxels, every centroid byte the same:
+// 192 k symbols in 1.2 KB -- is valid and was refused.  Found by tools/fuzz_executor.py.)
+static inline bool plausible_symbol_count(uint64_t n, size_t coded) { return n <= (uint64_t)coded * 1424u + 4096u; }
+
 int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too,
                          const std::function<void()>& after_occupancy) {
   DecodeTrace tr;
@@ -1696,7 +1703,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   }
 
   uint64_t occ_n = 0;
-  if (!r.get(occ_n) || occ_n > len * 64 + 64) return PCC_ERR_STREAM;
+  if (!r.get(occ_n) || !plausible_symbol_count(occ_n, r.len - r.pos)) return PCC_ERR_STREAM;
   Bytes& occ = fs.occ;
   occ.resize((size_t)occ_n);
   size_t used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, occ.data(), occ.size());
@@ -1710,7 +1717,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   cen.clear();
   if (p.do_voxel_centroid) {
     uint32_t n = 0;
-    if (!r.get(n) || n > len * 64 + 64) return PCC_ERR_STREAM;
+    if (!r.get(n) || !plausible_symbol_count(n, r.len - r.pos)) return PCC_ERR_STREAM;
     cen.resize(n);
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, cen.data(), cen.size());
     if (!used) return PCC_ERR_STREAM;
@@ -1721,7 +1728,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   fs.payload.clear();
   if (with_color) {
     uint64_t n = 0;
-    if (!r.get(n) || n > len * 64 + 64) return PCC_ERR_STREAM;
+    if (!r.get(n) || !plausible_symbol_count(n, r.len - r.pos)) return PCC_ERR_STREAM;
     Bytes& payload = fs.payload;
     payload.resize((size_t)n);
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, payload.data(), payload.size());

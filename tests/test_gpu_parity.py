@@ -876,11 +876,11 @@ def test_gpu_decode_of_the_headline_frame(pkg, oracle, ctx):
 
 # ---------------- randomised sweep ----------------
 
-def _random_case(pkg, seed):
+def _random_case(pkg, seed, sizes=(1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000, 30000, 70000)):
     """A random frame and codec configuration: size, shape, point order, non-finite points, duplicates, resolution
     (power of two or not), colour mode, colour bits, centroids."""
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000, 30000, 70000]))
+    n = int(rng.choice(list(sizes)))
     shape = rng.integers(0, 6)
     if shape == 0:      # volume
         xyz = rng.uniform(0.0, 1.0, (n, 3))

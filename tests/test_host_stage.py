@@ -348,6 +348,40 @@ def test_normalize_group_matches_numpy(pkg):
         assert np.abs(a[ax] - raw[ax]).max() < 1e-5
 
 
+def test_decoder_accepts_streams_that_compress_a_thousandfold(pkg, oracle):
+    """A static order-0 range coder spends as little as 0.0056 bits on a symbol (table total below 2^16, absent symbols count 1):
+    fewer than 1424 symbols per byte.  Frames of coincident points reach hundreds -- 64 000 voxels of a lattice whose points sit
+    on the voxel corners: every centroid byte equal, 192 000 symbols in 1.2 KB -- and a line along an axis does it for the
+    occupancy bytes.  The decoder's guard against hostile counts (refuse before allocating) must not refuse them: round 3's
+    allowed 64 symbols per byte and did (found by tools/fuzz_executor.py, seed 900562 of the large frames).  Counts beyond
+    what the coded bytes can hold are still refused."""
+    b = pkg.binding
+    host = b.Context(None)
+    import test_gpu_parity as T   # (the generator of its random sweep: this is the frame the campaign tripped over)
+    lattice, lattice_kw = T._random_case(pkg, 900562, (100_000, 196_608, 196_609, 300_000, 393_217, 450_000, 800_000))   # tools/fuzz_executor.py --big
+    assert len(lattice) == 450_000 and lattice_kw["keep_centroid"] == 1 and lattice_kw["color_bits"] == 0
+    t = np.linspace(0.0, 1.0, 50_000)
+    line = np.zeros(len(t), dtype=b.POINT_DTYPE)
+    line["x"], line["y"], line["z"] = t, 0.25, 0.75
+    for pts, kw in ((lattice, lattice_kw), (line, dict(octree_bits=14, color_bits=0, keep_centroid=1, frame_id=3))):
+        r = oracle.encode_intra(pts, oracle.make_params(**kw))
+        ref = oracle.decode_intra(r.bitstream).points
+        if pts is lattice:   # three centroid bytes per voxel: far more symbols than round 3's guard (64 per byte of the stream) let through
+            assert 3 * len(ref) > 64 * len(r.bitstream) + 64
+        got, info = host.decode_intra(r.bitstream)
+        assert info["consumed"] == len(r.bitstream) and got.tobytes() == ref.tobytes()
+    # a header that asks for more symbols than its bytes can hold: refused (no allocation of 2^40 bytes)
+    stream = bytearray(r.bitstream)
+    at = stream.index(b"<PCL-OCT-COMPRESSED>") + len(b"<PCL-OCT-COMPRESSED>")
+    import struct
+    hdr = at + 4 + 1 + 1 + 1 + 8 + 8 + 1 + 8 + 48 + 1 + 1 + 1 + 4 + 4 + 1   # frame header of writeFrameHeader (impl.hpp:1472-1486), then u64 occupancy count
+    n_occ, = struct.unpack_from("<Q", stream, hdr)
+    assert 0 < n_occ < 10 ** 7
+    struct.pack_into("<Q", stream, hdr, 1 << 40)
+    with pytest.raises(b.PccError):
+        host.decode_intra(bytes(stream))
+
+
 def test_host_decoder_accepts_the_2048_wide_strip_a_reference_encoder_writes(pkg, oracle):
     """Colour coding type 2 with fewer than 2048 voxels: the reference's encoder writes ONE strip 2048 pixels wide
     (jpegcc.h:256-275, the width is never narrowed in the `num_lines == 0` branch; the pixels beyond the voxels are an

@@ -25,8 +25,12 @@ from oracle import oracle as O  # noqa: E402
 import test_gpu_parity as T  # noqa: E402
 
 
+BIG = (100_000, 196_608, 196_609, 300_000, 393_217, 450_000, 800_000)   # around and beyond 48 / 96 sort tiles: both kernel shapes, several look-back groups
+SIZES = None
+
+
 def one(pkg, ctx, seed):
-    pts, kw = T._random_case(pkg, seed)
+    pts, kw = T._random_case(pkg, seed, SIZES) if SIZES else T._random_case(pkg, seed)
     want = O.encode_intra(pts, O.make_params(**kw))
     b = pkg.binding
     if want is None or want.depth > 31:
@@ -49,7 +53,10 @@ def main():
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--offset", type=int, default=0)
     ap.add_argument("--seed", type=int, default=None, help="replay one seed")
+    ap.add_argument("--big", action="store_true", help="frames of 100 000 to 800 000 points instead of 1 to 70 000")
     a = ap.parse_args()
+    global SIZES
+    SIZES = BIG if a.big else None
     pkg = G.load_package()
     ctx = pkg.binding.Context(0)
     if a.seed is not None:
