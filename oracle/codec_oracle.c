@@ -100,6 +100,10 @@ int pcco_encode_intra(const pcco_point *pts, size_t n, const pcco_params *p, pcc
   /* impl.hpp:89-99: fresh tree + bbox every frame, then insert all points */
   pcco_octree *t = pcco_octree_new(p->octree_resolution);
   pcco_octree_add_points(t, pts, n);
+  if (pcco_octree_too_deep(t)) { /* more than 32 levels: beyond what PCL's arithmetic defines (octree_oracle.c) */
+    pcco_octree_free(t);
+    return 2;
+  }
   if (pcco_octree_leaf_count(t) == 0) { /* impl.hpp:206-212: frame dropped */
     pcco_octree_free(t);
     return 1;

@@ -31,6 +31,8 @@ struct pcco_octree {
   double res;
   double min[3], max[3];
   int bbox_defined;
+  int too_deep;         /* the box would need a 33rd level: PCL's own `1 << octree_depth_` is undefined from there on (it is what
+                           this file restates), so the restatement stops and says so instead of running away with it */
   unsigned depth;       /* octree_depth_ */
   obranch *root;        /* root_node_ (always a branch) */
   uint64_t leaf_count, branch_count, object_count;
@@ -103,6 +105,7 @@ static void adopt_bbox(pcco_octree *t, const float p[3]) {
     }
     if (!(any || !t->bbox_defined)) break;
     if (t->bbox_defined) {
+      if (t->depth >= 32) { t->too_deep = 1; return; }
       /* grow: the old root becomes child ((!upX)<<2 | (!upY)<<1 | !upZ) of a new root */
       unsigned child_idx = (unsigned)(((!up[0]) << 2) | ((!up[1]) << 1) | (!up[2]));
       obranch *nr = (obranch *)calloc(1, sizeof(obranch));
@@ -131,6 +134,7 @@ static void add_point_idx(pcco_octree *t, const pcco_point *pts, int i) {
   t->object_count++;
   float p[3] = {pts[i].x, pts[i].y, pts[i].z};
   adopt_bbox(t, p);
+  if (t->too_deep) return;
   /* genOctreeKeyforPoint */
   unsigned key[3];
   for (int a = 0; a < 3; a++) key[a] = (unsigned)(((double)p[a] - t->min[a]) / t->res);
@@ -168,8 +172,10 @@ void pcco_octree_add_points(pcco_octree *t, const pcco_point *pts, size_t n) {
     /* pcl::isFinite(PointXYZRGB): x, y and z finite */
     if (isfinite(pts[i].x) && isfinite(pts[i].y) && isfinite(pts[i].z))
       add_point_idx(t, pts, (int)i);
+    if (t->too_deep) return;
   }
 }
+int pcco_octree_too_deep(const pcco_octree *t) { return t->too_deep; }
 
 uint64_t pcco_octree_leaf_count(const pcco_octree *t) { return t->leaf_count; }
 uint64_t pcco_octree_object_count(const pcco_octree *t) { return t->object_count; }

@@ -12,6 +12,7 @@ void pcco_octree_add_points(pcco_octree *t, const pcco_point *pts, size_t n);
 uint64_t pcco_octree_leaf_count(const pcco_octree *t);
 uint64_t pcco_octree_object_count(const pcco_octree *t);
 unsigned pcco_octree_depth(const pcco_octree *t);
+int pcco_octree_too_deep(const pcco_octree *t);  /* the adaptive box asked for a 33rd level: nothing was coded */
 void pcco_octree_bbox(const pcco_octree *t, double bb[6]);
 void pcco_octree_serialize(const pcco_octree *t, const pcco_point *pts, const pcco_params *prm,
                            int cloud_with_color, pcco_frame *f);

@@ -207,6 +207,12 @@ def encode_intra(points: np.ndarray, params: Params, opt0=False, keep=True):
     f = Frame()
     L = lib(opt0)
     rc = L.pcco_encode_intra(points.ctypes.data, len(points), C.byref(params), C.byref(f))
+    if rc == 2:   # the adaptive box would need more than 32 levels: beyond what PCL's own arithmetic defines
+        L.pcco_frame_free(C.byref(f))
+        r = EncodeResult()
+        r.depth = 33
+        r.too_deep = True
+        return r
     if rc != 0:
         L.pcco_frame_free(C.byref(f))
         return None

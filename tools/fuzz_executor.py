@@ -29,8 +29,25 @@ BIG = (100_000, 196_608, 196_609, 300_000, 393_217, 450_000, 800_000)   # around
 SIZES = None
 
 
+DEEP = False
+
+
 def one(pkg, ctx, seed):
     pts, kw = T._random_case(pkg, seed, SIZES) if SIZES else T._random_case(pkg, seed)
+    if DEEP:   # the same clouds, 4096 times larger, at a resolution that gives a tree of 15 to 31 levels (two-word codes beyond 21;
+        # the adaptive box may add a level or two: 32 and more are refused by the product).  Resolutions stay above 1e-6: below
+        # FLT_EPSILON PCL's box arithmetic (and with it the oracle) grows the box to 60 levels and more, which nothing supports.
+        pts = pts.copy()
+        for ax in ("x", "y", "z"):
+            pts[ax] *= np.float32(4096.0)
+        xyz = np.stack([pts["x"], pts["y"], pts["z"]], 1).astype(np.float64)
+        fin = xyz[np.isfinite(xyz).all(axis=1)]
+        ext = max(float((fin.max(axis=0) - fin.min(axis=0)).max()) if len(fin) > 1 else 4096.0, 4.0)
+        r = np.random.default_rng(seed)
+        res = max(ext / 2.0 ** float(r.uniform(15.0, 30.5)), 1e-6)
+        if r.integers(0, 2):
+            res = 2.0 ** round(np.log2(res))
+        kw = dict(kw, octree_resolution=float(res), point_resolution=float(res))
     want = O.encode_intra(pts, O.make_params(**kw))
     b = pkg.binding
     if want is None or want.depth > 31:
@@ -53,10 +70,13 @@ def main():
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--offset", type=int, default=0)
     ap.add_argument("--seed", type=int, default=None, help="replay one seed")
+    ap.add_argument("--verbose", action="store_true", help="print every seed before it runs (to find one that kills the process)")
     ap.add_argument("--big", action="store_true", help="frames of 100 000 to 800 000 points instead of 1 to 70 000")
+    ap.add_argument("--deep", action="store_true", help="frames of up to 9 000 points at resolutions that give trees of 15 to 31 levels")
     a = ap.parse_args()
-    global SIZES
-    SIZES = BIG if a.big else None
+    global SIZES, DEEP
+    SIZES = BIG if a.big else ((1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000) if a.deep else None)
+    DEEP = a.deep
     pkg = G.load_package()
     ctx = pkg.binding.Context(0)
     if a.seed is not None:
@@ -65,6 +85,8 @@ def main():
     t_end = time.time() + 60.0 * a.minutes
     seed, done, bad = a.first + a.offset, 0, []
     while time.time() < t_end:
+        if a.verbose:
+            print("seed", seed, flush=True)
         try:
             one(pkg, ctx, seed)
         except Exception as e:  # noqa: BLE001 -- every failure is a finding
