@@ -278,6 +278,13 @@ struct pcc_pipeline {
   // entropy stage on the GPU: take ready frames one by one, copy what their entropy stage needs into the thread's batch
   // (the context goes back to the GPU stage at once), flush when the batch is full or the job runs out of frames
   void entropy_thread_gpu(int index, double& te, double& ce, size_t& done) {
+    // (option "entropy_gpu_batch" may have changed since the thread's batch was made: a batch of another capacity is replaced --
+    //  a smaller one used to refuse the frames beyond its capacity, "the batch is full", and the call failed with PCC_ERR_STATE;
+    //  found by random pipeline runs)
+    if (batches[(size_t)index] && pcc_entropy_batch_capacity(batches[(size_t)index]) != (size_t)gpu_batch) {
+      pcc_entropy_batch_destroy(batches[(size_t)index]);
+      batches[(size_t)index] = nullptr;
+    }
     if (!batches[(size_t)index]) batches[(size_t)index] = pcc_entropy_batch_create(device, (size_t)gpu_batch);
     pcc_entropy_batch* batch = batches[(size_t)index];
     std::vector<size_t> frames_in_batch;
@@ -313,6 +320,7 @@ struct pcc_pipeline {
           if (rc < 0) status[r.frame] = rc;
           free_ctx.push_back(r.ctx);
         }
+        if (rc < 0) { std::lock_guard<std::mutex> lk(stat_mu); if (err.empty()) err = pcc_entropy_batch_last_error(batch); }
         cv_free.notify_all();
         if (rc >= 0) frames_in_batch.push_back(r.frame);
         if ((int)frames_in_batch.size() >= gpu_batch) flush();

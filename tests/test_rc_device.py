@@ -109,6 +109,11 @@ def entropy_batch_and_pipeline(pkg, oracle, lanes):
             got = pipe.encode_host(frames, b.make_params(frame_id=2, **kw))
             assert [g[0] for g in got] == ref
             assert pipe.last_entropy_mode() == 1
+        # the batch size may change between calls: larger (the threads' batches, made for four frames, used to refuse the fifth:
+        # "the batch is full", PCC_ERR_STATE -- found by random pipeline runs) and smaller
+        for gb in (7, 2):
+            pipe.set_option("entropy_gpu_batch", gb)
+            assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         pipe.set_option("entropy_on_gpu", 0)
         assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         assert pipe.last_entropy_mode() == 0
