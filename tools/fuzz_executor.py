@@ -30,6 +30,7 @@ SIZES = None
 
 
 DEEP = False
+OPTIONS = False
 
 
 def one(pkg, ctx, seed):
@@ -50,6 +51,14 @@ def one(pkg, ctx, seed):
         kw = dict(kw, octree_resolution=float(res), point_resolution=float(res))
     want = O.encode_intra(pts, O.make_params(**kw))
     b = pkg.binding
+    if OPTIONS:   # where the JPEG stage runs (0 host from the image, 1 coefficients on the GPU, 2 Huffman-coded rows / strips on the GPU),
+        # whether the image comes back, the key layouts of the sort: any combination gives the same bytes
+        r = np.random.default_rng(seed + 77)
+        ctx.set_option("jpeg_on_gpu", int(r.integers(0, 3)))
+        ctx.set_option("copy_image", 1)   # (assert_matches_oracle looks at the snake image)
+        ctx.set_option("force_pairs", int(r.choice([0, 0, 1, 2])))
+        ctx.set_option("no_cell_ranks", int(r.integers(0, 2)))
+        ctx.set_option("pack_upload", int(r.integers(0, 2)))
     if want is None or want.depth > 31:
         try:
             ctx.encode_intra_host(pts, b.make_params(**kw))
@@ -72,9 +81,11 @@ def main():
     ap.add_argument("--seed", type=int, default=None, help="replay one seed")
     ap.add_argument("--verbose", action="store_true", help="print every seed before it runs (to find one that kills the process)")
     ap.add_argument("--big", action="store_true", help="frames of 100 000 to 800 000 points instead of 1 to 70 000")
+    ap.add_argument("--options", action="store_true", help="a random setting of the context options (JPEG stage placement, key layouts, packed upload) per frame")
     ap.add_argument("--deep", action="store_true", help="frames of up to 9 000 points at resolutions that give trees of 15 to 31 levels")
     a = ap.parse_args()
-    global SIZES, DEEP
+    global SIZES, DEEP, OPTIONS
+    OPTIONS = a.options
     SIZES = BIG if a.big else ((1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000) if a.deep else None)
     DEEP = a.deep
     pkg = G.load_package()
