@@ -189,6 +189,19 @@ def test_trees_of_22_to_31_levels(pkg, oracle, ctx, bits, kw):
     assert host.tobytes() == ref.tobytes()
 
 
+def test_a_large_frame_in_a_deep_tree(pkg, oracle, ctx):
+    """More than 96 sort tiles AND more than 21 levels: the narrow (512 x 8) DEEP instantiations of sort pass and leaf scan, which
+    the cases above (at most 70 000 points) do not reach.  (A random campaign ran 514 such frames; this is one of them kept.)"""
+    rng = np.random.default_rng(2604)
+    scale = 4096.0
+    xyz = (rng.uniform(0.1, 0.9, (420_000, 3)) * scale).astype(np.float32)
+    pts = cloud(pkg, xyz, seed=26)
+    res = scale * 2.0 ** -26
+    hot, want = assert_matches_oracle(pkg, oracle, ctx, pts, octree_resolution=res, point_resolution=res, color_coding_type=1)
+    assert 22 <= hot.depth <= 31
+    assert_matches_oracle(pkg, oracle, ctx, cloud(pkg, rng.uniform(0.2, 0.8, (5_000, 3)), seed=1), octree_bits=9)   # and back to shallow frames
+
+
 def test_a_tree_of_32_levels_is_refused(pkg, ctx):
     """Two points 2^31 voxels apart: the box would need 32 levels (PCL's growth itself stops at 31)."""
     pts = cloud(pkg, np.array([[0.0, 0.0, 0.0], [3.0e9, 1.0, 1.0]]), seed=3)
