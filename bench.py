@@ -62,11 +62,10 @@ def parse():
 def kernel_algorithmic_bytes(name, n, L, B, with_color, image_bytes):
     # no centroids in the bench workloads: the sort key is [code | colour] or the code alone, 8 bytes, no payload array
     col = 4 if with_color else 0
-    fused = os.environ.get("PCC_FUSED_KEYS", "0") != "0" and (n + 2047) // 2048 <= 1024
-    if name == "k_boxes_events":           # fused mode: the streaming workgroups also write the keys (the cloud is read once)
-        return (16 + col) * n + 8 * n if fused else 16 * n   # x,y,z(,w) (+ colour word) of every point (+ key out)
-    if name == "k_make_keys":              # fused mode: only the chunk that holds the growth events is visited
-        return (16 + col + 8) * min(n, 2048) if fused else (16 + col) * n + 8 * n
+    if name == "k_boxes_events":
+        return 16 * n                      # x,y,z(,w) of every point
+    if name == "k_make_keys":
+        return (16 + col) * n + 8 * n      # x,y,z(,w) (+ colour word) of every point, key out
     if name == "k_sort_pass":
         return 2 * 8 * n                   # read keys, write keys
     if name == "k_leaf_scan":
@@ -246,22 +245,9 @@ def main():
     stats = pipe.stats()
     entropy_mode_timed = pipe.last_entropy_mode()   # (option "entropy_on_gpu": 0 host, the default; 1 GPU; -1 decided per call from a cost estimate)
     ktimes, profiled = pipe.kernel_times()
-    # fused front end (PCC_FUSED_KEYS=1, off by default): chunks of each context's LAST frame of the timed call whose wait for
-    # the plan ran out and that k_make_keys had to visit -- with frames in flight the grid is not resident as a whole
-    fused_fallback = None
-    if os.environ.get("PCC_FUSED_KEYS", "0") != "0":
-        import ctypes
-        lib_ = b.load_library()
-        lib_.pcc_debug_fused_chunks.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
-        fused_fallback = {"contexts": 0, "chunks": 0, "left_to_k_make_keys": 0}
-        for w in range(pipe.n_contexts):
-            o3 = (ctypes.c_uint32 * 3)()
-            if lib_.pcc_debug_fused_chunks(pipe.context(w).h, o3) == 0 and o3[2]:
-                fused_fallback["contexts"] += 1
-                fused_fallback["chunks"] += int(o3[1])
-                fused_fallback["left_to_k_make_keys"] += int(o3[1] - o3[0])
     for c in prof_ctxs:
         c.set_profiling(False)
+    own_elapsed = elapsed
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
@@ -281,6 +267,26 @@ def main():
 
     total_points = n_points * args.steps * world
     value = total_points / elapsed / 1e6
+
+    # ---- what every rank saw: the host entropy stage is what bounds a node with few CPUs per GPU, and a flat scaling curve
+    #      has to be readable from the line itself (value per rank, what its GPU stage alone sustains, its share of the CPUs,
+    #      where its entropy stage ran and what that stage can sustain there) ----
+    cpus_here = default_workers(world)
+    host_bound_fps = (cpus_here / (stats["entropy_cpu_us"] * 1e-6)) if stats["entropy_cpu_us"] > 0 and not entropy_mode_timed else None
+    mine = {
+        "rank": rank, "value": round(n_points * args.steps / own_elapsed / 1e6, 3), "ms_per_step": round(own_elapsed / args.steps * 1e3, 4),
+        "gpu_only_mpoints_per_s": round(gpu_only_fps * n_points / 1e6, 1), "host_cpus_for_this_rank": cpus_here, "host_threads": pipe.workers,
+        "entropy_stage": {"ran_on": "gpu" if entropy_mode_timed else "host",
+                          "host_frames_per_s_bound": None if host_bound_fps is None else round(host_bound_fps, 0),
+                          "gpu_stage_frames_per_s": round(gpu_only_fps, 0),
+                          "host_cpu_ms_per_frame": round(stats["entropy_cpu_us"] / 1e3, 3)},
+        # the host stage of this rank cannot keep up with what its GPU stage delivers: more GPUs on these CPUs add nothing
+        "host_bound": bool(host_bound_fps is not None and host_bound_fps < gpu_only_fps),
+    }
+    ranks = [mine]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
 
     # ---- kernel durations: serialised leg (one frame at a time on one stream, nothing else on the GPU) ----
     with_color = cfg["color_bits"] > 0
@@ -353,7 +359,7 @@ def main():
             "path_sum_of_kernel_spans_ms": round(sum_spans, 5),
             "path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
             "path_frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-            "frames_in_flight_in_timed_region": int(os.environ.get("PCC_PIPELINE_GPU_THREADS") or min(pipe.workers, 12)),
+            "frames_in_flight_in_timed_region": pipe.get("gpu_threads"),
             "kernel_avg_ms_sharing_the_gpu": round(shared.get(dominant, 0.0), 5) if shared else None,
         }
 
@@ -442,10 +448,10 @@ def main():
                                     cfg["octree_bits"],
                                     "colour JPEG snake q%d" % cfg["jpeg_quality"] if with_color else "geometry only"),
                        "frames_per_gpu": args.steps, "host_threads_per_gpu": pipe.workers,
-                       "frames_per_coder_call": int(os.environ.get("PCC_PIPELINE_BATCH", "4")), "L": int(L), "B": int(B),
+                       "frames_per_coder_call": pipe.get("frames_per_coder_call"), "L": int(L), "B": int(B),
                        "depth": int(depth), "bitstream_bytes": int(nbytes),
                        "sharding": "frame f -> gpu f mod N, no collectives"},
-            "gpu_only_mpoints_per_s": round(gpu_only_fps * n_points / 1e6, 1),
+            "gpu_only_mpoints_per_s": round(sum(r["gpu_only_mpoints_per_s"] for r in ranks), 1),   # all ranks, each its own GPU
             "host_ms_per_frame": {"launch_call": round(stats["launch_us"] / 1e3, 3),
                                   "finish_call": round(stats["finish_us"] / 1e3, 3),
                                   "entropy_call": round(stats["entropy_us"] / 1e3, 3),
@@ -458,16 +464,16 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_frame": {k: round(v, 5) for k, v in sorted(span_frame_ms.items(), key=lambda kv: -kv[1])},
             "host_input": host_input,
-            "host_cpus_for_this_rank": default_workers(world),
-            # what the host entropy stage can sustain on this rank's CPUs (CPU time per frame measured in the timed region)
-            "entropy_stage": {"ran_on": "gpu" if entropy_mode_timed else "host",
-                              "host_frames_per_s_bound": (round(default_workers(world) / (stats["entropy_cpu_us"] * 1e-6), 0)
-                                                          if stats["entropy_cpu_us"] > 0 and not entropy_mode_timed else None),
-                              "gpu_stage_frames_per_s": round(gpu_only_fps, 0)},
+            "host_cpus_for_this_rank": cpus_here,
+            # what the host entropy stage can sustain on a rank's CPUs (CPU time per frame measured in the timed region) against
+            # what its GPU stage delivers: rank 0's here, every rank's under "ranks"
+            "entropy_stage": mine["entropy_stage"],
+            "host_bound": any(r["host_bound"] for r in ranks),
+            "ranks": ranks,
             # a call of few frames cannot be shorter than the frames one entropy thread codes one after the other
             "short_call_floor_ms": round(-(-args.steps // max(pipe.workers, 1)) * stats["entropy_us"] / 1e3, 3),
             "library": library,
-            "fused_fallback_chunks": fused_fallback,
+            "entropy_coder": {"frames_per_coder_call": pipe.get("frames_per_coder_call"), "device_form": "lanes" if pipe.get("rc_device_lanes") else "waves"},
             "cgroup_throttled_ms_in_timed_region": throttled_ms,
             "warmup_frames_run": warm + args.steps * int(os.environ.get("PCC_BENCH_SHAPE_WARMUP", "1")),
             "cpu_baseline": cpu_baseline,

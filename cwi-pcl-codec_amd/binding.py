@@ -25,29 +25,35 @@ PCC_OK = 0
 ERR_NAMES = {-1: "PCC_ERR_ARG", -2: "PCC_ERR_HIP", -3: "PCC_ERR_EMPTY", -4: "PCC_ERR_UNSUPPORTED",
              -5: "PCC_ERR_STREAM", -6: "PCC_ERR_STATE"}
 
-# every symbol include/pcc_codec.h declares
-EXPORTS = [
-    "pcc_create", "pcc_create_host", "pcc_destroy", "pcc_last_error", "pcc_version",
-    "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish",
-    "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
-    "pcc_stream_create", "pcc_stream_destroy", "pcc_use_stream",
-    "pcc_entropy_encode", "pcc_entropy_encode2", "pcc_entropy_encode_many", "pcc_get_output_cloud", "pcc_decode_intra", "pcc_decode_intra_gpu", "pcc_get_decode_times",
-    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_host_times",
-    "pcc_set_profiling",
-    "pcc_set_option",
-    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_last_entropy_mode", "pcc_pipeline_workers", "pcc_pipeline_contexts",
-    "pcc_pipeline_context",
-    "pcc_pipeline_encode", "pcc_pipeline_encode_host", "pcc_pipeline_reserve", "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
-    "pcc_pipeline_last_error",
+# every symbol include/pcc_codec.h declares: the drop-in boundary (the class shim, the evaluation app, a frame loop)
+BOUNDARY_EXPORTS = [
+    "pcc_create", "pcc_destroy", "pcc_last_error", "pcc_version",
+    "pcc_encode_intra", "pcc_encode_intra_device", "pcc_reserve", "pcc_hotpath_launch", "pcc_hotpath_finish", "pcc_entropy_encode",
+    "pcc_get_output_cloud", "pcc_decode_intra", "pcc_decode_intra_gpu",
+    "pcc_device_alloc", "pcc_device_free", "pcc_device_upload", "pcc_set_option",
+    "pcc_pipeline_create", "pcc_pipeline_destroy", "pcc_pipeline_set_option", "pcc_pipeline_get", "pcc_pipeline_contexts", "pcc_pipeline_context",
+    "pcc_pipeline_encode", "pcc_pipeline_encode_host", "pcc_pipeline_reserve", "pcc_pipeline_last_error",
     "pcc_pipeline_create_multi", "pcc_multi_pipeline_destroy", "pcc_multi_pipeline_size", "pcc_multi_pipeline_member",
     "pcc_multi_pipeline_encode_host", "pcc_multi_pipeline_encode", "pcc_multi_pipeline_last_error",
-    "pcc_quality_metrics", "pcc_remove_outliers", "pcc_device_range_encode",
-    "pcc_entropy_batch_create", "pcc_entropy_batch_destroy", "pcc_entropy_batch_size", "pcc_entropy_batch_capacity",
-    "pcc_entropy_batch_add", "pcc_entropy_batch_flush", "pcc_entropy_batch_last_error",
-    "pcc_encode_delta", "pcc_delta_blocks", "pcc_decode_delta", "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
-    "pcc_host_range_encode", "pcc_host_range_encode_many", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
-    "pcc_host_snake_position", "pcc_normalize_group", "pcc_normalize_group_boxes", "pcc_restore_scaling",
+    "pcc_quality_metrics", "pcc_remove_outliers", "pcc_encode_delta", "pcc_decode_delta",
+    "pcc_normalize_group_boxes", "pcc_restore_scaling",
 ]
+# every symbol include/pcc_codec_tools.h declares: measurement, tests, tools
+TOOLS_EXPORTS = [
+    "pcc_create_host",
+    "pcc_get_kernel_times", "pcc_get_kernel_spans", "pcc_get_kernel_span_starts", "pcc_get_host_times", "pcc_set_profiling", "pcc_get_decode_times",
+    "pcc_hotpath_launch_host", "pcc_upload_lane_create", "pcc_upload_lane_destroy", "pcc_host_alloc", "pcc_host_free",
+    "pcc_stream_create", "pcc_stream_destroy", "pcc_use_stream", "pcc_entropy_encode_many",
+    "pcc_pipeline_gpu_stage_only", "pcc_pipeline_stats", "pcc_pipeline_cpu_times", "pcc_pipeline_kernel_times",
+    "pcc_delta_blocks", "pcc_device_range_encode",
+    "pcc_entropy_batch_create", "pcc_entropy_batch_destroy", "pcc_entropy_batch_size", "pcc_entropy_batch_capacity",
+    "pcc_entropy_batch_add", "pcc_entropy_batch_flush", "pcc_entropy_batch_last_error", "pcc_entropy_batch_set_option",
+    "pcc_host_rigid_compress", "pcc_host_rigid_decompress",
+    "pcc_host_range_encode", "pcc_host_range_encode_many", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
+    "pcc_host_snake_position",
+    "pcc_debug_sort_plan", "pcc_debug_pipeline_cpus", "pcc_debug_host_rc_wide",
+]
+EXPORTS = BOUNDARY_EXPORTS + TOOLS_EXPORTS
 
 
 class PccError(RuntimeError):
@@ -176,8 +182,6 @@ def load_library():
     lib.pcc_host_free.argtypes = [vp]
     lib.pcc_host_free.restype = None
     lib.pcc_entropy_encode.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
-    lib.pcc_entropy_encode2.argtypes = [vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream),
-                                        vp, C.POINTER(HotResult), C.POINTER(Params), C.POINTER(Bitstream)]
     lib.pcc_entropy_encode_many.argtypes = [i32, C.POINTER(vp), C.POINTER(C.POINTER(HotResult)), C.POINTER(C.POINTER(Params)),
                                             C.POINTER(C.POINTER(Bitstream))]
     lib.pcc_get_output_cloud.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -197,8 +201,11 @@ def load_library():
     lib.pcc_pipeline_create.argtypes = [i32, i32]
     lib.pcc_pipeline_destroy.argtypes = [vp]
     lib.pcc_pipeline_destroy.restype = None
-    lib.pcc_pipeline_workers.argtypes = [vp]
-    lib.pcc_pipeline_last_entropy_mode.argtypes = [vp]
+    lib.pcc_pipeline_get.argtypes = [vp, C.c_char_p]
+    lib.pcc_entropy_batch_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.pcc_debug_sort_plan.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.pcc_debug_pipeline_cpus.argtypes = [vp, i32, C.POINTER(i32), i32]
+    lib.pcc_debug_host_rc_wide.argtypes = []
     lib.pcc_pipeline_contexts.argtypes = [vp]
     lib.pcc_pipeline_context.restype = vp
     lib.pcc_pipeline_context.argtypes = [vp, i32]
@@ -255,7 +262,7 @@ def load_library():
     lib.pcc_host_jpeg_decode.argtypes = [vp, sz, vp, sz, C.POINTER(i32), C.POINTER(i32)]
     lib.pcc_host_snake_position.restype = C.c_uint32
     lib.pcc_host_snake_position.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
-    lib.pcc_normalize_group.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.c_double, vp, vp]
+    lib.pcc_normalize_group_boxes.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.c_double, vp, vp, vp]
     lib.pcc_restore_scaling.argtypes = [vp, sz, vp, vp]
     _lib = lib
     return lib
@@ -374,10 +381,7 @@ class Context:
 
     def entropy_encode2(self, hot_a: HotResult, params_a, other, hot_b: HotResult, params_b):
         """Two frames at once (the other frame's bitstream is stored in context `other`)."""
-        a, b = Bitstream(), Bitstream()
-        self._check(self.lib.pcc_entropy_encode2(self.h, C.byref(hot_a), C.byref(params_a), C.byref(a),
-                                                 other.h, C.byref(hot_b), C.byref(params_b), C.byref(b)))
-        return ((_bytes_at(a.data, a.len), [int(x) for x in a.perf]), (_bytes_at(b.data, b.len), [int(x) for x in b.perf]))
+        return tuple(Context.entropy_encode_many([self, other], [hot_a, hot_b], [params_a, params_b]))
 
     @staticmethod
     def entropy_encode_many(ctxs, hots, params):
@@ -561,7 +565,7 @@ class Pipeline:
         if not self.h:
             raise RuntimeError("pcc_pipeline_create(%r) failed: no usable MI355X/HIP device -- the hot path has no "
                                "CPU fallback" % (device,))
-        self.workers = self.lib.pcc_pipeline_workers(self.h)
+        self.workers = self.get("workers")
         self.n_contexts = self.lib.pcc_pipeline_contexts(self.h)
 
     def close(self):
@@ -577,7 +581,15 @@ class Pipeline:
 
     def last_entropy_mode(self):
         """Where the entropy stage of the last call ran: 0 host, 1 GPU (option "entropy_on_gpu" -1 decides per call)."""
-        return int(self.lib.pcc_pipeline_last_entropy_mode(self.h))
+        return self.get("last_entropy_mode")
+
+    def get(self, name):
+        """What the pipeline runs with: "workers", "gpu_threads", "contexts", "frames_per_coder_call", "last_entropy_mode",
+        "rc_device_lanes", "entropy_gpu_batch" (pcc_pipeline_get)."""
+        v = int(self.lib.pcc_pipeline_get(self.h, name.encode()))
+        if v < 0:
+            raise PccError(v, "pipeline value " + name)
+        return v
 
     def set_option(self, name, value):
         rc = self.lib.pcc_pipeline_set_option(self.h, name.encode(), int(value))

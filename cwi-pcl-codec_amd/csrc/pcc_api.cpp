@@ -1,4 +1,4 @@
-// pcc_api.cpp -- the C ABI declared in include/pcc_codec.h: context, HBM arena, launch of the
+// pcc_api.cpp -- the C ABI declared in include/pcc_codec.h (the boundary) and include/pcc_codec_tools.h (measurement, tests): context, HBM arena, launch of the
 // HIP hot path, device->host hand-over and the host entropy stage.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -17,7 +17,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/pcc_codec.h"
+#include "../../include/pcc_codec_tools.h"
 #include "pcc_device.h"
 #include "pcc_host_codec.h"
 #include "pcc_kernels.h"
@@ -25,6 +25,7 @@
 #include "pcc_decode.h"
 #include "pcc_delta.h"
 #include "pcc_rc_device.h"
+#include "pcc_dev.h"
 
 using namespace pcc;
 
@@ -98,7 +99,6 @@ struct pcc_ctx {
   // HBM arena (see pcc_device.h for the layout)
   DevBuf<uint8_t> d_points;  // only for the host-input entry point
   DevBuf<uint64_t> d_boxes;   // eight self-describing words per chunk (k_boxes_events)
-  DevBuf<uint64_t> d_plan;    // fused mode: the sort plan and one word per chunk, self-describing as well
   uint32_t frame_seq = 0;     // sequence number of the last enqueued frame; stamps its chunk boxes
   DevBuf<FrameState> d_state;
   DevBuf<uint64_t> d_keys_a, d_keys_b, d_leaf_code;
@@ -106,10 +106,10 @@ struct pcc_ctx {
   DevBuf<uint32_t> d_digit_tot, d_tile_prefix0, d_leaf_start, d_leaf_base, d_idx_a, d_idx_b;
   DevBuf<uint32_t> d_idx2_a, d_idx2_b, d_leaf_hi;  // trees deeper than 21 levels only (two-word codes): allocated when one comes by
   bool deep_hint = false;                          // the frame before was one: enqueue the deep kernels straight away
-  bool local_off = false;                          // a frame came by whose groups were too long for the local fix-up (PCC_SORT_LOCAL only)
   int force_pairs = 0;                             // test hooks (pcc_set_option): which key layout the sort is given
   bool no_cell_ranks = false;
-  bool payload_hint = false;                       // the frame before had a payload in its sort (PCC_SORT_BARE only)
+  bool rc_lanes = false;                           // device range coder of this context / batch: one lane per stream instead of one wave (option "rc_device_lanes")
+  int icp_waves = 0;                               // delta path: 4 = a workgroup per macroblock, 1 = a wave per macroblock, 0 = by block count
   DevBuf<uint8_t> d_leaf_t, d_bgr, d_centroid, d_image, d_sync;
   // the per-MCU-row Huffman records and, right behind them, the occupancy stream: what the host stage needs of a
   // colour frame is one contiguous piece of HBM and comes back in ONE copy (a copy costs some 40 us to set up)
@@ -219,16 +219,12 @@ int reserve(pcc_ctx* ctx, size_t n) {
     PCC_HIP(ctx->d_boxes.ensure(8 * tiles));
     PCC_HIP(hipMemsetAsync(ctx->d_boxes.p, 0, ctx->d_boxes.cap * sizeof(uint64_t), ctx->stream));
   }
-  if (ctx->d_plan.cap < kPlanGranulesHost + tiles) {  // (the same: nothing in a fresh array may look like this frame's plan)
-    PCC_HIP(ctx->d_plan.ensure(kPlanGranulesHost + tiles));
-    PCC_HIP(hipMemsetAsync(ctx->d_plan.p, 0, ctx->d_plan.cap * sizeof(uint64_t), ctx->stream));
-  }
   PCC_HIP(ctx->d_state.ensure(1));
   PCC_HIP(ctx->d_keys_a.ensure(n));
   PCC_HIP(ctx->d_keys_b.ensure(n));
   PCC_HIP(ctx->d_idx_a.ensure(n));
   PCC_HIP(ctx->d_idx_b.ensure(n));
-  PCC_HIP(ctx->d_hist_rows.ensure(std::max(stiles, tiles) * kMaxPasses * kMaxBins));  // a row per sort tile, or per chunk (fused mode)
+  PCC_HIP(ctx->d_hist_rows.ensure(stiles * kMaxPasses * kMaxBins));  // a row per sort tile
   PCC_HIP(ctx->d_digit_tot.ensure((size_t)kMaxPasses * kMaxBins));
   PCC_HIP(ctx->d_tile_prefix0.ensure(stiles * kMaxBins));
   PCC_HIP(ctx->d_sync.ensure(sync_area_bytes((uint32_t)n, kMaxPasses)));
@@ -259,7 +255,7 @@ int reserve(pcc_ctx* ctx, size_t n) {
 // microseconds of extra latency are hidden by the other frames in flight.  PCC_WAIT=event restores the runtime's wait.
 int wait_stream(pcc_ctx* ctx, int site = 2) {
   static const int mode = [] {
-    const char* e = getenv("PCC_WAIT");
+    const char* e = dev_env("PCC_WAIT");
     return (e && !strcmp(e, "event")) ? 1 : 0;
   }();
   PCC_HIP(hipEventRecord(ctx->ev_wait, ctx->stream));
@@ -385,6 +381,8 @@ extern "C" {
 const char* pcc_version(void) {
 #if defined(PCC_EMU)
   return "pcc_emu 0.1 (CPU wave64 executor: test infrastructure, not the product)";
+#elif defined(PCC_DEV)
+  return "pcc_hip 0.1 (gfx950, dev build)";
 #elif defined(PCC_WAVE_OPS_SHFL)
   return "pcc_hip 0.1 (gfx950, shfl bisect build)";
 #elif defined(PCC_KTIME)
@@ -400,7 +398,8 @@ pcc_ctx* pcc_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   pcc_ctx* c = new pcc_ctx();
   c->device = device;
-  { const char* e = getenv("PCC_PACK_UPLOAD"); c->pack_upload = e && e[0] == '1'; }
+  { const char* e = dev_env("PCC_PACK_UPLOAD"); c->pack_upload = e && e[0] == '1'; }
+  { const char* e = dev_env("PCC_RC_DEVICE"); c->rc_lanes = e && !strcmp(e, "lanes"); }
   {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
@@ -428,13 +427,13 @@ void pcc_destroy(pcc_ctx* c) {
     return;
   }
   (void)hipSetDevice(c->device);
-  if (getenv("PCC_WAIT_STATS") && c->usual_wait_ns[0] > 0)
+  if (dev_env("PCC_WAIT_STATS") && c->usual_wait_ns[0] > 0)
     fprintf(stderr, "[pcc_ctx %p] usual waits: kernels %.0f us, copies %.0f us, other %.0f us\n", (void*)c, c->usual_wait_ns[0] / 1e3,
             c->usual_wait_ns[1] / 1e3, c->usual_wait_ns[2] / 1e3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->locked_host) { unlock_host_range(c->locked_host); c->locked_host = nullptr; }
   c->d_dec.release(); c->d_dec_points.release(); c->h_dec_stage.release(); c->h_dec_points.release();
-  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_plan.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release(); c->d_idx2_a.release(); c->d_idx2_b.release(); c->d_leaf_hi.release();
+  c->delta_cloud.release(); c->d_points.release(); c->d_spans.release(); c->h_spans.release(); c->d_boxes.release(); c->d_state.release(); c->d_keys_a.release(); c->d_keys_b.release(); c->d_idx_a.release(); c->d_idx_b.release(); c->d_idx2_a.release(); c->d_idx2_b.release(); c->d_leaf_hi.release();
   c->d_leaf_code.release(); c->d_hist_rows.release(); c->d_digit_tot.release(); c->d_tile_prefix0.release(); c->d_sync.release();
   c->d_leaf_start.release(); c->d_leaf_base.release(); c->d_leaf_t.release(); c->d_occ.release(); c->d_bgr.release();
   c->d_centroid.release(); c->d_image.release(); c->d_simplified.release(); c->d_coefs.release(); c->h_coefs.release(); c->d_lines.release(); c->h_lines.release();
@@ -476,7 +475,8 @@ int pcc_set_option(pcc_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "profile_events")) ctx->profile_events = value != 0;
   else if (!strcmp(name, "force_pairs")) ctx->force_pairs = value;          // test hooks: see launch_frame
   else if (!strcmp(name, "no_cell_ranks")) ctx->no_cell_ranks = value != 0;
-  else if (!strcmp(name, "rc_device_lanes")) set_range_encode_lanes(value);  // (process-wide) the device range coder: one lane per stream instead of one wave
+  else if (!strcmp(name, "icp_waves")) ctx->icp_waves = value;               // test hook: one ICP kernel shape for every macroblock
+  else if (!strcmp(name, "rc_device_lanes")) ctx->rc_lanes = value != 0;     // the device range coder of THIS context: one lane per stream instead of one wave
   else return fail(ctx, PCC_ERR_ARG, std::string("unknown option ") + name);
   return PCC_OK;
 }
@@ -581,16 +581,6 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.lp.write_image = (a.lp.do_color && prm->color_coding_type == 1) ? 1u : 0u;
   a.max_passes = std::min(std::max(ctx->pass_hint, 1), (int)kMaxPasses);
   a.deep_launch = ctx->deep_hint ? 1 : 0;
-  {
-    // PCC_SORT_BARE=1 (experiment, off by default): sort passes without the payload path, three tiles per CU; frames that
-    // turn out to need a payload (centroids, codes too long for the colour to share the key) are sent back once
-    static const bool bare_env = [] { const char* e = getenv("PCC_SORT_BARE"); return e && e[0] == '1'; }();
-    a.bare_launch = (bare_env && !ctx->payload_hint && !a.deep_launch) ? 1 : 0;
-    // PCC_SORT_LOCAL=1 (experiment, off by default): the lowest code bits are sorted locally in k_leaf_scan when that saves
-    // a global sort pass; a frame with a group too long for it is sent back once and the context stops trying
-    static const bool local_env = [] { const char* e = getenv("PCC_SORT_LOCAL"); return e && e[0] == '1'; }();
-    a.local_launch = (local_env && !ctx->local_off && !a.deep_launch && !stop_after_leaf_scan) ? 1 : 0;
-  }
   // test hooks (pcc_set_option "force_pairs" / "no_cell_ranks"; nothing reads the environment per frame):
   // force_pairs 1: the pair sort on small frames; 2: keep the point index in the key although nothing needs it (the packed
   // [code | index] + colour payload sort); no_cell_ranks 1: the full varying Morton code is sorted
@@ -598,18 +588,6 @@ static int launch_frame(pcc_ctx* ctx, const void* dev_points, size_t n, size_t s
   a.need_index = (a.lp.do_centroid || stop_after_leaf_scan || ctx->force_pairs == 2) ? 1 : 0;
   a.no_cell_ranks = ctx->no_cell_ranks ? 1 : 0;
   a.boxes = ctx->d_boxes.p; a.state = ctx->d_state.p;
-  {
-    // The two-kernel form (k_boxes_events reads the coordinates, k_make_keys reads the cloud again) is the default: it has
-    // run on the chip.  PCC_FUSED_KEYS=1: the streaming workgroups wait for workgroup 0's plan and write the keys themselves
-    // (the cloud is read once) -- off until it has been timed on an MI355X with ten frames in flight, where the grid is not
-    // resident as a whole and a late chunk idles on its CU for up to plan_spins before it falls back.
-    // PCC_PLAN_SPINS: how long a streaming workgroup waits for the plan (test hook: 1 = every chunk falls back)
-    static const int fused_env = [] { const char* e = getenv("PCC_FUSED_KEYS"); return e ? atoi(e) : 0; }();
-    static const int spins_env = [] { const char* e = getenv("PCC_PLAN_SPINS"); return e ? atoi(e) : 0; }();
-    a.fused_keys = fused_env ? 1 : 0;
-    a.plan = ctx->d_plan.p;
-    a.plan_spins = spins_env > 0 ? (uint32_t)spins_env : kDefaultPlanSpins;
-  }
   a.keys_a = ctx->d_keys_a.p; a.keys_b = ctx->d_keys_b.p;
   a.idx_a = ctx->d_idx_a.p; a.idx_b = ctx->d_idx_b.p;
   if (a.deep_launch) {
@@ -674,29 +652,13 @@ void pcc_upload_lane_destroy(pcc_upload_lane* l) {
   delete l;
 }
 
-// developer aid (not part of include/pcc_codec.h): the sort geometry of the last frame whose state came back --
+// developer aid (include/pcc_codec_tools.h, the pcc_debug_* block): the sort geometry of the last frame whose state came back --
 // {sort passes, code bits that were sorted, varying Morton bits, key bits per axis below the cell ranks, bytes per key and pass}
 int pcc_debug_sort_plan(pcc_ctx* ctx, int32_t out[5]) {
   if (!ctx || !out) return PCC_ERR_ARG;
   PCC_NEED_GPU();
   const FrameState& st = *ctx->h_state.p;
   out[0] = st.npasses; out[1] = st.code_bits; out[2] = st.vbits; out[3] = st.code_low_bits; out[4] = st.payload ? 12 : 8;
-  return PCC_OK;
-}
-
-// developer aid (not part of include/pcc_codec.h): fused mode of the last frame launched on this context --
-// {chunks whose keys the streaming workgroups of k_boxes_events made themselves, chunks of the frame, 1 if the mode was on}
-int pcc_debug_fused_chunks(pcc_ctx* ctx, uint32_t out[3]) {
-  if (!ctx || !out) return PCC_ERR_ARG;
-  PCC_NEED_GPU();
-  PCC_HIP(hipSetDevice(ctx->device));
-  const uint32_t chunks = (uint32_t)((ctx->args.n + kTile - 1) / kTile);
-  out[0] = 0; out[1] = chunks; out[2] = (ctx->args.fused_keys && ctx->args.plan && chunks <= kFusedMaxChunks) ? 1u : 0u;
-  if (!out[2] || !chunks) return PCC_OK;
-  std::vector<uint64_t> w(chunks);
-  PCC_HIP(hipStreamSynchronize(ctx->stream));
-  PCC_HIP(hipMemcpy(w.data(), ctx->args.plan + kPlanGranulesHost, chunks * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  for (uint64_t x : w) out[0] += ((uint32_t)(x >> 32) == ctx->args.frame_seq && (uint32_t)x != 0u) ? 1u : 0u;
   return PCC_OK;
 }
 
@@ -800,13 +762,7 @@ static int wait_frame_state(pcc_ctx* ctx) {
   for (int attempt = 0; attempt < 6; ++attempt) {
     if (st.error == kErrPasses && ctx->args.max_passes < (int)kMaxPasses) {
       ctx->args.max_passes = kMaxPasses;
-    } else if (st.error == kErrLocal && ctx->args.local_launch) {
-      ctx->args.local_launch = 0;
-      ctx->local_off = true;
-    } else if (st.error == kErrPayload && ctx->args.bare_launch) {
-      ctx->args.bare_launch = 0;
     } else if (st.error == kErrDeep && !ctx->args.deep_launch) {
-      ctx->args.bare_launch = 0;
       // a tree deeper than 21 levels: its Morton codes need two words; the kernels' DEEP instantiations and their arrays
       ctx->args.deep_launch = 1;
       ctx->args.max_passes = kMaxPasses;
@@ -831,7 +787,6 @@ static int wait_frame_state(pcc_ctx* ctx) {
   if (st.n_epochs == 0) return fail(ctx, PCC_ERR_EMPTY, "no finite point: frame dropped");
   ctx->pass_hint = st.npasses;
   ctx->deep_hint = st.depth > kMaxDepth;  // (a shallow frame behind a deep one goes back to the single-word kernels)
-  ctx->payload_hint = st.payload != 0;
   return PCC_OK;
 }
 
@@ -882,7 +837,7 @@ int pcc_hotpath_finish(pcc_ctx* ctx, pcc_hot_result* out) {
   if (ctx->n == 0) return fail(ctx, PCC_ERR_EMPTY, "empty cloud: frame dropped");
   PCC_HIP(hipSetDevice(ctx->device));
   // developer aid (PCC_FINISH_TRACE=1): calls that take longer than 2 ms say where the time went (wall / CPU of this thread)
-  static const bool trace = [] { const char* e = getenv("PCC_FINISH_TRACE"); return e && e[0] == '1'; }();
+  static const bool trace = [] { const char* e = dev_env("PCC_FINISH_TRACE"); return e && e[0] == '1'; }();
   auto now_pair = [](double t[2]) {
     timespec a, b;
     clock_gettime(CLOCK_MONOTONIC, &a);
@@ -1048,15 +1003,6 @@ int pcc_entropy_encode_many(int n, pcc_ctx* const ctx[], const pcc_hot_result* c
   entropy_encode_frames(n, hot, prm, o, pf, t);
   for (int i = 0; i < n; ++i) { out[i]->data = ctx[i]->bitstream.data(); out[i]->len = ctx[i]->bitstream.size(); }
   return PCC_OK;
-}
-
-int pcc_entropy_encode2(pcc_ctx* ctx_a, const pcc_hot_result* hot_a, const pcc_params* prm_a, pcc_bitstream* out_a,
-                        pcc_ctx* ctx_b, const pcc_hot_result* hot_b, const pcc_params* prm_b, pcc_bitstream* out_b) {
-  pcc_ctx* c[2] = {ctx_a, ctx_b};
-  const pcc_hot_result* h[2] = {hot_a, hot_b};
-  const pcc_params* p[2] = {prm_a, prm_b};
-  pcc_bitstream* o[2] = {out_a, out_b};
-  return pcc_entropy_encode_many(2, c, h, p, o);
 }
 
 int pcc_encode_intra_device(pcc_ctx* ctx, const void* dev_points, size_t n, size_t stride, size_t rgb_offset,
@@ -1454,6 +1400,11 @@ pcc_entropy_batch* pcc_entropy_batch_create(int device, size_t max_frames) {
   return b;
 }
 
+// options of the batch's own context ("rc_device_lanes": which form of the device range coder its flushes launch)
+int pcc_entropy_batch_set_option(pcc_entropy_batch* b, const char* name, int value) {
+  return b ? pcc_set_option(b->ctx, name, value) : PCC_ERR_ARG;
+}
+
 void pcc_entropy_batch_destroy(pcc_entropy_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
@@ -1566,7 +1517,7 @@ static int entropy_batch_flush_frames(pcc_entropy_batch* b, pcc_bitstream* out, 
   PCC_HIP(b->d_lens.ensure(nj));
   PCC_HIP(b->d_offs.ensure(nj));
   PCC_HIP(b->d_jobs.ensure(nj));
-  const bool lanes = range_encode_lanes() != 0;  // (read once: the option is process-wide and may be flipped by another thread)
+  const bool lanes = ctx->rc_lanes;
   if (lanes) PCC_HIP(b->d_hists.ensure((size_t)nj * 256));
   PCC_HIP(b->h_lens.ensure(nj));
   for (uint32_t k = 0; k < nj; ++k) { jobs[k].out = b->d_out.p + out_off[k]; jobs[k].out_len = b->d_lens.p + k; }
@@ -1644,7 +1595,7 @@ int pcc_device_range_encode(pcc_ctx* ctx, int n_streams, const uint8_t* const* i
   const size_t job_off = at;
   at += ((size_t)n_streams * sizeof(RcJob) + 63) & ~(size_t)63;
   const size_t hist_off = at;   // (the lane-per-stream form counts the symbols of every stream here first)
-  const bool lanes = range_encode_lanes() != 0;
+  const bool lanes = ctx->rc_lanes;
   if (lanes) at += (size_t)n_streams * 256 * sizeof(uint32_t);
   PCC_HIP(ctx->d_rc.ensure(at));
   std::vector<RcJob> jobs((size_t)n_streams);
@@ -1724,11 +1675,7 @@ int pcc_host_jpeg_decode(const uint8_t* jpg, size_t len, uint8_t* rgb, size_t rg
   return PCC_OK;
 }
 uint32_t pcc_host_snake_position(uint32_t i, uint32_t w, uint32_t h) { return snake_position(i, w, h); }
-
-int pcc_normalize_group(pcc_point_xyzrgb** clouds, const size_t* sizes, size_t n_clouds, double f, float bb_min[3],
-                        float bb_max[3]) {
-  return pcc_normalize_group_boxes(clouds, sizes, n_clouds, f, bb_min, bb_max, nullptr);
-}
+int pcc_debug_host_rc_wide(void) { return StaticRangeCoder::wide_available() ? 1 : 0; }
 
 int pcc_normalize_group_boxes(pcc_point_xyzrgb** clouds, const size_t* sizes, size_t n_clouds, double f, float bb_min[3],
                               float bb_max[3], float* per_cloud) {
@@ -1914,6 +1861,7 @@ int pcc_encode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   da.var_threshold = dp->icp_var_threshold > 0.f ? dp->icp_var_threshold : 100.f;
   da.do_icp_color_offset = cp.do_icp_color_offset ? 1 : 0;
   // second stream: the residual intra coder's (idle until the blocks are decided); its two timing events do as fork / join
+  da.shape = ctx->icp_waves == 4 ? 1 : (ctx->icp_waves == 1 ? 2 : 0);
   launch_delta_blocks(da, ctx->stream, ctx->sub[3]->stream, ctx->sub[3]->ev_begin, ctx->sub[3]->ev_end);
   PCC_HIP(hipGetLastError());
   ctx->h_blocks.resize(nbp);
@@ -2028,7 +1976,7 @@ int pcc_decode_delta(pcc_ctx* ctx, const pcc_point_xyzrgb* i_cloud, size_t n_i, 
   PCC_HIP(hipSetDevice(ctx->device));
   ctx->delta_cloud_n = 0;
   bool delta_copy_pending = false;
-  static const bool trace = getenv("PCC_TRACE_DELTA") != nullptr;  // developer knob: where the call's time goes
+  static const bool trace = dev_env("PCC_TRACE_DELTA") != nullptr;  // developer knob: where the call's time goes
   timespec tr0;
   clock_gettime(CLOCK_MONOTONIC, &tr0);
   auto mark = [&](const char* what) {

@@ -526,10 +526,9 @@ void launch_delta_blocks(const DeltaArgs& a, hipStream_t stream, hipStream_t aux
   hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, stream, a.work, nbp, a.order, a.counts);
   // Few blocks: every one gets a workgroup (the longest block's latency is what counts).  Many blocks: the heavy ones
   // (first in the order) get a workgroup each, the rest a wave each; both launches cover the worst case and the
-  // surplus workgroups leave at once.  PCC_ICP_WAVES = 1 / 4 forces one shape for all blocks (tests).
-  const char* force = getenv("PCC_ICP_WAVES");
+  // surplus workgroups leave at once.  a.shape = 1 / 2 on entry forces one shape for all blocks (test hook: option "icp_waves").
   DeltaArgs b = a;
-  b.shape = force ? (force[0] == '4' ? 1 : 2) : (nbp <= 2048 ? 1 : 0);
+  b.shape = a.shape ? a.shape : (nbp <= 2048 ? 1 : 0);
   // the two shapes work on disjoint blocks: side by side on two streams when the caller has a second one
   const bool fork = b.shape == 0 && aux && ev_fork && ev_join;
   if (fork) {

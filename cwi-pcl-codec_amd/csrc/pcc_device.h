@@ -63,8 +63,6 @@ enum FrameError : int32_t {
   kErrPasses = 4,          // the frame needs more sort passes than the host enqueued (host re-launches)
   kErrSpin = 5,            // a look-back poll ran into kSpinLimit (should not happen)
   kErrDeep = 6,            // the tree is deeper than kMaxDepth and the host enqueued the single-word kernels (host re-launches)
-  kErrLocal = 8,           // local fix-up of the low code bits (PCC_SORT_LOCAL): a group of equal high bits is too long for it (host re-launches without)
-  kErrPayload = 7,         // the keys carry a payload and the host enqueued the payload-free sort passes (host re-launches)
 };
 
 struct FrameState {
@@ -86,8 +84,6 @@ struct FrameState {
   int32_t payload;                   // what the u32 payload of the sort carries: 0 nothing, 1 point index (pairs
                                      // mode), 2 the point's colour word (packed mode with colour: no gather later)
   int32_t colour_in_key;             // 1: the low 24 key bits (ibits = 24) are the point's colour, no payload, no index
-  int32_t local_bits;                // > 0 (experiment, PCC_SORT_LOCAL): the sort passes leave the lowest local_bits code bits alone and
-                                     // k_leaf_scan sorts every group of equal higher bits in LDS (and writes the sorted colour words to idx_a)
   int32_t keys_final;                // which key buffer the last sort pass wrote: 0 = a, 1 = b
   int32_t deep;                      // 1: two-word codes (depth > kMaxDepth): key = low 63 code bits, payload = 3: the high code bits
   int32_t payload2;                  // deep only, the second payload array: 0 nothing, 1 point index, 2 the point's colour word

@@ -7,6 +7,7 @@
 //   JPEG        = libjpeg-turbo as configured by jpeg_io.hpp:259-314 (encode) and :110-188 (decode)
 //   header      = impl.hpp:1472-1486 + the PCL base header it calls at :1477
 #include "pcc_host_codec.h"
+#include "pcc_dev.h"
 
 #include <float.h>
 #include <immintrin.h>
@@ -384,7 +385,7 @@ void rc_run_many_wide(RcStream* sb, int live, size_t i0, size_t i1, RcWide& L) {
 
 bool StaticRangeCoder::wide_available() {
   static const bool ok = [] {
-    const char* e = getenv("PCC_RC_WIDE");
+    const char* e = dev_env("PCC_RC_WIDE");
     if (e && e[0] == '0') return false;
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && __builtin_cpu_supports("avx512bw") &&
            __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
@@ -1044,7 +1045,7 @@ namespace {
 struct DecodeTrace {
   bool on;
   std::chrono::steady_clock::time_point t;
-  DecodeTrace() : on(getenv("PCC_DECODE_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  DecodeTrace() : on(dev_env("PCC_DECODE_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
   void lap(const char* what) {
     if (!on) return;
     const auto now = std::chrono::steady_clock::now();
@@ -1929,7 +1930,7 @@ int decode_frame(const uint8_t* stream, size_t len, PointVec& points, pcc_cloud&
   int walk_rc = PCC_OK;
   bool walked = false;
   auto start_walk = [&]() {
-    static const bool serial = getenv("PCC_DECODE_SERIAL") != nullptr;  // developer knob: no second thread
+    static const bool serial = dev_env("PCC_DECODE_SERIAL") != nullptr;  // developer knob: no second thread
     if (serial || info.params.do_voxel_centroid || fs.count > 8 * (uint64_t)fs.occ.size()) return;
     points.resize((size_t)fs.count);
     try {

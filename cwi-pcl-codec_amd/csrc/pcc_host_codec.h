@@ -10,7 +10,7 @@
 #include <functional>
 #include <vector>
 
-#include "../../include/pcc_codec.h"
+#include "../../include/pcc_codec_tools.h"
 
 namespace pcc {
 

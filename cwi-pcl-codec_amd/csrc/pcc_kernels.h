@@ -69,9 +69,6 @@ struct HotPathArgs {
   int need_index;  // somebody reads the point index of the sorted elements (centroids, macroblock trees): keep it in the key
   FixedBox box;    // defineBoundingBox before addPointsFromInputCloud
   int stop_after_leaf_scan;  // macroblock trees: only the sorted points and the leaf (= block) arrays are wanted
-  int fused_keys;      // 1: the streaming workgroups of k_boxes_events make the sort keys themselves (the cloud is read once)
-  uint64_t* plan;      // fused mode: 64 plan granules, then one granule per chunk, {frame_seq, value} each (zeroed when allocated)
-  uint32_t plan_spins; // fused mode: how often a streaming workgroup polls for the plan before it leaves its chunk to k_make_keys
   uint64_t* boxes;     // eight {value, frame_seq} words per 2048-point chunk (zeroed when allocated)
   uint32_t frame_seq;  // never 0, different from the frame before on this arena: tells this frame's chunk boxes from older ones
   FrameState* state;
@@ -79,16 +76,12 @@ struct HotPathArgs {
   uint64_t* keys_b;
   uint32_t* idx_a;
   uint32_t* idx_b;
-  int local_launch;    // 1: enqueue the LOCAL leaf scan (PCC_SORT_LOCAL=1, an experiment): the device may then leave the lowest code bits
-                       // to a local fix-up and save a sort pass; kErrLocal sends a frame back whose groups are too long for it
-  int bare_launch;     // 1: enqueue the payload-free sort passes (PCC_SORT_BARE=1, an experiment): a frame whose keys carry a
-                       // payload comes back with kErrPayload
   int deep_launch;     // 1: enqueue the DEEP instantiations (two-word Morton codes: trees of 22 to 31 levels); the device sends
                        // a deep frame that meets the single-word kernels back with kErrDeep
   uint32_t* idx2_a;    // deep only: second payload of the sort (point index or colour word), ping-pong
   uint32_t* idx2_b;
   uint32_t* leaf_hi;   // deep only: high word of each leaf's code
-  uint16_t* hist_rows;  // [sort tiles or chunks][kMaxPasses][kMaxBins] digit counts (at most 4096 each) from the key makers
+  uint16_t* hist_rows;  // [sort tiles][kMaxPasses][kMaxBins] digit counts (at most 4096 each) from k_make_keys
   uint32_t* digit_tot;  // [kMaxPasses][kMaxBins]
   uint32_t* tile_prefix0;  // [sort tiles][kMaxBins] exclusive tile prefix of the pass-0 digit counts
   uint8_t* sync_area;   // tickets | leaf scan status | sort status (sync_area_bytes), zeroed by k_boxes_events
@@ -151,17 +144,6 @@ class KernelTimer {
 };
 
 size_t sync_area_bytes(uint32_t n, int passes);
-// fused mode is for frames whose bounding-box chunks can all be resident at once (the streaming workgroups wait for the plan)
-constexpr uint32_t kFusedMaxChunks = 1024;
-constexpr size_t kPlanGranulesHost = 512;  // = kPlanGranules of pcc_kernels.hip (plan words, epoch table)
-// a poll and an s_sleep(32) take about a microsecond on the GPU: the plan of a lone frame arrives after ~15 us, so this
-// bound is only met when the grid is not resident as a whole (other frames' kernels in the way).  The CPU executor of
-// tests/emu has no clock to speak of: there the bound is large, and a test sets it to 1 to see the fallback work.
-#ifdef PCC_EMU
-constexpr uint32_t kDefaultPlanSpins = 1u << 22;
-#else
-constexpr uint32_t kDefaultPlanSpins = 96;
-#endif
 void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm);
 
 }  // namespace pcc

@@ -29,6 +29,7 @@
 
 #include "pcc_device.h"
 #include "pcc_kernels.h"
+#include "pcc_dev.h"
 
 namespace pcc {
 
@@ -219,6 +220,12 @@ __device__ __forceinline__ void publish_u64(uint64_t* p, uint64_t v) {
 __device__ __forceinline__ uint64_t poll_u64(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The frame's sticky error word.  A workgroup that gives up stores its code; kernels of LATER launches read the word like any
+// other field of the state, but k_leaf_scan's tiles read it in the launch in which other tiles may store into it -- so inside
+// kernels it is written, and there read, like every word that crosses workgroups inside a launch.  (Several workgroups may
+// raise: any of their codes sends the frame back or fails it.)
+__device__ __forceinline__ void raise_error(FrameState* st, int code) { publish_u32(reinterpret_cast<uint32_t*>(&st->error), (uint32_t)code); }
+__device__ __forceinline__ int poll_error(const FrameState* st) { return (int)poll_u32(reinterpret_cast<const uint32_t*>(&st->error)); }
 
 // A place where the code relies on all 64 lanes of the wave having executed everything above it before any lane goes
 // on (the LDS operations of one wave are issued in program order): nothing on the GPU; a meeting point of the lanes in
@@ -280,8 +287,7 @@ struct KSpan {
 // ------------------------------------------------------------------------------------------
 constexpr int kBoxWords = 8;  // mn xyz, mx xyz, first finite index, finite count
 
-// ---- octree key of a point (P3, genOctreeKeyforPoint) -> the code that is sorted.  Shared by k_make_keys and by the
-//      streaming workgroups of k_boxes_events when they make the keys themselves (fused mode, below).
+// ---- octree key of a point (P3, genOctreeKeyforPoint) -> the code that is sorted
 constexpr uint64_t kInvalidKey = ~0ull;
 struct KeyGeom {
   int vb, cm, np, ibits, payload, payload2;
@@ -322,34 +328,6 @@ __device__ __forceinline__ uint32_t code_digit(const KeyGeom& g, int q, uint64_t
   return (g.pshift[q] >= 63 ? (hi >> (g.pshift[q] - 63)) : (uint32_t)(lo >> g.pshift[q])) & g.pmask[q];
 }
 
-// ---- fused mode ("read the cloud once"): the streaming workgroups keep their 2048 points in registers, and once
-//      workgroup 0 has published the sort plan they turn them into sort keys and digit counts themselves; k_make_keys
-//      then only visits the chunks that could not do that (the chunk that holds the growth events -- normally chunk 0
-//      alone --, a workgroup whose wait for the plan ran out).  The plan is a block of self-describing 8-byte granules
-//      {frame sequence number, value} (cdna_hip_programming.md guideline 16, form R2: the data is the flag, every word
-//      one agent-scope store and one agent-scope load, no fence).  Behind the plan, one granule per chunk says what
-//      became of it: 1 = keys and digit counts written, 2 = the same, but a key fell outside the predicted window.
-//      A streaming workgroup waits for workgroup 0, which waits for every streaming workgroup's BOX -- published
-//      before the wait starts -- so nobody waits for anybody who waits for him; the wait is bounded all the same
-//      (`plan_spins`), because with other frames' kernels on the GPU the grid need not be resident as a whole.
-constexpr int kPlanMn = 0;          // 6 words: the final box origin (three doubles)
-constexpr int kPlanBits = 6;        // vb | cm << 8 | np << 16 | ibits << 24
-constexpr int kPlanFlags = 7;       // 1 valid | packed << 1 | payload << 2 | colour_in_key << 4
-constexpr int kPlanPrefix = 8;      // 3 words
-constexpr int kPlanCellBase = 11;   // 3 words
-constexpr int kPlanCellDim = 14;    // 3 words
-constexpr int kPlanLastEpoch = 17;  // index of the first point of the last epoch
-constexpr int kPlanPass = 18;       // kMaxPasses words: bits | shift << 8
-constexpr int kPlanRanks = kPlanPass + kMaxPasses;  // 16 words: cell_rank[64]
-constexpr int kPlanEpochs = kPlanRanks + 16;        // number of epochs
-constexpr int kPlanWords = kPlanEpochs + 1;
-// behind the plan's words: the epoch table, ten granules per epoch {first index, origin (three doubles), key offsets (3)},
-// for the workgroups whose chunk holds points of earlier epochs (the chunk with the growth events)
-constexpr int kPlanEpochBase = 64, kPlanEpochWords = 10;
-constexpr int kPlanGranules = 512;  // the per-chunk granules start here
-static_assert(kPlanPass + kMaxPasses == kPlanRanks && kPlanWords + 3 <= 64 && kPlanEpochBase + kPlanEpochWords * kMaxEpochs <= kPlanGranules &&
-              kPlanGranules == (int)kPlanGranulesHost, "one wave sweeps the plan");
-
 __device__ __forceinline__ void publish_box(uint64_t* dst, const ChunkBox& b, uint32_t seq) {
   uint32_t v[kBoxWords];
   __builtin_memcpy(v, &b, sizeof(b));
@@ -374,21 +352,8 @@ __device__ __forceinline__ bool fetch_box(const uint64_t* src, uint32_t seq, Chu
   return decode_box(w, seq, b);
 }
 
-// what the streaming workgroups need to make keys themselves (fused mode); all null / zero otherwise
-struct FusedKeys {
-  uint64_t* plan;        // kPlanGranules plan granules, then one granule per chunk
-  uint64_t* keys;
-  uint32_t* idx;
-  uint16_t* hist_rows;   // one row of kMaxPasses x kMaxBins digit counts per CHUNK in this mode (a count is at most 4096: 16 bits)
-  double inv_res_pow2;
-  uint32_t plan_spins;   // polls of the plan before a workgroup gives up and leaves its chunk to k_make_keys
-  int do_color;
-};
-
-template <bool FUSED>
 __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n, uint32_t c, uint32_t n_chunks, uint64_t* __restrict__ boxes,
-                                                uint32_t seq, uint4* __restrict__ sync_area, uint32_t sync_vec16, float* s_f, int* s_i,
-                                                double res, const FusedKeys& fk) {
+                                                uint32_t seq, uint4* __restrict__ sync_area, uint32_t sync_vec16, float* s_f, int* s_i) {
   float(*s_mn)[kBlock / 64] = reinterpret_cast<float(*)[kBlock / 64]>(s_f);
   float(*s_mx)[kBlock / 64] = reinterpret_cast<float(*)[kBlock / 64]>(s_f + 3 * (kBlock / 64));
   int* s_first = s_i;
@@ -399,25 +364,18 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
   const uint32_t base = c * kTile;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   int first = 0x7fffffff, cnt = 0;
-  // fused mode: the chunk stays in registers until the plan is there (a non-finite point as NaN; colour words only when
-  // the frame has colours)
-  float px[FUSED ? kItems : 1], py[FUSED ? kItems : 1], pz[FUSED ? kItems : 1];
-  uint32_t pc[FUSED ? kItems : 1];
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
     const uint32_t i = base + k * kBlock + threadIdx.x;
-    if (FUSED) { px[FUSED ? k : 0] = __builtin_nanf(""); pc[FUSED ? k : 0] = 0u; }
     if (i < n) {
       float x, y, z;
       load_xyz(pv, i, x, y, z);
-      if (FUSED && fk.do_color) pc[FUSED ? k : 0] = load_rgba(pv, i);
       if (finite3(x, y, z)) {
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
         mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         first = min(first, (int)i);
         ++cnt;
-        if (FUSED) { px[FUSED ? k : 0] = x; py[FUSED ? k : 0] = y; pz[FUSED ? k : 0] = z; }
       }
     }
   }
@@ -444,141 +402,30 @@ __device__ __forceinline__ void chunk_box_block(const PointView& pv, uint32_t n,
     publish_box(boxes + (size_t)c * kBoxWords, b, seq);
   }
   PCC_KTR(6, 7);
-  if (!FUSED) return;
-
-  // ---- fused mode: wait for the plan (bounded), then keys and digit counts of this chunk ----
-  uint32_t* s_plan = reinterpret_cast<uint32_t*>(s_f) + 64;   // [kPlanWords] + {got it, a key missed the window, got the epoch table}
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_f) + 128;  // [np][kMaxBins]
-  if (wave_id() == 0) {
-    const int l = lane_id();
-    bool got = false;
-    // Hundreds of workgroups wait here: while the plan is not there they all look at ONE word (the whole wave reads the same
-    // address: one request), and only sweep the granules once that one carries this frame's tag (the others follow
-    // within nanoseconds: they are stored by one instruction of one wave) -- polling traffic on the lines workgroup 0 is
-    // about to write is what would slow everybody down (guideline 16, pitfall 9).
-    bool first_seen = false;
-    for (uint32_t spin = 0; spin < fk.plan_spins; ++spin) {
-      if (!first_seen) {
-        first_seen = (uint32_t)(poll_u64(fk.plan + kPlanFlags) >> 32) == seq;
-        if (!first_seen) { __builtin_amdgcn_s_sleep(32); continue; }
-      }
-      const uint64_t w = l < kPlanWords ? poll_u64(fk.plan + l) : ((uint64_t)seq << 32);
-      const bool there = (uint32_t)(w >> 32) == seq;
-      if (__ballot(!there) == 0ull) {
-        if (l < kPlanWords) s_plan[l] = (uint32_t)w;
-        got = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (l == 0) { s_plan[kPlanWords] = got ? 1u : 0u; s_plan[kPlanWords + 1] = 0u; }
-  }
-  __syncthreads();
-  if (!s_plan[kPlanWords]) return;                       // the wait ran out: k_make_keys does this chunk
-  const uint32_t flags = s_plan[kPlanFlags];
-  if (!(flags & 1u)) return;                            // the frame ended in an error or holds no finite point
-  KeyGeom g;
-  {
-    const uint32_t bits = s_plan[kPlanBits];
-    g.vb = (int)(bits & 0xffu); g.cm = (int)((bits >> 8) & 0xffu); g.np = (int)((bits >> 16) & 0xffu); g.ibits = (int)(bits >> 24);
-    g.packed_mode = ((flags >> 1) & 1u) != 0; g.payload = (int)((flags >> 2) & 3u); g.colour_in_key = ((flags >> 4) & 1u) != 0;
-    g.deep = false; g.payload2 = 0;  // (a deep frame's plan is not valid: k_make_keys makes its keys)
-    g.ranked = g.cm < g.vb;
-    g.lm = g.cm >= 32 ? 0xffffffffu : ((1u << g.cm) - 1u);
-    g.m = g.vb >= 32 ? 0xffffffffu : ((1u << g.vb) - 1u);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { g.prefix[a] = s_plan[kPlanPrefix + a]; g.cbase[a] = s_plan[kPlanCellBase + a]; g.cdim[a] = s_plan[kPlanCellDim + a]; }
-#pragma unroll
-    for (int q = 0; q < kMaxPasses; ++q) { const uint32_t w = s_plan[kPlanPass + q]; g.pshift[q] = (int)(w >> 8); g.pmask[q] = (1u << (w & 0xffu)) - 1u; }
-  }
-  if (g.np > 7) return;  // (single-word codes have at most seven passes; the LDS behind the digit counts is laid out for that)
-  double emn[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) emn[a] = __longlong_as_double((long long)(((uint64_t)s_plan[kPlanMn + 2 * a + 1] << 32) | s_plan[kPlanMn + 2 * a]));
-  const uint8_t* ranks = reinterpret_cast<const uint8_t*>(s_plan + kPlanRanks);
-  // A chunk that holds points of earlier epochs (the one with the growth events: chunk 0 of a shuffled cloud; many chunks of
-  // a cloud sorted along an axis) needs the epoch table: ten granules per epoch behind the plan's words, swept the same way.
-  const int ne = (int)s_plan[kPlanEpochs];
-  const bool early = (int)base < (int)s_plan[kPlanLastEpoch];
-  uint32_t* s_ep = s_hist + 7 * kMaxBins;  // [ne][kPlanEpochWords]
-  if (early) {
-    if (wave_id() == 0) {
-      const int l = lane_id(), nw = ne * kPlanEpochWords;
-      bool all_there = true;
-      for (int r0 = 0; r0 < nw && all_there; r0 += 64) {
-        bool got = false;
-        for (uint32_t spin = 0; spin < fk.plan_spins; ++spin) {
-          const uint64_t w = r0 + l < nw ? poll_u64(fk.plan + kPlanEpochBase + r0 + l) : ((uint64_t)seq << 32);
-          if (__ballot((uint32_t)(w >> 32) != seq) == 0ull) {
-            if (r0 + l < nw) s_ep[r0 + l] = (uint32_t)w;
-            got = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        all_there = got;
-      }
-      // (a word of its own: the other waves may still be reading s_plan[kPlanWords] above -- no barrier lies between their
-      //  read and this write; found by the executor's happens-before checker, tests/emu/race.cpp)
-      if (l == 0) s_plan[kPlanWords + 2] = all_there ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_plan[kPlanWords + 2]) return;  // (the table did not arrive in time: k_make_keys does this chunk)
-  }
-  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) s_hist[k] = 0u;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const uint32_t i = base + k * kBlock + threadIdx.x;
-    if (i >= n) break;
-    uint64_t key = kInvalidKey;
-    bool counted = px[FUSED ? k : 0] == px[FUSED ? k : 0];  // finite (NaN marks the others)
-    double pmn[3] = {emn[0], emn[1], emn[2]};   // (copies, not pointers: the arrays stay in registers)
-    uint32_t pshift[3] = {0u, 0u, 0u};
-    if (early && counted) {  // the epoch the point belongs to (points in front of the first epoch are the non-finite ones)
-      int e = ne - 1;
-      while (e > 0 && (int)s_ep[e * kPlanEpochWords] > (int)i) --e;
-      const uint32_t* q = s_ep + e * kPlanEpochWords;
-      counted = (int)i >= (int)s_ep[0];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        pmn[a] = __longlong_as_double((long long)(((uint64_t)q[2 + 2 * a] << 32) | q[1 + 2 * a]));
-        pshift[a] = q[7 + a];
-      }
-    }
-    if (counted) {
-      bool ok = true;
-      uint32_t hi_unused;
-      const uint64_t code = point_code(g, pmn, pshift, ranks, res, fk.inv_res_pow2, px[FUSED ? k : 0], py[FUSED ? k : 0], pz[FUSED ? k : 0], ok, hi_unused);
-      if (!ok) s_plan[kPlanWords + 1] = 1u;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
-#pragma unroll
-      for (int q = 0; q < kMaxPasses; ++q)
-        if (q < g.np) atomicAdd(&s_hist[q * kMaxBins + code_digit(g, q, code, 0u)], 1u);
-      const uint64_t low = g.colour_in_key ? (uint64_t)(pc[FUSED ? k : 0] & 0xffffffu) : (g.ibits ? (uint64_t)i : 0ull);
-      key = g.packed_mode ? ((code << g.ibits) | low) : code;
-    }
-    if (g.payload == 1) fk.idx[i] = i;
-    else if (g.payload == 2) fk.idx[i] = pc[FUSED ? k : 0];
-    fk.keys[i] = key;
-  }
-  __syncthreads();
-  uint16_t* row = fk.hist_rows + (size_t)c * kMaxPasses * kMaxBins;
-  for (int k = threadIdx.x; k < g.np * kMaxBins; k += kBlock) row[k] = (uint16_t)s_hist[k];
-  if (threadIdx.x == 0) publish_u64(fk.plan + kPlanGranules + c, ((uint64_t)seq << 32) | (s_plan[kPlanWords + 1] ? 2u : 1u));
 }
 
+// what the host tells the plan (workgroup 0): which sort it enqueued and what the stages behind the sort will read
+struct PlanOptions {
+  int force_pairs;      // testing: (key, index) pairs even where the packed key would fit
+  int need_index;       // somebody reads the point index of the sorted elements (centroids, macroblock trees)
+  int no_cell_ranks;    // testing: sort the full varying Morton code
+  int do_color;         // the frame has colours (they ride in the key or in the payload)
+  int passes_launched;  // sort passes enqueued: a frame that needs more comes back with kErrPasses
+  int deep_launched;    // the DEEP instantiations are enqueued: a deep frame that meets the others comes back with kErrDeep
+};
+
 __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t n, uint32_t n_chunks, uint64_t* boxes, uint32_t seq,
-                                                         uint4* __restrict__ sync_area, uint32_t sync_vec16, double res,
-                                                         int force_pairs, int need_index, int no_cell_ranks, int passes_launched, int deep_launched, int bare_launched, int local_launched, int do_color, FixedBox box,
-                                                         FrameState* __restrict__ st, FusedKeys fk, unsigned long long* span) {
+                                                         uint4* __restrict__ sync_area, uint32_t sync_vec16, double res, PlanOptions opt, FixedBox box,
+                                                         FrameState* __restrict__ st, unsigned long long* span) {
   const KSpan kspan(span);
-  __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction (fused mode: plan, digit counts)
+  __shared__ float s_p[3][kTile];  // workgroup 0: the chunk being replayed; the others: a few words for their reduction
   __shared__ int s_redi[2][kBlock / 64];
   if (blockIdx.x != 0) {
-    if (fk.plan) chunk_box_block<true>(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0], res, fk);
-    else chunk_box_block<false>(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0], res, fk);
+    chunk_box_block(pv, n, blockIdx.x - 1u, n_chunks, boxes, seq, sync_area, sync_vec16, &s_p[0][0], &s_redi[0][0]);
     return;
   }
+  const int force_pairs = opt.force_pairs, need_index = opt.need_index, no_cell_ranks = opt.no_cell_ranks, do_color = opt.do_color;
+  const int passes_launched = opt.passes_launched, deep_launched = opt.deep_launched;
   __shared__ int ev_index[kMaxEpochs], ev_lowered[kMaxEpochs], ev_depth_before[kMaxEpochs];
   __shared__ double ev_mn[kMaxEpochs][3];
   __shared__ float s_g[6][kBlock / 64];
@@ -818,12 +665,10 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       if (threadIdx.x == 0) {
         st->n_epochs = 0; st->depth = 0; st->n_finite = 0; st->first_finite = -1;
         st->n_leaves = 0; st->n_branches = 0; st->npasses = 0; st->error = kErrNone;
-        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0; st->deep = 0; st->payload2 = 0; st->local_bits = 0; st->keys_final = 0;
+        st->vbits = 0; st->vbits_axis = 0; st->ibits = 0; st->n_growth_events = 0; st->packed = 1; st->payload = 0; st->colour_in_key = 0; st->deep = 0; st->payload2 = 0; st->keys_final = 0;
         st->code_low_bits = 0; st->code_bits = 0;
         st->passes_launched = passes_launched;
       }
-      // fused mode: nobody makes keys for this frame (the streaming workgroups need not wait for their time-out to learn it)
-      if (fk.plan && threadIdx.x < kPlanWords) publish_u64(fk.plan + threadIdx.x, (uint64_t)seq << 32);
       return;
     }
     float fx, fy, fz;  // chunk 0 held no finite point: the first one of the cloud comes from the chunk boxes
@@ -878,17 +723,6 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (last_of_run) {
       st->ep_index[w] = ev_index[k];
       for (int a = 0; a < 3; ++a) { st->ep_mn[w][a] = ev_mn[k][a]; st->ep_shift[w][a] = later[a]; }
-      if (fk.plan) {  // fused mode: the same row for the streaming workgroups whose chunk holds points of earlier epochs
-        uint64_t* q = fk.plan + kPlanEpochBase + w * kPlanEpochWords;
-        const uint64_t tag = (uint64_t)seq << 32;
-        publish_u64(q, tag | (uint32_t)ev_index[k]);
-        for (int a = 0; a < 3; ++a) {
-          const uint64_t bits = (uint64_t)__double_as_longlong(ev_mn[k][a]);
-          publish_u64(q + 1 + 2 * a, tag | (uint32_t)bits);
-          publish_u64(q + 2 + 2 * a, tag | (uint32_t)(bits >> 32));
-          publish_u64(q + 7 + a, tag | later[a]);
-        }
-      }
     }
     if (k == 0) {
       st->n_epochs = ne;
@@ -903,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     }
   } else if (wave_id() == 1) {
     if (depth > kMaxDepthDeep && err == kErrNone) err = kErrDepth;
-    // two-word codes (pcc_device.h): no cell ranks, no fused keys, pairs of payloads.  Which instantiations of the kernels
+    // two-word codes (pcc_device.h): no cell ranks, pairs of payloads.  Which instantiations of the kernels
     // behind this one were enqueued is the host's decision (it cannot know the depth): a frame in the deep sequence is
     // treated as deep whatever its depth, a deep frame in the single-word sequence is sent back (kErrDeep)
     const bool deep = deep_launched != 0;
@@ -941,7 +775,6 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       if (passes_for(bits) < passes_for(cbits)) { cm = m; cbits = bits; for (int a = 0; a < 3; ++a) cdim[a] = d[a]; }
     }
     if (no_cell_ranks || deep) { cm = vb; cbits = 3 * vb; cdim[0] = cdim[1] = cdim[2] = 1u; }
-    uint8_t st_rank_of_lane = 0;  // rank of cell `lane` (also goes into the fused mode's plan below)
     {
       const unsigned nc = cdim[0] * cdim[1] * cdim[2];
       const int i = lane_id();
@@ -956,7 +789,6 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
         const uint64_t other = lane_of(mort, (int)j);
         rank += (other < mort) ? 1u : 0u;
       }
-      st_rank_of_lane = (uint8_t)rank;
       if ((unsigned)i < nc && nc > 1u) { st->cell_rank[i] = (uint8_t)rank; st->cell_abs[rank] = mort; }
       if (i < 3) { st->cell_base[i] = kmin[i] >> cm; st->cell_dim[i] = cdim[i]; }
       if (i == 0) { st->code_low_bits = cm; st->code_bits = cbits; }
@@ -973,21 +805,13 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     if (!packed) ibits = 0;
     // digit plan: as few passes as 9-bit digits allow, the code bits spread evenly over them.  Deep trees: the low word's
     // bits first, then the high word's (a digit never straddles the two; a shift of 63 or more means "of the high word")
-    // Experiment (PCC_SORT_LOCAL, the host enqueued the LOCAL leaf scan): when leaving the lowest 3, 6 or 9 code bits to a
-    // local fix-up saves a global pass, the passes only sort the bits above them -- keys with equal higher bits (one cube of
-    // 2, 4 or 8 voxels a side) end up next to each other and k_leaf_scan sorts each such group in LDS
-    int local_bits = 0;
-    if (local_launched && bare && !deep)
-      for (int lb = 3; lb <= 9 && lb <= 3 * cm && !local_bits; lb += 3)
-        if (cbits - lb >= 1 && passes_for(cbits - lb) < passes_for(cbits)) local_bits = lb;
-    const int vbits = cbits - local_bits;  // what the passes sort
+    const int vbits = cbits;  // what the passes sort
     const int lo_bits = vbits < 63 ? vbits : 63, hi_bits = vbits - lo_bits;
     int np_lo = (lo_bits + kMaxDigitBits - 1) / kMaxDigitBits;
     if (np_lo < 1) np_lo = 1;
     const int np_hi = (hi_bits + kMaxDigitBits - 1) / kMaxDigitBits;
     const int np = np_lo + np_hi;
     if (err == kErrNone && np > passes_launched) err = kErrPasses;  // the host re-launches with more passes
-    if (err == kErrNone && bare_launched && !bare) err = kErrPayload;  // ... with the sort passes that move a payload
     // digit q of `n` digits over `bits` bits: width, and offset of its first bit
     auto digit = [](int q, int n, int bits, int& width, int& offset) {
       width = 0; offset = 0;
@@ -1000,9 +824,9 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
     const int p = lane_id();
     if (p < kMaxPasses) {
       int bits = 0, sh = 0;
-      if (p < np_lo) { digit(p, np_lo, lo_bits, bits, sh); sh += local_bits; }
+      if (p < np_lo) digit(p, np_lo, lo_bits, bits, sh);
       else if (p < np) { digit(p - np_lo, np_hi, hi_bits, bits, sh); sh += 63; }
-      else { bits = 0; sh = vbits + local_bits; }
+      else { bits = 0; sh = vbits; }
       st->pass_bits[p] = bits;
       st->pass_shift[p] = sh;
     }
@@ -1016,54 +840,9 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
       st->colour_in_key = (bare && do_color) ? 1 : 0;
       st->deep = deep ? 1 : 0;
       st->payload2 = !deep ? 0 : (need_index ? 1 : (do_color ? 2 : 0));
-      st->local_bits = local_bits;
-      st->keys_final = np & 1;  // (with local_bits the keys in that buffer are sorted by their higher bits only: k_leaf_tile reads none of them)
+      st->keys_final = np & 1;
       st->npasses = err != kErrNone ? 0 : np;
       st->error = err;
-    }
-    // fused mode: the same plan for the streaming workgroups, who are waiting for it with their points in registers
-    // (one granule per lane; every value is uniform over the wave, or this lane's own: pass p, the cell ranks)
-    if (fk.plan) {
-      __shared__ uint8_t s_rank8[64];
-      {
-        const unsigned nc = cdim[0] * cdim[1] * cdim[2];
-        s_rank8[p] = ((unsigned)p < nc && nc > 1u) ? st_rank_of_lane : (uint8_t)0;
-      }
-      PCC_WAVE_SYNC_LDS();
-#define PCC_PICK3(arr, k) ((k) == 0 ? (arr)[0] : ((k) == 1 ? (arr)[1] : (arr)[2]))  /* (no indexed register arrays) */
-      uint32_t v = 0u;
-      if (p < 6) {
-        const uint64_t bits = (uint64_t)__double_as_longlong(PCC_PICK3(mn, p >> 1));
-        v = (p & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits;
-      } else if (p == kPlanBits) {
-        v = (uint32_t)vb | ((uint32_t)cm << 8) | ((uint32_t)np << 16) | ((uint32_t)ibits << 24);
-      } else if (p == kPlanFlags) {
-        const uint32_t payload = bare ? 0u : (packed ? (do_color ? 2u : 0u) : 1u);
-        v = ((err == kErrNone && !deep) ? 1u : 0u) | ((uint32_t)packed << 1) | (payload << 2) | (((bare && do_color) ? 1u : 0u) << 4);
-      } else if (p >= kPlanPrefix && p < kPlanPrefix + 3) {
-        v = vb >= 32 ? 0u : ((PCC_PICK3(kmin, p - kPlanPrefix) >> vb) << vb);
-      } else if (p >= kPlanCellBase && p < kPlanCellBase + 3) {
-        v = PCC_PICK3(kmin, p - kPlanCellBase) >> cm;
-      } else if (p >= kPlanCellDim && p < kPlanCellDim + 3) {
-        v = PCC_PICK3(cdim, p - kPlanCellDim);
-      } else if (p == kPlanLastEpoch) {
-        v = (uint32_t)ev_index[nev - 1];
-      } else if (p == kPlanEpochs) {  // runs of growth events at one point count once (the last of a run stands for the epoch)
-        int runs = 0;
-        for (int k2 = 0; k2 < nev; ++k2) runs += !(k2 + 1 < nev && ev_index[k2 + 1] == ev_index[k2]);
-        v = (uint32_t)runs;
-      } else if (p >= kPlanPass && p < kPlanPass + kMaxPasses) {
-        const int q = p - kPlanPass;  // (the plan is only used for single-word codes: np = np_lo)
-        int bq = 0, sh = 0;
-        digit(q, np_lo, lo_bits, bq, sh);
-        sh += local_bits;
-        if (q >= np_lo) bq = 0;
-        v = (uint32_t)bq | ((uint32_t)sh << 8);
-      } else if (p >= kPlanRanks && p < kPlanRanks + 16) {
-        v = reinterpret_cast<const uint32_t*>(s_rank8)[p - kPlanRanks];
-      }
-      if (p < kPlanWords) publish_u64(fk.plan + p, ((uint64_t)seq << 32) | v);
-#undef PCC_PICK3
     }
   }
   PCC_KTR(6, 6);
@@ -1078,23 +857,22 @@ __global__ __launch_bounds__(kBlock) void k_boxes_events(PointView pv, uint32_t 
 // (1024 threads x 4 points; 512 x 8 was tried for the sake of frames in flight -- a smaller workgroup finds room on a
 // busy CU sooner, which took k_digit_totals from 22 to 14 us under load -- but here it lost both ways: 15.4 -> 18.9 us
 // alone, 38.6 -> 41.9 us under load)
-// <1024, 4>: one row of digit counts per 4096-key sort tile (the kernel makes every key of the frame);
-// <256, 8>: one row per 2048-point chunk, and the kernel only visits the chunks the streaming workgroups of
-// k_boxes_events left alone (fused mode: `chunk_state` = the per-chunk granules behind the plan) -- nearly all of its
-// workgroups return at once, so they are small ones (four waves to dispatch instead of sixteen)
 template <int kKeyThreads, int KEY_ITEMS>
 __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_t n, double res, double inv_res_pow2,
                                                             FrameState* __restrict__ st, uint64_t* __restrict__ keys,
                                                             uint32_t* __restrict__ idx, uint32_t* __restrict__ idx2, uint16_t* __restrict__ hist_rows,
-                                                            const uint64_t* __restrict__ chunk_state, uint32_t seq, unsigned long long* span) {
+                                                            unsigned long long* span) {
   const KSpan kspan(span);
   constexpr int kKeyTile = kKeyThreads * KEY_ITEMS;
+  static_assert(kKeyTile == kSortTile, "one row of digit counts per sort tile");
   __shared__ uint32_t s_h[kMaxPasses][kMaxBins];
   const int ne = st->n_epochs;
-  if (ne == 0 || st->error != kErrNone) return;
-  // one workgroup per tile, or (fused mode: nearly every chunk has its keys already) a few workgroups that look at all
-  // chunks' granules in turn and make the keys of those that were left alone
-  const uint32_t n_tiles_all = (n + (uint32_t)kKeyTile - 1u) / (uint32_t)kKeyTile;
+  // No plan (the frame holds no finite point, or k_boxes_events refused it: npasses is 0 then): nothing to do.  The error
+  // word itself is NOT looked at here: workgroups of this very launch store into it (kErrPrefix, below), and lanes that read
+  // it before and after such a store would disagree about leaving -- part of a workgroup at the barriers below, counting
+  // digits in LDS nobody zeroed (found by the happens-before checker of tests/emu as reads of uninitialised LDS).
+  if (ne == 0 || st->npasses == 0) return;
+  const uint32_t tile = blockIdx.x;  // one workgroup per sort tile
   KeyGeom g;
   g.np = st->npasses;
   g.vb = st->vbits_axis; g.ibits = st->ibits;
@@ -1111,17 +889,6 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   const int ep0 = st->ep_index[0], ep_last = st->ep_index[ne - 1];
 #pragma unroll
   for (int p = 0; p < kMaxPasses; ++p) { g.pshift[p] = st->pass_shift[p]; g.pmask[p] = (1u << st->pass_bits[p]) - 1u; }
-  // (the one-workgroup-per-tile form takes exactly one turn: the compiler is told so, and keeps that form's registers)
-  constexpr bool kLooping = kKeyThreads == kBlock;
-  for (uint32_t tile = blockIdx.x; tile < n_tiles_all; tile = kLooping ? tile + gridDim.x : n_tiles_all) {
-  if (chunk_state) {
-    const uint64_t w = chunk_state[tile];
-    if ((uint32_t)(w >> 32) == seq && (uint32_t)w != 0u) {  // keys and digit counts of this chunk are there already
-      if ((uint32_t)w == 2u && threadIdx.x == 0) st->error = kErrPrefix;
-      continue;
-    }
-  }
-  if (kLooping) __syncthreads();  // (nobody is still reading the digit counts of the tile before)
   for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) (&s_h[0][0])[k] = 0u;
   __syncthreads();
   const uint32_t base = tile * kKeyTile;
@@ -1141,7 +908,7 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
       }
       bool ok = true;
       const uint64_t code = point_code(g, st->ep_mn[e], st->ep_shift[e], st->cell_rank, res, inv_res_pow2, x, y, z, ok, hi);
-      if (!ok) st->error = kErrPrefix;  // the +-1 voxel slack was not enough: refuse rather than mis-sort
+      if (!ok) raise_error(st, kErrPrefix);  // the +-1 voxel slack was not enough: refuse rather than mis-sort
 #pragma unroll
       for (int p = 0; p < kMaxPasses; ++p)
         if (p < g.np) atomicAdd(&s_h[p][code_digit(g, p, code, hi)], 1u);
@@ -1159,7 +926,6 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
   __syncthreads();
   uint16_t* row = hist_rows + (size_t)tile * kMaxPasses * kMaxBins;  // (a tile has at most 4096 keys: a count fits 16 bits)
   for (int k = threadIdx.x; k < g.np * kMaxBins; k += kKeyThreads) row[k] = (uint16_t)(&s_h[0][0])[k];
-  }
 }
 
 // column sums of hist_rows: digit_tot[pass][digit] = number of keys with that digit in that pass.
@@ -1173,7 +939,7 @@ __global__ __launch_bounds__(kKeyThreads) void k_make_keys(PointView pv, uint32_
 // (for frames of many tiles the wide shape stays: a thread of the narrow one would walk rows / 16 of them)
 constexpr uint32_t kDtCols = 16;
 template <uint32_t kDtThreads>
-__global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows, uint32_t rows_per_tile,
+__global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* __restrict__ st, uint32_t n_rows,
                                                        const uint16_t* __restrict__ hist_rows,
                                                        uint32_t* __restrict__ digit_tot, uint32_t* __restrict__ tile_prefix0, unsigned long long* span) {
   const KSpan kspan(span);
@@ -1215,14 +981,14 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
   if (pass == 0 && held) {
     uint32_t run = before;
 #pragma unroll
-    for (uint32_t k = 0; k < kHeld; ++k) {  // (rows_per_tile = 2: the rows are 2048-point chunks, a sort tile starts at every other one)
-      if (r0 + k < r1 && (r0 + k) % rows_per_tile == 0u) tile_prefix0[(size_t)((r0 + k) / rows_per_tile) * kMaxBins + col] = run;
+    for (uint32_t k = 0; k < kHeld; ++k) {
+      if (r0 + k < r1) tile_prefix0[(size_t)(r0 + k) * kMaxBins + col] = run;
       run += mine[k];
     }
   } else if (pass == 0) {
     uint32_t run = before;
     for (uint32_t r = r0; r < r1; ++r) {
-      if (r % rows_per_tile == 0u) tile_prefix0[(size_t)(r / rows_per_tile) * kMaxBins + col] = run;
+      tile_prefix0[(size_t)r * kMaxBins + col] = run;
       run += hist_rows[(size_t)r * kMaxPasses * kMaxBins + col];
     }
   }
@@ -1238,20 +1004,17 @@ __global__ __launch_bounds__(kDtThreads) void k_digit_totals(const FrameState* _
 // (second launch bound = waves per SIMD the register allocation has to leave room for: four, i.e. one 1024-thread or
 // two 512-thread workgroups per CU.  Without it the 512-thread shape takes 151 registers -- it is allowed 256 -- and
 // only one workgroup fits a CU, which is the whole point of that shape gone.)
-constexpr uint32_t kXcdTicketBase = 16;                           // tickets[16 + 8 pass + xcd]
-constexpr size_t kTicketBytes = (16 + 8 * kMaxPasses + 8) * sizeof(uint32_t) / 16 * 16 + 16;
+constexpr size_t kTicketBytes = ((kMaxPasses + 1) * sizeof(uint32_t) + 15) / 16 * 16;  // tickets[pass], tickets[kMaxPasses] = the leaf scan's
 // (DEEP: two-word codes -- the u32 payload is the code's high word, whose digits the last passes sort by, and a second
 // payload array carries the point index or the colour word)
-// (PAY = false: no payload path, two thirds of the LDS and a six-waves-per-SIMD register budget, so that THREE 512-thread
-// tiles share a CU -- an experiment behind PCC_SORT_BARE=1 until a GPU has timed it: 80 registers, 64 bytes of scratch per lane)
-template <int THREADS, int ITEMS, bool DEEP = false, bool PAY = true>
-__global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
+template <int THREADS, int ITEMS, bool DEEP = false>
+__global__ __launch_bounds__(THREADS, 4) void k_sort_pass(const uint64_t* buf_a, const uint64_t* buf_b,
                                                             uint64_t* out_a, uint64_t* out_b,
                                                             uint32_t* idx_a, uint32_t* idx_b, uint32_t* idx2_a, uint32_t* idx2_b, uint32_t n, int pass,
                                                             FrameState* st, const uint32_t* __restrict__ digit_tot,
                                                             const uint32_t* __restrict__ tile_prefix0,
                                                             uint32_t* status_all, uint32_t* tickets,
-                                                            uint32_t n_tiles_max, int xcd_chunk, unsigned long long* span) {
+                                                            uint32_t n_tiles_max, unsigned long long* span) {
   const KSpan kspan(span);
   PCC_KT(0);
   if (pass >= st->npasses) return;
@@ -1259,7 +1022,7 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
   static_assert(THREADS * ITEMS == kSortTile && THREADS >= kMaxBins, "a tile is 4096 keys (the histogram rows of k_make_keys); one thread per digit");
   // s_raw is used twice: while ranking, one 64-bit lane mask per (wave, digit); afterwards the tile's
   // keys (and payload) in digit order, so that the global writes are runs
-  constexpr int kTileWords = DEEP ? kSortTile * 2 : (PAY ? kSortTile * 3 / 2 : kSortTile);  // keys + one payload (+ a second one)
+  constexpr int kTileWords = DEEP ? kSortTile * 2 : kSortTile * 3 / 2;  // keys + one payload (+ a second one)
   constexpr int kRawWords = NW * kMaxBins > kTileWords ? NW * kMaxBins : kTileWords;
   __shared__ __attribute__((aligned(16))) uint64_t s_raw[kRawWords];
   uint64_t* s_match = s_raw;
@@ -1284,29 +1047,8 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
   // one that cannot start because of workgroups waiting the other way round.)  Pass 0 waits for nobody -- its
   // tile prefixes come from k_digit_totals -- and keeps blockIdx.  The ticket, 245 workgroups queueing on one
   // word, takes a microsecond or two to come back: the digit totals are fetched meanwhile.
-  // XCD-aware tickets (xcd_chunk = tiles per chunk, 0 = off): consecutive tiles write adjacent runs of every digit, so two
-  // neighbours on the same XCD fill whole lines in ONE L2, while neighbours on different XCDs each write a partial line
-  // (workgroups go to the XCDs round robin: with one counter for everybody, neighbouring tiles never share an XCD).  Every
-  // XCD has a counter of its own and takes the tiles of every eighth chunk of `xcd_chunk` consecutive tiles, in ascending
-  // order; a workgroup whose XCD has no tile left takes one of another XCD's.  Which XCD a workgroup runs on is read from
-  // the hardware and is only a hint: whatever the register says, every tile is taken exactly once, and -- per-XCD
-  // tickets ascend -- the lowest tile not started yet is always somebody's next ticket, so a tile still only ever waits
-  // for tiles that can start.
   uint32_t ticket = blockIdx.x;
-  if (xcd_chunk > 0) {
-    if (threadIdx.x == 0) {
-      const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID
-      ticket = ~0u;
-      for (uint32_t k = 0; k < 8u; ++k) {
-        const uint32_t y = (x + k) & 7u;
-        const uint32_t t = atomicAdd(&tickets[kXcdTicketBase + (uint32_t)pass * 8u + y], 1u);
-        const uint32_t cand = ((t / (uint32_t)xcd_chunk) * 8u + y) * (uint32_t)xcd_chunk + t % (uint32_t)xcd_chunk;
-        if (cand < n_tiles) { ticket = cand; break; }
-      }
-    }
-  } else if (pass != 0 && threadIdx.x == 0) {
-    ticket = atomicAdd(&tickets[pass], 1u);
-  }
+  if (pass != 0 && threadIdx.x == 0) ticket = atomicAdd(&tickets[pass], 1u);
   const uint32_t dtot = d_me < nbins ? digit_tot[(size_t)pass * kMaxBins + d_me] : 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins / 2; k += THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[k] = 0u;
   for (int k = threadIdx.x; k < NW * kMaxBins; k += THREADS) s_match[k] = 0ull;
@@ -1318,7 +1060,7 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
   PCC_KT(1);
   if (tile >= n_tiles) return;
 
-  const bool with_payload = PAY && st->payload != 0;
+  const bool with_payload = st->payload != 0;
   const bool with_payload2 = DEEP && st->payload2 != 0;
   const int shift = st->ibits + st->pass_shift[pass];
   // the digit of a key: of the key word or, in the last passes over a two-word code, of the payload (the high word)
@@ -1422,12 +1164,12 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
     if (threadIdx.x < q) {
       while ((poll_u32(status + (size_t)(g * kLookBackGroup + threadIdx.x) * kMaxBins) >> 30) == 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+        if (++spins > kSpinLimit) { raise_error(st, kErrSpin); break; }
       }
     } else if (also_wait_for_previous_group && g > 0 && threadIdx.x == 64) {
       while ((poll_u32(gstatus + (size_t)(g - 1) * kMaxBins) >> 30) == 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+        if (++spins > kSpinLimit) { raise_error(st, kErrSpin); break; }
       }
     }
     __syncthreads();
@@ -1446,7 +1188,7 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
       }
       if (all) { partial = sum; break; }
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+      if (++spins > kSpinLimit) { raise_error(st, kErrSpin); break; }
     }
   };
   // The last tile of a group publishes the group's count before it looks back itself: the two hops of the
@@ -1471,7 +1213,7 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
       if (g > 0 && threadIdx.x == 64) {
         while ((poll_u32(gstatus + (size_t)(g - 1) * kMaxBins) >> 30) == 0) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+          if (++spins > kSpinLimit) { raise_error(st, kErrSpin); break; }
         }
       }
       __syncthreads();
@@ -1505,7 +1247,7 @@ __global__ __launch_bounds__(THREADS, PAY ? 4 : 6) void k_sort_pass(const uint64
         j -= used;
         if (used == 0) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > kSpinLimit) { st->error = kErrSpin; break; }
+          if (++spins > kSpinLimit) { raise_error(st, kErrSpin); break; }
         }
 #pragma unroll
         for (int k = 0; k < kLookBackGroup; ++k)
@@ -1601,9 +1343,8 @@ __device__ __forceinline__ uint64_t scan_unpack(uint64_t w) { return (((w >> 30)
 
 // (two workgroup shapes, like k_sort_pass: 1024 threads x 4 keys for small grids, 512 x 8 -- two workgroups per CU, one
 // looks back while the other scans -- for the rest)
-constexpr uint32_t kLocalGroupMax = 192;  // longest group of equal higher code bits the local fix-up takes on
-template <int THREADS, int ITEMS, bool DEEP = false, bool LOCAL = false>
-__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a, const uint64_t* buf_b, uint32_t* colour_out,
+template <int THREADS, int ITEMS, bool DEEP = false>
+__global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a, const uint64_t* buf_b,
                                                             const uint32_t* __restrict__ idx_a, const uint32_t* __restrict__ idx_b,
                                                             FrameState* st, uint64_t* leaf_status, uint32_t* ticket,
                                                             uint32_t* __restrict__ leaf_start, uint64_t* __restrict__ leaf_code, uint32_t* __restrict__ leaf_hi,
@@ -1616,135 +1357,20 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
   constexpr uint64_t kFlagAgg = 1ull << 62, kFlagIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
   __shared__ uint64_t s_w[NW];
   __shared__ uint64_t s_prefix;
-  __shared__ uint32_t s_tile;
-  const uint32_t nfin = (st->error == kErrNone) ? st->n_finite : 0u;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tile id = ticket: see k_sort_pass
+  __shared__ uint32_t s_tile, s_nfin;
+  // The error word is read ONCE per workgroup: tiles of this very launch store kErrSpin into it (look-back below), and lanes
+  // that read it before and after such a store would disagree about leaving -- part of a workgroup at the barriers below.
+  if (threadIdx.x == 0) {
+    s_tile = atomicAdd(ticket, 1u);  // tile id = ticket: see k_sort_pass
+    s_nfin = (poll_error(st) == kErrNone) ? st->n_finite : 0u;
+  }
   __syncthreads();
-  const uint32_t tile = s_tile;
+  const uint32_t tile = s_tile, nfin = s_nfin;
   if ((uint64_t)tile * kSortTile >= nfin) return;
   const uint64_t* keys = (st->npasses & 1) ? buf_b : buf_a;
   const uint32_t* highs = (st->npasses & 1) ? idx_b : idx_a;  // DEEP: the codes' high words (the sort's payload)
   const int ibits = st->ibits, depth = st->depth;
   const int lane = lane_id(), wave = wave_id();
-  // ---- LOCAL (experiment): the passes sorted the code bits above `local_bits` only.  Keys with equal higher bits form a
-  // group of consecutive positions; sorting every group by its low bits (ties by position) sorts the array, and moves no
-  // key out of its group's positions.  A tile takes the complete groups that touch its positions [W0 - 1, W1) into LDS (the
-  // key before the tile is needed for the first head flag), ranks every key inside its group -- a cube of 4 x 4 x 4 voxels
-  // holds a few dozen points of a surface --, and writes ITS positions of the neighbouring tiles sort a shared boundary group each for itself, to the same order.
-  const int lbits = LOCAL ? st->local_bits : 0;
-  __shared__ uint64_t s_in[LOCAL ? kSortTile + 2 * kLocalGroupMax + 2 : 1], s_srt[LOCAL ? kSortTile + 2 * kLocalGroupMax + 2 : 1];
-  __shared__ uint32_t s_halo[2];
-  uint32_t win0 = 0;  // global position of s_srt[0]
-  if (LOCAL && lbits > 0) {
-    const uint32_t W0 = tile * kSortTile, W1 = min(W0 + (uint32_t)kSortTile, nfin);
-    const int gshift = ibits + lbits;
-    if (wave == 0) {  // how far the group of position W0 - 1 reaches back, how far the group of position W1 - 1 reaches on
-      uint32_t hb = 0, ha = 0;
-      if (W0 > 0) {
-        const uint64_t g0 = keys[W0 - 1] >> gshift;
-        hb = 1;
-        for (uint32_t r0 = 1; r0 <= kLocalGroupMax; r0 += 64) {  // positions W0 - 1 - (r0 + lane)
-          const uint32_t back = r0 + (uint32_t)lane;
-          const bool same = back < W0 && (keys[W0 - 1 - back] >> gshift) == g0;
-          const uint64_t diff = __ballot(!same);
-          if (diff) { hb += (uint32_t)__ffsll((long long)diff) - 1u; break; }
-          hb += 64u;
-        }
-      }
-      {
-        const uint64_t g1 = keys[W1 - 1] >> gshift;
-        for (uint32_t r0 = 0; r0 <= kLocalGroupMax; r0 += 64) {  // positions W1 + r0 + lane
-          const uint32_t at = W1 + r0 + (uint32_t)lane;
-          const bool same = at < nfin && (keys[at] >> gshift) == g1;
-          const uint64_t diff = __ballot(!same);
-          if (diff) { ha += (uint32_t)__ffsll((long long)diff) - 1u; break; }
-          ha += 64u;
-        }
-      }
-      if (lane == 0) { s_halo[0] = hb; s_halo[1] = ha; }
-    }
-    __syncthreads();
-    const uint32_t hb = s_halo[0], ha = s_halo[1];
-    // (a tile that gives up still tells the tiles behind it not to wait for its sums: the frame is run again anyway)
-    constexpr uint64_t kGiveUp = 2ull << 62;
-    if (hb > kLocalGroupMax || ha > kLocalGroupMax) {  // (uniform) a group too long for this: the frame runs again without
-      if (threadIdx.x == 0) { st->error = kErrLocal; publish_u64(leaf_status + tile, kGiveUp); }
-      return;
-    }
-    win0 = W0 - hb;
-    const uint32_t wn = W1 + ha - win0;
-    for (uint32_t j = threadIdx.x; j < wn; j += THREADS) s_in[j] = keys[win0 + j];
-    __syncthreads();
-    const uint64_t lmask = ((1ull << lbits) - 1ull) << ibits;
-    // Every thread takes kPer consecutive window positions.  The ends of a key's group are the nearest group boundaries to
-    // its left and right: a running maximum of "a group starts here" positions from the left and a running minimum from the
-    // right, carried across the threads by two block-wide scans -- so that the ranking loop below knows its bounds up front
-    // and its LDS reads do not hang on each other (a walk that looks at a key to decide whether to go on is a chain of
-    // LDS latencies).
-    constexpr uint32_t kPer = (kSortTile + 2 * kLocalGroupMax + 2 + THREADS - 1) / THREADS;
-    __shared__ uint32_t s_bnd[2][NW];
-    const uint32_t p0 = threadIdx.x * kPer;
-    uint64_t mine[kPer];
-    uint32_t gfirst[kPer], glast[kPer];
-    uint32_t run_first = 0u, run_last = 0xffffffffu;  // last group start at or before / first group end at or behind, inside this thread's span
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-      const uint32_t j = p0 + k;
-      mine[k] = j < wn ? s_in[j] : ~0ull;
-      const bool starts = j < wn && (j == 0 || (s_in[j - 1] >> gshift) != (mine[k] >> gshift));
-      if (starts) run_first = j + 1u;  // (+ 1: 0 = none in this span)
-      gfirst[k] = run_first;
-    }
-#pragma unroll
-    for (int k = (int)kPer - 1; k >= 0; --k) {
-      const uint32_t j = p0 + (uint32_t)k;
-      const bool ends = j < wn && (j + 1 == wn || (s_in[j + 1] >> gshift) != (mine[k] >> gshift));
-      if (ends) run_last = j;
-      glast[k] = run_last;
-    }
-    // carry in: the latest group start of the threads before, the earliest group end of the threads behind
-    const uint32_t incl_first = wave_scan_u32(run_first, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
-    // (a scan from the right = a scan from the left over the mirrored lanes)
-    const uint32_t mirrored = (uint32_t)__shfl((int)run_last, 63 - lane);
-    const uint32_t incl_last_m = wave_scan_u32(mirrored, 0xffffffffu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
-    const uint32_t incl_last = (uint32_t)__shfl((int)incl_last_m, 63 - lane);
-    if (lane == 63) s_bnd[0][wave] = incl_first;
-    if (lane == 0) s_bnd[1][wave] = incl_last;
-    __syncthreads();
-    uint32_t before_first = 0u, behind_last = 0xffffffffu;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      if (w < wave) before_first = max(before_first, s_bnd[0][w]);
-      if (w > wave) behind_last = min(behind_last, s_bnd[1][w]);
-    }
-    const uint32_t lane_before = max(before_first, wave_shr1_u32(incl_first, 0u) * (lane ? 1u : 0u));
-    uint32_t lane_behind = (uint32_t)__shfl((int)incl_last, lane + 1 < 64 ? lane + 1 : 63);
-    lane_behind = min(behind_last, lane == 63 ? 0xffffffffu : lane_behind);
-    bool too_long = false;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-      const uint32_t j = p0 + k;
-      if (j >= wn) continue;
-      const uint32_t first = (gfirst[k] ? gfirst[k] : lane_before) - 1u;  // (a window starts at a group start: never "none")
-      const uint32_t last = glast[k] != 0xffffffffu ? glast[k] : lane_behind;
-      const uint64_t low = mine[k] & lmask;
-      if (last - first >= 2u * kLocalGroupMax) { too_long = true; continue; }
-      uint32_t less = 0;
-      for (uint32_t q = first; q <= last; ++q) {
-        const uint64_t o = s_in[q] & lmask;
-        less += (o < low || (o == low && q < j)) ? 1u : 0u;
-      }
-      s_srt[first + less] = mine[k];
-    }
-    if (__syncthreads_or(too_long ? 1 : 0)) {
-      if (threadIdx.x == 0) { st->error = kErrLocal; publish_u64(leaf_status + tile, kGiveUp); }
-      return;
-    }
-    // What k_leaf_tile reads of the sorted keys in this mode (bare keys: nobody needs a point index) is each point's colour:
-    // the low 24 key bits go out as 4-byte words (the sort's unused payload array); a geometry-only frame writes nothing.
-    if (st->colour_in_key)
-      for (uint32_t i = W0 + threadIdx.x; i < W1; i += THREADS) colour_out[i] = (uint32_t)s_srt[i - win0] & 0xffffffu;
-  }
   // sorted codes whose high part is a cell rank (FrameState::code_low_bits) become Morton codes again here: nothing
   // downstream of this kernel sees a rank
   __shared__ uint64_t s_cell_abs[64];
@@ -1764,7 +1390,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
   auto code_at = [&](uint32_t i) {  // the code of sorted element i
     CodeT c;
     if (DEEP) code_make(c, keys[i], highs[i]);  // (no index bits, no cell ranks in a deep frame's keys)
-    else if (LOCAL && lbits > 0) code_make(c, unrank(s_srt[i - win0] >> ibits), 0u);  // the fixed-up keys, from LDS
     else code_make(c, unrank(keys[i] >> ibits), 0u);
     return c;
   };
@@ -1817,7 +1442,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_leaf_scan(const uint64_t* buf_a,
         j -= take;
         if (take == 0) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > kSpinLimit) { if (lane == 0) st->error = kErrSpin; break; }
+          if (++spins > kSpinLimit) { if (lane == 0) raise_error(st, kErrSpin); break; }
         }
       }
       if (lane == 0) publish_u64(leaf_status + tile, kFlagIncl | ((before + mine) & kVal));
@@ -2032,7 +1657,7 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   uint64_t* s_mask = reinterpret_cast<uint64_t*>(s_scratch + kFinTile + kOccWindow);
   uint8_t* s_t = reinterpret_cast<uint8_t*>(s_mask + kFinSlots * kMaskStride);
 
-  const uint64_t* keys = st->keys_final ? buf_b : buf_a;  // (= the last pass's output, or k_leaf_scan's when it fixed the low bits up)
+  const uint64_t* keys = st->keys_final ? buf_b : buf_a;  // (= the last pass's output)
   const int ibits = st->ibits, D = st->depth;
   const int lane = lane_id(), wave = wave_id();
   IndexOf index_of;
@@ -2041,9 +1666,8 @@ __global__ __launch_bounds__(kFinThreads, 6) void k_leaf_tile(PointView pv, doub
   const uint32_t* pay2_sorted = (st->npasses & 1) ? idx2_b : idx2_a;
   index_of.idx = st->payload == 1 ? pay_sorted : ((DEEP && st->payload2 == 1) ? pay2_sorted : nullptr);
   index_of.imask = (ibits >= 64) ? ~0ull : ((1ull << ibits) - 1ull);
-  const bool local_colours = !DEEP && st->local_bits > 0 && st->colour_in_key;  // (k_leaf_scan<LOCAL> wrote the sorted colour words to idx_a)
-  const uint32_t* colour_pay = local_colours ? idx_a : (st->payload == 2 ? pay_sorted : ((DEEP && st->payload2 == 2) ? pay2_sorted : nullptr));
-  const uint64_t* colour_keys = (st->colour_in_key && !local_colours) ? keys : nullptr;
+  const uint32_t* colour_pay = st->payload == 2 ? pay_sorted : ((DEEP && st->payload2 == 2) ? pay2_sorted : nullptr);
+  const uint64_t* colour_keys = st->colour_in_key ? keys : nullptr;
   auto leaf_code_at = [&](uint32_t j) { CodeT c; code_make(c, leaf_code[j], DEEP ? leaf_hi[j] : 0u); return c; };
 
   // ---- A1: leaf records, per-level "opens a node at level >= v" masks, LDS init ----
@@ -2826,50 +2450,11 @@ extern "C" int pcc_debug_read_ktime(unsigned long long* out, size_t count) {
 
 size_t sync_area_bytes(uint32_t n, int passes) {
   const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
-  size_t b = kTicketBytes;                         // tickets: one per pass, the leaf scan's, eight per pass for the XCD-aware form
+  size_t b = kTicketBytes;                         // tickets: one per pass, the leaf scan's
   b += ((tiles * sizeof(uint64_t) + 15) / 16) * 16;  // leaf scan status
   const size_t groups = (tiles + kLookBackGroup - 1) / kLookBackGroup;
   b += (size_t)passes * (tiles + groups) * kMaxBins * sizeof(uint32_t);  // sort status: per tile, per group of tiles
   return b;
-}
-
-// developer aid: what the runtime thinks of the kernels' residency (workgroups per CU, registers, LDS)
-extern "C" int pcc_debug_occupancy(char* text, size_t cap) {
-  std::string out;
-  char line[256];
-  hipDeviceProp_t prop;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-    snprintf(line, sizeof(line), "device: CUs %d, LDS per CU %zu, LDS per block %zu, regs per CU %d, max threads per CU %d\n", prop.multiProcessorCount,
-             (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock, prop.regsPerMultiprocessor, prop.maxThreadsPerMultiProcessor);
-    out += line;
-  }
-  auto one = [&](const char* name, const void* fn, int threads) {
-    int blocks = -1;
-    hipFuncAttributes at{};
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, threads, 0);
-    (void)hipFuncGetAttributes(&at, fn);
-    snprintf(line, sizeof(line), "%-26s threads %4d: %d workgroups per CU  (regs %d, static LDS %zu, max threads %d)\n", name, threads, blocks, at.numRegs,
-             (size_t)at.sharedSizeBytes, at.maxThreadsPerBlock);
-    out += line;
-  };
-  one("k_boxes_events", (const void*)k_boxes_events, kBlock);
-  one("k_make_keys<1024,4>", (const void*)k_make_keys<kSortThreads, kSortItems>, kSortThreads);
-  one("k_make_keys<256,8>", (const void*)k_make_keys<kBlock, kItems>, kBlock);
-  one("k_sort_pass<1024,4>", (const void*)k_sort_pass<kSortThreads, kSortItems, false>, kSortThreads);
-  one("k_sort_pass<512,8>", (const void*)k_sort_pass<512, 8, false>, 512);
-  one("k_sort_pass<512,8,deep>", (const void*)k_sort_pass<512, 8, true>, 512);
-  one("k_sort_pass<512,8,bare>", (const void*)k_sort_pass<512, 8, false, false>, 512);
-  one("k_leaf_scan<1024,4>", (const void*)k_leaf_scan<kSortThreads, kSortItems, false>, kSortThreads);
-  one("k_leaf_scan<512,8>", (const void*)k_leaf_scan<512, 8, false>, 512);
-  one("k_leaf_scan<512,8,local>", (const void*)k_leaf_scan<512, 8, false, true>, 512);
-  one("k_leaf_tile", (const void*)k_leaf_tile<false>, kFinThreads);
-  one("k_leaf_tile<deep>", (const void*)k_leaf_tile<true>, kFinThreads);
-  one("k_jpeg_rows", (const void*)k_jpeg_rows, kJpegThreads);
-  one("k_occ_histogram", (const void*)k_occ_histogram, 256);
-  if (text && cap) { strncpy(text, out.c_str(), cap - 1); text[cap - 1] = 0; }
-  return 0;
 }
 
 // Up to this many tiles the wide workgroup (1024 threads x 4 keys: 16 waves share a tile's latency-bound steps) is used,
@@ -2895,65 +2480,39 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   uint32_t* sort_status = reinterpret_cast<uint32_t*>(sync + kTicketBytes + (((size_t)s_tiles * sizeof(uint64_t) + 15) / 16) * 16);
   const uint32_t sync_vec16 = (uint32_t)(sync_area_bytes(n, passes) / 16);
   PCC_STAMP("begin");
-  // Fused mode (frames of up to kFusedMaxChunks chunks): the streaming workgroups of k_boxes_events hold their points in
-  // registers until workgroup 0 has published the sort plan, then write keys and digit counts themselves -- the cloud is
-  // read once -- and k_make_keys only visits the chunks that were left alone (normally chunk 0, where the box grows).
   const bool deep = a.deep_launch != 0;  // the DEEP instantiations (two-word codes): a frame deeper than 21 levels came by
   static const int forced_shape = [] {  // developer knob: PCC_SORT_SHAPE=narrow|wide
-    const char* e = getenv("PCC_SORT_SHAPE");
+    const char* e = dev_env("PCC_SORT_SHAPE");
     return !e ? 0 : (!strcmp(e, "narrow") ? 1 : (!strcmp(e, "wide") ? 2 : 0));
   }();
   const bool many_tiles = forced_shape ? forced_shape == 1 : s_tiles > kSortSmallGridTiles;
-  // both experiments exist in the narrow (512 x 8) shape only: derived from the shape that is launched, so that what
-  // k_boxes_events is told about the sort is what the kernels after it do
-  const bool local_scan = a.local_launch != 0 && !deep && many_tiles;  // local fix-up of the low code bits (experiment)
-  const bool bare_sort = a.bare_launch != 0 && !deep && many_tiles;    // payload-free sort passes (experiment)
-  const bool fused = a.fused_keys && a.plan && n_tiles <= kFusedMaxChunks && !deep;
-  FusedKeys fk{};
-  if (fused) {
-    fk.plan = a.plan; fk.keys = a.keys_a; fk.idx = a.idx_a; fk.hist_rows = a.hist_rows;
-    fk.inv_res_pow2 = a.inv_res_pow2; fk.plan_spins = a.plan_spins; fk.do_color = (int)a.lp.do_color;
-  }
+  const PlanOptions opt{a.force_pairs, a.need_index, a.no_cell_ranks, (int)a.lp.do_color, passes, deep ? 1 : 0};
   hipLaunchKernelGGL(k_boxes_events, dim3(n_tiles + 1u), dim3(kBlock), 0, stream, a.pv, n, n_tiles, a.boxes, a.frame_seq, reinterpret_cast<uint4*>(sync), sync_vec16,
-                     a.res, a.force_pairs, a.need_index, a.no_cell_ranks, passes, deep ? 1 : 0, bare_sort ? 1 : 0, local_scan ? 1 : 0, (int)a.lp.do_color, a.box, a.state, fk, span("k_boxes_events"));
+                     a.res, opt, a.box, a.state, span("k_boxes_events"));
   PCC_STAMP("k_boxes_events");
-  if (fused)
-    hipLaunchKernelGGL((k_make_keys<kBlock, kItems>), dim3(std::min(n_tiles, 64u)), dim3(kBlock), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
-                       a.plan + kPlanGranules, a.frame_seq, span("k_make_keys"));
-  else
-    hipLaunchKernelGGL((k_make_keys<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
-                       (const uint64_t*)nullptr, 0u, span("k_make_keys"));
+  hipLaunchKernelGGL((k_make_keys<kSortThreads, kSortItems>), dim3(s_tiles), dim3(kSortThreads), 0, stream, a.pv, n, a.res, a.inv_res_pow2, a.state, a.keys_a, a.idx_a, a.idx2_a, a.hist_rows,
+                     span("k_make_keys"));
   PCC_STAMP("k_make_keys");
-  {
-    const uint32_t n_rows = fused ? n_tiles : s_tiles, rows_per_tile = fused ? 2u : 1u;
-    if (n_rows <= 512)
-      hipLaunchKernelGGL(k_digit_totals<256>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(256), 0, stream, a.state, n_rows, rows_per_tile, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
-    else
-      hipLaunchKernelGGL(k_digit_totals<1024>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, n_rows, rows_per_tile, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
-  }
+  if (s_tiles <= 512)
+    hipLaunchKernelGGL(k_digit_totals<256>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(256), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
+  else
+    hipLaunchKernelGGL(k_digit_totals<1024>, dim3((uint32_t)passes * kMaxBins / kDtCols), dim3(1024), 0, stream, a.state, s_tiles, a.hist_rows, a.digit_tot, a.tile_prefix0, span("k_digit_totals"));
   PCC_STAMP("k_digit_totals");
   // Few tiles (every tile has a CU to itself): 16 waves share a tile's latency-bound steps.  Many tiles: 8 waves with
   // twice the keys per thread need 62 KB of LDS instead of 87 KB, so two tiles share a CU and one loads or waits for
   // its predecessors while the other ranks and writes.
-  // One ticket counter for all workgroups of a pass (round 2's form, the one that has run on the chip) is the default:
-  // a tile then only ever waits for tiles that have started.  PCC_SORT_XCD=16: XCD-aware tickets, chunks of 16 tiles (one
-  // look-back group) when every XCD gets at least two chunks' worth of tiles -- off until it has been timed on an MI355X
-  // with other streams' workgroups filling some XCDs (the lowest unstarted tile then waits for a workgroup on ITS XCD)
-  static const int xcd_env = [] { const char* e = getenv("PCC_SORT_XCD"); return e ? atoi(e) : 0; }();
-  const int xcd_chunk = (xcd_env > 0 && s_tiles >= 32u) ? xcd_env : 0;
-#define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, xcd_chunk, span("k_sort_pass")
+  // One ticket counter for all workgroups of a pass: a tile only ever waits for tiles that have started.
+#define PCC_SORT_ARGS a.keys_a, a.keys_b, a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.idx2_a, a.idx2_b, n, pass, a.state, a.digit_tot, a.tile_prefix0, sort_status, tickets, s_tiles, span("k_sort_pass")
   for (int pass = 0; pass < passes; ++pass) {
-    if (many_tiles && bare_sort) hipLaunchKernelGGL((k_sort_pass<512, 8, false, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
-    else if (many_tiles && deep) hipLaunchKernelGGL((k_sort_pass<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
+    if (many_tiles && deep) hipLaunchKernelGGL((k_sort_pass<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
     else if (many_tiles) hipLaunchKernelGGL((k_sort_pass<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SORT_ARGS);
     else if (deep) hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems, true>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SORT_ARGS);
     else hipLaunchKernelGGL((k_sort_pass<kSortThreads, kSortItems, false>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SORT_ARGS);
     PCC_STAMP("k_sort_pass");
   }
 #undef PCC_SORT_ARGS
-#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.idx_a, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
-  if (many_tiles && local_scan) hipLaunchKernelGGL((k_leaf_scan<512, 8, false, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
-  else if (many_tiles && deep) hipLaunchKernelGGL((k_leaf_scan<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
+#define PCC_SCAN_ARGS a.keys_a, a.keys_b, a.idx_a, a.idx_b, a.state, leaf_status, tickets + kMaxPasses, a.leaf_start, a.leaf_code, a.leaf_hi, a.leaf_base, a.leaf_t, a.occ, span("k_leaf_scan")
+  if (many_tiles && deep) hipLaunchKernelGGL((k_leaf_scan<512, 8, true>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
   else if (many_tiles) hipLaunchKernelGGL((k_leaf_scan<512, 8, false>), dim3(s_tiles), dim3(512), 0, stream, PCC_SCAN_ARGS);
   else if (deep) hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems, true>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SCAN_ARGS);
   else hipLaunchKernelGGL((k_leaf_scan<kSortThreads, kSortItems, false>), dim3(s_tiles), dim3(kSortThreads), 0, stream, PCC_SCAN_ARGS);
@@ -2961,8 +2520,8 @@ void launch_hot_path(const HotPathArgs& a, hipStream_t stream, KernelTimer* tm) 
   PCC_STAMP("k_leaf_scan");
   if (a.stop_after_leaf_scan) return;
   const uint32_t max_h = n / 256u + 1u;  // tallest possible snake image
-  static const bool linear_rows = [] { const char* e = getenv("PCC_LEAF_ROWS"); return e && !strcmp(e, "linear"); }();
-  static const bool uniform_probes = [] { const char* e = getenv("PCC_LEAF_PROBES"); return e && !strcmp(e, "uniform"); }();
+  static const bool linear_rows = [] { const char* e = dev_env("PCC_LEAF_ROWS"); return e && !strcmp(e, "linear"); }();
+  static const bool uniform_probes = [] { const char* e = dev_env("PCC_LEAF_PROBES"); return e && !strcmp(e, "uniform"); }();
   LeafParams lp = a.lp;
   lp.linear_rows = linear_rows ? 1u : 0u;
   lp.uniform_probes = uniform_probes ? 1u : 0u;

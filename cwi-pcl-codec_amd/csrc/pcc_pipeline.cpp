@@ -33,7 +33,8 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/pcc_codec.h"
+#include "../../include/pcc_codec_tools.h"
+#include "pcc_dev.h"
 
 namespace {
 typedef std::chrono::steady_clock Clock;
@@ -79,6 +80,7 @@ struct pcc_pipeline {
   int entropy_mode = 0;
   size_t pin_cores_taken = 0;  // of g_pin_cores_taken, given back when the pipeline is destroyed
   int gpu_batch = 256;
+  bool rc_lanes = false;  // option "rc_device_lanes": the form of the device range coder the entropy threads' batches launch
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
   // most frames an entropy thread codes in one call: four share a scalar loop (the default, measured on the GPU box);
   // PCC_PIPELINE_BATCH=16: sixteen through AVX-512 lanes (1.47 against 2.00 ns per symbol and stream on the build container's
@@ -102,7 +104,7 @@ struct pcc_pipeline {
     const size_t left = job.n_frames > taken ? job.n_frames - taken : 0;
     // (with the entropy threads on cores of their own -- see pcc_pipeline_create -- the last frames of a call are best
     // spread wider: 20 frames on 16 threads as five pairs and ten singles, 4.6 ms against 5.0 ms)
-    static const double forced = [] { const char* e = getenv("PCC_PIPELINE_SPREAD"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.0; }();
+    static const double forced = [] { const char* e = pcc::dev_env("PCC_PIPELINE_SPREAD"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.0; }();
     const double spread = forced > 0.0 ? forced : (left <= 2 * (size_t)std::max(n_entropy, 1) ? 1.4 : 2.0);
     const size_t per = (size_t)(((double)left * spread + (double)n_entropy - 1.0) / (double)std::max(n_entropy, 1));
     return std::min<size_t>(std::max<size_t>(per, 1), (size_t)batch);
@@ -287,6 +289,7 @@ struct pcc_pipeline {
     }
     if (!batches[(size_t)index]) batches[(size_t)index] = pcc_entropy_batch_create(device, (size_t)gpu_batch);
     pcc_entropy_batch* batch = batches[(size_t)index];
+    if (batch) (void)pcc_entropy_batch_set_option(batch, "rc_device_lanes", rc_lanes ? 1 : 0);
     std::vector<size_t> frames_in_batch;
     std::vector<pcc_bitstream> outs;
     auto flush = [&]() {
@@ -498,10 +501,11 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   p->lane = pcc_upload_lane_create(device);
   // one stream per GPU-stage thread, created back to back (the runtime hands out its hardware queues round robin)
   // (PCC_PIPELINE_OWN_STREAMS=1: every context keeps its own stream, as before)
-  if (!(getenv("PCC_PIPELINE_OWN_STREAMS") && getenv("PCC_PIPELINE_OWN_STREAMS")[0] == '1'))
+  if (!(pcc::dev_env("PCC_PIPELINE_OWN_STREAMS") && pcc::dev_env("PCC_PIPELINE_OWN_STREAMS")[0] == '1'))
     for (int w = 0; w < p->n_gpu; ++w) p->gpu_streams.push_back(pcc_stream_create(device));
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
   p->batches.assign((size_t)p->n_entropy, nullptr);
+  if (const char* e = pcc::dev_env("PCC_RC_DEVICE")) p->rc_lanes = !strcmp(e, "lanes");
   if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_mode = !strcmp(e, "gpu") ? 1 : (!strcmp(e, "host") ? 0 : -1);
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p, w] { p->entropy_thread(w); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
@@ -591,18 +595,25 @@ int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
   std::lock_guard<std::mutex> lk(p->mu);  // between jobs: the threads read these when a job starts
   if (!strcmp(name, "entropy_on_gpu")) p->entropy_mode = value < 0 ? -1 : (value != 0 ? 1 : 0);  // -1: per call, from the cost estimate
   else if (!strcmp(name, "entropy_gpu_batch")) p->gpu_batch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
+  else if (!strcmp(name, "rc_device_lanes")) p->rc_lanes = value != 0;
   else if (!strcmp(name, "pack_upload")) { for (pcc_ctx* c : p->ctxs) (void)pcc_set_option(c, "pack_upload", value); }  // host frames: 16 B per point over PCIe
   else return PCC_ERR_ARG;
   return PCC_OK;
 }
 
-int pcc_pipeline_last_entropy_mode(pcc_pipeline* p) {
-  if (!p) return 0;
+int pcc_pipeline_get(pcc_pipeline* p, const char* name) {
+  if (!p || !name) return PCC_ERR_ARG;
   std::lock_guard<std::mutex> lk(p->mu);
-  return p->entropy_on_gpu ? 1 : 0;
+  if (!strcmp(name, "workers")) return p->n_entropy;
+  if (!strcmp(name, "gpu_threads")) return p->n_gpu_device;
+  if (!strcmp(name, "contexts")) return (int)p->ctxs.size();
+  if (!strcmp(name, "frames_per_coder_call")) return p->batch;
+  if (!strcmp(name, "last_entropy_mode")) return p->entropy_on_gpu ? 1 : 0;
+  if (!strcmp(name, "rc_device_lanes")) return p->rc_lanes ? 1 : 0;
+  if (!strcmp(name, "entropy_gpu_batch")) return p->gpu_batch;
+  return PCC_ERR_ARG;
 }
-int pcc_pipeline_workers(pcc_pipeline* p) { return p ? p->n_entropy : 0; }
-// developer aid (not part of include/pcc_codec.h): the CPUs entropy thread `worker` may run on, lowest first; returns how many
+// developer aid (include/pcc_codec_tools.h, the pcc_debug_* block): the CPUs entropy thread `worker` may run on, lowest first; returns how many
 // there are (at most `cap` are written), -1 for a bad argument
 int pcc_debug_pipeline_cpus(pcc_pipeline* p, int worker, int* out, int cap) {
   if (!p || worker < 0 || worker >= p->n_entropy || (cap > 0 && !out)) return -1;
@@ -649,7 +660,7 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->arena_used = 0;
     p->taken = 0;
     {
-      static const bool want = [] { const char* e = getenv("PCC_PIPELINE_TRACE"); return e && e[0] == '1'; }();
+      static const bool want = [] { const char* e = pcc::dev_env("PCC_PIPELINE_TRACE"); return e && e[0] == '1'; }();
       p->tracing = want && mode == 0 && n_frames <= 64;
       if (p->tracing) p->trace.assign(n_frames, pcc_pipeline::FrameTrace());
       p->t_last_thread = 0;

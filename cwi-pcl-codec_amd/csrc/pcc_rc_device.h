@@ -16,8 +16,6 @@ struct RcJob {            // one stream (device pointers)
 // dev_hists: room for 256 counts per job (the lane-per-stream form makes the counts of streams that come without them
 // there first); null: the wave-per-stream form whatever the mode
 void launch_range_encode(const RcJob* dev_jobs, uint32_t n_jobs, uint32_t* dev_hists, hipStream_t stream);
-void set_range_encode_lanes(int on);  // 1: one lane per stream (PCC_RC_DEVICE=lanes); 0 (default): one wave per stream
-int range_encode_lanes();
 // after the coder: the streams packed side by side (stream j at dev_packed + dev_offsets[j], offsets multiples of 16),
 // so that one device-to-host copy of the coded bytes brings everything back
 void launch_pack_streams(const RcJob* dev_jobs, const uint32_t* dev_offsets, uint8_t* dev_packed, uint32_t n_jobs, hipStream_t stream);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void k_range_encode(const RcJob* __restrict__ j
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The same coder with one LANE per stream (opt-in: pcc_set_option "rc_device_lanes"; PCC_RC_DEVICE=lanes).
+// The same coder with one LANE per stream (opt-in per context / batch / pipeline: option "rc_device_lanes").
 //
 // k_range_encode above keeps one stream's state in scalar registers and leaves 63 of a wave's 64 lanes to fetch symbols: a
 // wave is a slow scalar core, and a chip full of them is bounded by the CUs' scalar units (measured, round 2: 109 ns per
@@ -290,17 +290,10 @@ void launch_pack_streams(const RcJob* dev_jobs, const uint32_t* dev_offsets, uin
   if (n_jobs) hipLaunchKernelGGL(k_pack_streams, dim3(n_jobs), dim3(256), 0, stream, dev_jobs, dev_offsets, dev_packed, n_jobs);
 }
 
-// 0: one wave per stream (the form that has run on the chip); 1: one lane per stream
-static std::atomic<int>& rc_lanes() {
-  static std::atomic<int> v{[] { const char* e = getenv("PCC_RC_DEVICE"); return (e && !strcmp(e, "lanes")) ? 1 : 0; }()};
-  return v;
-}
-void set_range_encode_lanes(int on) { rc_lanes().store(on ? 1 : 0); }
-int range_encode_lanes() { return rc_lanes().load(); }
-
+// dev_hists null: one wave per stream (the form that has run on the chip); else one lane per stream
 void launch_range_encode(const RcJob* dev_jobs, uint32_t n_jobs, uint32_t* dev_hists, hipStream_t stream) {
   if (!n_jobs) return;
-  if (rc_lanes().load() && dev_hists) {
+  if (dev_hists) {
     hipLaunchKernelGGL(k_stream_histograms, dim3(n_jobs), dim3(256), 0, stream, dev_jobs, n_jobs, dev_hists);
     hipLaunchKernelGGL(k_range_encode_lanes, dim3((n_jobs + 63u) / 64u), dim3(64), 0, stream, dev_jobs, n_jobs, dev_hists);
   } else {

@@ -20,6 +20,19 @@
  * Ownership: input buffers are caller-owned; every pointer returned in an out-struct
  * is library-owned and stays valid until the next call on the same context.
  * Errors: every call returns PCC_OK (0) or a negative code; pcc_last_error() gives text.
+ *
+ * Layout of the interface: THIS header is the drop-in boundary -- everything the class shim (cwi-pcl-codec_amd/shim/), the
+ * evaluation app and a frame loop call.  pcc_codec_tools.h declares what measurements, tests and tools use on top of it
+ * (kernel and host-stage timings, the pipeline's pieces one by one, the host stages' building blocks, the device range
+ * coder's harness, pcc_debug_*); a caller of the codec never needs it.
+ *
+ * Environment: the shipped library reads NINE variables, all of them deployment configuration of pcc_pipeline (none changes
+ * an output byte): PCC_PIPELINE_ENTROPY = host | gpu | auto (where the entropy stage runs; default host),
+ * PCC_PIPELINE_GPU_THREADS, PCC_PIPELINE_UPLOAD_THREADS (frames in flight on the GPU / uploads), PCC_PIPELINE_BATCH
+ * (frames per coder loop, 1..16, default 4), PCC_PIPELINE_PIN = groups | cores | none with PCC_PIPELINE_PIN_OFFSET and
+ * PCC_PIPELINE_PIN_SPAN (core pinning of the entropy threads), and torchrun's LOCAL_RANK / LOCAL_WORLD_SIZE (each rank pins
+ * inside its own share of the cores).  Developer switches (traces, bisecting forms) exist only in the `make dev` build:
+ * csrc/pcc_dev.h.
  */
 #ifndef PCC_CODEC_H
 #define PCC_CODEC_H
@@ -114,19 +127,8 @@ typedef struct pcc_cloud {
   size_t consumed;           /* bytes of the input consumed */
 } pcc_cloud;
 
-/* Per-kernel timing of the last hot-path run (HIP events on the context's stream). */
-#define PCC_MAX_KERNEL_TIMES 64
-typedef struct pcc_kernel_times {
-  int32_t count;
-  const char *name[PCC_MAX_KERNEL_TIMES];
-  float ms[PCC_MAX_KERNEL_TIMES];
-} pcc_kernel_times;
-
 /* ---- lifetime ---- */
 pcc_ctx *pcc_create(int device);                 /* replaces `new OctreePointCloudCodecV2` (eval.hpp:377) */
-/* A context without a GPU: only the host stages work on it (pcc_entropy_encode, pcc_decode_intra).
- * Every GPU entry point returns PCC_ERR_STATE -- there is no CPU fallback for the hot path. */
-pcc_ctx *pcc_create_host(void);
 void pcc_destroy(pcc_ctx *ctx);
 const char *pcc_last_error(pcc_ctx *ctx);
 /* What this binary is: "pcc_hip 0.1 (gfx950)" for the product library and nothing else -- the same sources compiled for the
@@ -152,32 +154,6 @@ int pcc_reserve(pcc_ctx *ctx, size_t max_points, size_t bitstream_bytes);
 /* addPointsFromInputCloud + serializeTree + leaf callbacks (impl.hpp:99,166,1509-1578) on the GPU; asynchronous. */
 int pcc_hotpath_launch(pcc_ctx *ctx, const void *dev_points, size_t n, size_t stride, size_t rgb_offset,
                        const pcc_params *params);
-/* The same for a cloud in HOST memory (the reference's timed span starts there, eval.hpp:462-464): the points are
- * copied to the context's HBM arena asynchronously, the kernels start when they have arrived.  Ordinary (pageable)
- * memory is page-locked for the time of the copy; memory from pcc_host_alloc is used as it is.  `lane` (may be NULL)
- * is a stream shared by the contexts of one GPU that carries the uploads one after the other, at full PCIe rate,
- * while the kernels of earlier frames run; with NULL the copy is queued in front of the kernels on the context's own
- * stream.  The caller's buffer must stay untouched until pcc_hotpath_finish returns. */
-typedef struct pcc_upload_lane pcc_upload_lane;
-pcc_upload_lane *pcc_upload_lane_create(int device);
-void pcc_upload_lane_destroy(pcc_upload_lane *lane);
-int pcc_hotpath_launch_host(pcc_ctx *ctx, pcc_upload_lane *lane, const void *host_points, size_t n, size_t stride,
-                            size_t rgb_offset, const pcc_params *params);
-/* A context's GPU work runs on a stream of its own unless it borrows one.  Why a caller would care: the HIP runtime
- * spreads the streams of a process over four hardware queues, round robin in the order the streams are created, and
- * the frames in flight overlap best when every queue carries the same number of them (cfg2, saturated GPU stage: 12
- * streams as 3 3 3 3: 11 200 frames/s, 10 streams as 3 3 2 2: 10 400, 12 as 4 4 4 0: 10 000; tools/queue_balance.py).
- * With more contexts than frames in flight -- a context is held until its host stage is over -- the streams that
- * happen to be busy are not balanced; pcc_pipeline therefore creates one stream per GPU-stage thread, one after the
- * other, and lends it to whichever context the thread is driving.  Only between frames (no launch in flight on the
- * context); NULL gives the context its own stream back. */
-typedef struct pcc_stream pcc_stream;
-pcc_stream *pcc_stream_create(int device);
-void pcc_stream_destroy(pcc_stream *stream);
-int pcc_use_stream(pcc_ctx *ctx, pcc_stream *stream);
-/* page-locked host memory for callers that fill their frames themselves (capture, file readers) */
-void *pcc_host_alloc(size_t bytes);
-void pcc_host_free(void *p);
 /* wait for the kernels, bring occupancy bytes / colour image / centroid bytes to the host */
 int pcc_hotpath_finish(pcc_ctx *ctx, pcc_hot_result *out);
 /* writeFrameHeader + entropyEncoding (impl.hpp:175-178, 1472-1486, 1682-1760): host only, no GPU calls;
@@ -185,16 +161,6 @@ int pcc_hotpath_finish(pcc_ctx *ctx, pcc_hot_result *out);
  * is a different context (the bitstream is stored there). */
 int pcc_entropy_encode(pcc_ctx *ctx_for_output, const pcc_hot_result *hot, const pcc_params *params,
                        pcc_bitstream *out);
-
-/* The same for several frames at once (different contexts): the serial range-coder loops of the frames are
- * interleaved in one loop, which costs a fraction of the time per frame (each symbol is a chain of dependent
- * operations that leaves most of a core idle).  Bytes identical to separate pcc_entropy_encode calls.  Up to four frames share
- * a scalar loop; ten to sixteen go through AVX-512 lanes where the host CPU has them (else through scalar loops of four). */
-#define PCC_MAX_FRAMES_AT_ONCE 16
-int pcc_entropy_encode_many(int n, pcc_ctx *const ctx[], const pcc_hot_result *const hot[], const pcc_params *const prm[],
-                            pcc_bitstream *const out[]);
-int pcc_entropy_encode2(pcc_ctx *ctx_a, const pcc_hot_result *hot_a, const pcc_params *prm_a, pcc_bitstream *out_a,
-                        pcc_ctx *ctx_b, const pcc_hot_result *hot_b, const pcc_params *prm_b, pcc_bitstream *out_b);
 
 /* getOutputCloud() (eval.hpp:862): the simplified cloud of the last encode, L points (impl.hpp:1576). */
 int pcc_get_output_cloud(pcc_ctx *ctx, const pcc_point_xyzrgb **points, size_t *n);
@@ -207,28 +173,12 @@ int pcc_decode_intra(pcc_ctx *ctx, const uint8_t *stream, size_t len, pcc_cloud 
  * level), the GPU the rest (voxel keys -> centres or centroids, inverse DCT, chroma upsampling, colour conversion and
  * un-snaking of the colour image).  Same cloud, bit for bit; out->points is page-locked library memory. */
 int pcc_decode_intra_gpu(pcc_ctx *ctx, const uint8_t *stream, size_t len, pcc_cloud *out);
-/* milliseconds of the last pcc_decode_intra_gpu: sequential host stages | upload + kernels + download | whole call */
-int pcc_get_decode_times(pcc_ctx *ctx, double out_ms[3]);
 
 /* ---- helpers around the path ---- */
 /* device memory for callers that keep clouds resident (bench, multi-frame pipelines) */
 int pcc_device_alloc(pcc_ctx *ctx, size_t bytes, void **dev_ptr);
 int pcc_device_free(pcc_ctx *ctx, void *dev_ptr);
 int pcc_device_upload(pcc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
-int pcc_get_kernel_times(pcc_ctx *ctx, pcc_kernel_times *out);
-/* The same launches measured on the GPU itself: from the start of a launch's first workgroup to the end of its last
- * wave, on the device's real-time clock (what a kernel trace reports; the events above sit BETWEEN the launches and
- * add a few microseconds of their own to every short kernel).  Sort passes a frame did not need are left out. */
-int pcc_get_kernel_spans(pcc_ctx *ctx, pcc_kernel_times *out);
-/* ... and when each of those launches started, milliseconds after the first one: the distance between the starts of two
- * consecutive launches is what a launch costs its stream (its span plus the dispatch and the end-of-kernel write-back
- * that the span leaves out) -- the figure a kernel trace calls the kernel's duration. */
-int pcc_get_kernel_span_starts(pcc_ctx *ctx, pcc_kernel_times *out);
-/* wall time of the last pcc_entropy_encode on this context, microseconds: occupancy range coder, JPEG
- * stage, colour range coder, whole stage */
-int pcc_get_host_times(pcc_ctx *ctx, double out_us[4]);
-/* enable per-kernel HIP-event timing (off by default: events between launches cost a little) */
-int pcc_set_profiling(pcc_ctx *ctx, int enabled);
 /* context knobs (do not change any output byte):
  *   "jpeg_on_gpu" (default 2): 2 = the whole JPEG stage but the file headers runs on the GPU (colour conversion,
  *                 4:2:0 downsample, FDCT, quantisation, Huffman coding per MCU row; the host stitches the rows
@@ -236,19 +186,15 @@ int pcc_set_profiling(pcc_ctx *ctx, int enabled);
  *                 from the image.
  *   "copy_image"  (default 1): bring the snake-mapped image itself back in pcc_hot_result.image (needed only
  *                 for inspection when jpeg_on_gpu is 1).
- *   "profile_events" (default 1): with pcc_set_profiling, also record HIP events between the launches
- *                 (pcc_get_kernel_times); 0 leaves only the launch spans on the GPU clock, so that the launches run
- *                 back to back as they do unprofiled.
- *   "force_pairs", "no_cell_ranks" (default 0): test hooks -- which key layout the sort is given (1: (code, index) pairs on
- *                 small frames; 2: the point index kept in the key although nothing reads it) / the full varying Morton
- *                 code sorted instead of cell ranks.  Same bytes either way.
- *   "rc_device_lanes" (default 0; process-wide): the device range coder (pcc_device_range_encode, pcc_entropy_batch_*) codes
- *                 one stream per LANE, 64 per wave, instead of one per wave -- same bytes; opt-in until it has been timed. */
+ *   "pack_upload" (default 0): a frame from host memory is packed to 16 bytes per point before it crosses PCIe.
+ *   (measurement and test hooks -- "profile_events", "force_pairs", "no_cell_ranks", "icp_waves", "rc_device_lanes" -- are
+ *   described in pcc_codec_tools.h) */
 int pcc_set_option(pcc_ctx *ctx, const char *name, int value);
 
 /* ---- a sequence of frames on one GPU (the app's frame loop, eval.hpp:818-835) ----
  * A pipeline owns a ring of pcc_ctx, a few GPU-stage threads that keep frames in flight on the GPU, and
- * `n_workers` entropy threads that run the serial host stage, two frames at a time (pcc_entropy_encode2).  Frames are independent I-frames (impl.hpp:89-90,126-130);
+ * `n_workers` entropy threads that run the serial host stage, a few frames per coder loop.  Frames are independent I-frames
+ * (impl.hpp:89-90,126-130);
  * the frames get consecutive frame ids starting at params->frame_id, dropped (empty / all non-finite) frames
  * do not consume one (frame_ID_ is the only state the reference carries from frame to frame, impl.hpp:133,
  * 206-212), so the bitstreams equal those of the reference's serial loop; a dropped frame yields len 0.  The calls block
@@ -263,12 +209,16 @@ void pcc_pipeline_destroy(pcc_pipeline *p);
  *                 decided per call from a cost estimate (frames, symbols per frame, entropy threads): long calls on hosts
  *                 with few cores per GPU go to the GPU -- opt-in until its two cost constants are calibrated on the box.
  *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread.
+ *   "rc_device_lanes" (default 0): with the entropy stage on the GPU, the device range coder codes one stream per LANE
+ *                 instead of one per wave (same bytes; never timed on an MI355X).
  *   "pack_upload" (default 0): frames from host memory are packed to 16 bytes per point before they cross PCIe. */
 int pcc_pipeline_set_option(pcc_pipeline *p, const char *name, int value);
-int pcc_pipeline_last_entropy_mode(pcc_pipeline *p); /* where the entropy stage of the last call ran: 0 host, 1 GPU */
-int pcc_pipeline_workers(pcc_pipeline *p);
+/* what the pipeline runs with: "workers" (entropy threads), "gpu_threads", "contexts", "frames_per_coder_call" (the batch
+ * size in force: PCC_PIPELINE_BATCH after its range check), "last_entropy_mode" (where the entropy stage of the last call
+ * ran: 0 host, 1 GPU), "rc_device_lanes", "entropy_gpu_batch"; PCC_ERR_ARG for an unknown name */
+int pcc_pipeline_get(pcc_pipeline *p, const char *name);
 int pcc_pipeline_contexts(pcc_pipeline *p);
-pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option / pcc_set_profiling / kernel times */
+pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option on the contexts of the ring */
 int pcc_pipeline_encode(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
                         size_t stride, size_t rgb_offset, const pcc_params *params, pcc_bitstream *out);
 /* The same sequence with the frames in HOST memory -- the call the reference app's frame loop maps to (eval.hpp:818-835
@@ -281,19 +231,6 @@ int pcc_pipeline_encode_host(pcc_pipeline *p, const void *const *host_frames, co
  * needed.  With max_points_per_frame > 0 every context of the ring is prepared as well (pcc_reserve): a context used
  * for the first time in the middle of a sequence otherwise stalls its thread for several milliseconds. */
 int pcc_pipeline_reserve(pcc_pipeline *p, size_t n_frames, size_t bytes_per_frame, size_t max_points_per_frame);
-/* the GPU stage alone (kernels + device->host hand-over), for capacity measurements */
-int pcc_pipeline_gpu_stage_only(pcc_pipeline *p, const void *const *dev_frames, const size_t *n_points, size_t n_frames,
-                                size_t stride, size_t rgb_offset, const pcc_params *params);
-/* per-frame means of the last call, microseconds: launch, finish, entropy call wall time; then the four values of
- * pcc_get_host_times; out_us[7] = frames processed */
-int pcc_pipeline_stats(pcc_pipeline *p, double out_us[8]);
-/* CPU time (not wall time) the pipeline's threads spent in the same three calls, per-frame means, microseconds;
- * out_us[3] = frames processed.  Wall minus CPU = time asleep waiting for the GPU. */
-int pcc_pipeline_cpu_times(pcc_pipeline *p, double out_us[4]);
-/* HIP-event kernel times of the last call, summed over the frames that ran on a context with profiling
- * enabled: sums->ms[i] = total milliseconds of kernel sums->name[i], launches[i] = number of launches
- * (arrays of PCC_MAX_KERNEL_TIMES), *frames = profiled frames */
-int pcc_pipeline_kernel_times(pcc_pipeline *p, pcc_kernel_times *sums, int32_t *launches, int32_t *frames);
 const char *pcc_pipeline_last_error(pcc_pipeline *p);
 
 /* ---- the same frame loop over several GPUs of one node (frames shard one per GPU, no collective) ----
@@ -364,77 +301,14 @@ typedef struct pcc_delta_result {
   float gpu_ms;
 } pcc_delta_result;
 
-/* one macroblock of the P frame as the GPU judged it (inspection / tests) */
-typedef struct pcc_delta_block {
-  int32_t i_block;            /* index of the I frame's macroblock with the same key, -1: none */
-  uint32_t n_p, n_i;          /* points in the P / I block */
-  int32_t do_icp;             /* passed the gates */
-  int32_t converged;          /* ICP converged and fitness < 2 * point_resolution */
-  int32_t iterations;
-  int8_t rgb_offsets[4];
-  uint16_t key[4];            /* x, y, z */
-  float fitness;
-  float rt[16];               /* final transformation, row-major */
-} pcc_delta_block;
-
 int pcc_encode_delta(pcc_ctx *ctx, const pcc_point_xyzrgb *i_cloud, size_t n_i, const pcc_point_xyzrgb *p_cloud, size_t n_p,
                      const pcc_delta_params *params, pcc_delta_result *out);
-int pcc_delta_blocks(pcc_ctx *ctx, const pcc_delta_block **blocks, size_t *n); /* of the last pcc_encode_delta */
 int pcc_decode_delta(pcc_ctx *ctx, const pcc_point_xyzrgb *i_cloud, size_t n_i, const uint8_t *i_stream, size_t i_len,
                      const uint8_t *p_stream, size_t p_len, const pcc_delta_params *params, pcc_cloud *out);
 
-/* ---- the static range coder for MANY independent streams on the GPU (csrc/pcc_rc_device.hip) ----
- * One wave per stream, coder state in scalar registers: roughly ten times slower per stream than a CPU core, but a
- * thousand streams run side by side -- for pipelines whose host has fewer cores than the GPUs can feed.  Same bytes as
- * pcc_host_range_encode.  Host pointers in and out (out[i]: room for 1028 + n[i] + n[i]/2 + 64 bytes); this entry point
- * is the measurement / test harness of the kernel, the frame pipeline does not use it yet. */
-int pcc_device_range_encode(pcc_ctx *ctx, int n_streams, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
-                            size_t *out_len, float *gpu_ms);
-
-/* ---- the entropy stage of MANY frames with the range coders on the GPU ----
- * For hosts with fewer CPU cores than their GPUs can feed (the north star keeps the serial coder on the host, and with
- * 16 cores per GPU that is the faster place).  pcc_entropy_batch_add copies what a frame's entropy stage needs out of
- * the frame's hot-path products -- so the context that produced it is free again -- and puts the colour JPEG together on the host;
- * pcc_entropy_batch_flush range-codes every stream of the batch on the GPU (one wave per stream, ~0.1 s per flush
- * whatever the batch size: use batches of hundreds of frames) and assembles the bitstreams -- byte-identical to
- * pcc_entropy_encode.  out[i] (i-th frame added) stays valid until the next flush. */
-typedef struct pcc_entropy_batch pcc_entropy_batch;
-pcc_entropy_batch *pcc_entropy_batch_create(int device, size_t max_frames);
-void pcc_entropy_batch_destroy(pcc_entropy_batch *b);
-size_t pcc_entropy_batch_size(pcc_entropy_batch *b);
-size_t pcc_entropy_batch_capacity(pcc_entropy_batch *b);
-int pcc_entropy_batch_add(pcc_entropy_batch *b, const pcc_hot_result *hot, const pcc_params *params); /* index, or < 0 */
-int pcc_entropy_batch_flush(pcc_entropy_batch *b, pcc_bitstream *out, size_t out_capacity, size_t *n_out);
-const char *pcc_entropy_batch_last_error(pcc_entropy_batch *b);
-
-/* ---- building blocks of the host stages (serial by nature; exposed for tests and tools) ---- */
-/* pcl::StaticRangeCoder::encodeCharVectorToStream / decodeStreamToCharVector (impl.hpp:1694 / :1778).
- * encode: writes at most out_cap bytes, returns the encoded size (or 0 if out_cap is too small). */
-size_t pcc_host_range_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap);
-size_t pcc_host_range_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t n);
-/* The same coder for up to sixteen independent vectors in ONE call -- how the entropy stage codes the streams of the frames
- * it holds (a lone coder is a chain of dependent operations and leaves most of a core idle): up to four share a scalar loop,
- * ten and more go through the lanes of AVX-512 registers where the CPU has them.  Every out[i] gets exactly the bytes
- * pcc_host_range_encode gives for in[i]; out_len[i] = encoded size, 0 if out_cap[i] is too small.  Returns PCC_OK, or
- * PCC_ERR_ARG for count outside 1..16. */
-int pcc_host_range_encode_many(int count, const uint8_t *const *in, const size_t *n, uint8_t *const *out,
-                               const size_t *out_cap, size_t *out_len);
-/* JPEGWriter::writeJPEG / JPEGReader::readJPEG (jpeg_io.hpp:211-330 / 90-192), RGB, 4:2:0 */
-size_t pcc_host_jpeg_encode(const uint8_t *rgb, int w, int h, int quality, uint8_t *out, size_t out_cap);
-int pcc_host_jpeg_decode(const uint8_t *jpg, size_t len, uint8_t *rgb, size_t rgb_cap, int *w, int *h);
-/* SnakeGridMapping iterator position (snake_grid_mapping.h:46-71) in closed form */
-uint32_t pcc_host_snake_position(uint32_t i, uint32_t w, uint32_t h);
-
-/* RigidTransformCoding::compressRigidTransform / deCompressRigidTransform (rigid_transform_coding_impl.hpp:63-203):
- * row-major 4x4 -> 6 int16 (quaternion + translation) or 10 (two rotation rows, sign word, translation) */
-size_t pcc_host_rigid_compress(const float tr[16], int16_t *comp_out, size_t cap);
-int pcc_host_rigid_decompress(const int16_t *comp, size_t count, float tr_out[16]);
-
-/* normalize_pointclouds / restore_scaling for one group (codec.h:216-227, impl.hpp:1871-1986), host side */
-int pcc_normalize_group(pcc_point_xyzrgb **clouds, const size_t *sizes, size_t n_clouds, double bb_expand_factor,
-                        float bb_min[3], float bb_max[3]);
-/* the same, also reporting the box in force for every cloud (bounding_boxes[k], impl.hpp:1928-1929):
- * per_cloud_boxes = n_clouds x {min x,y,z, max x,y,z}, or NULL */
+/* ---- normalize_pointclouds / restore_scaling for one group (codec.h:216-227, impl.hpp:1871-1986), host side ----
+ * also reports the box in force for every cloud (bounding_boxes[k], impl.hpp:1928-1929): per_cloud_boxes = n_clouds x
+ * {min x,y,z, max x,y,z}, or NULL */
 int pcc_normalize_group_boxes(pcc_point_xyzrgb **clouds, const size_t *sizes, size_t n_clouds, double bb_expand_factor,
                               float bb_min[3], float bb_max[3], float *per_cloud_boxes);
 int pcc_restore_scaling(pcc_point_xyzrgb *cloud, size_t n, const float bb_min[3], const float bb_max[3]);

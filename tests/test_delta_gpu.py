@@ -77,10 +77,11 @@ def test_delta_encode_matches_oracle_given_the_transforms(pkg, ctx, pair, colour
 
 
 @pytest.mark.parametrize("waves", ["1", "4"])
-def test_delta_icp_close_to_oracle_icp(pkg, ctx, pair, waves, monkeypatch):
+def test_delta_icp_close_to_oracle_icp(pkg, ctx, pair, waves, request):
     """The GPU's per-block ICP (both kernel shapes: one wave per block, one workgroup per block) against the oracle's
     restatement of PCL's defaults on the same blocks."""
-    monkeypatch.setenv("PCC_ICP_WAVES", waves)
+    ctx.set_option("icp_waves", int(waves))   # one ICP kernel shape for every macroblock (the context is shared: undone afterwards)
+    request.addfinalizer(lambda: ctx.set_option("icp_waves", 0))
     i_cloud, p_cloud = pair
     got = ctx.encode_delta(i_cloud, p_cloud, _params(pkg))
     simp = D.simplify(p_cloud, RES)
@@ -242,10 +243,11 @@ def test_cfg5_at_its_stated_size(pkg, oracle, ctx):
 
 
 @pytest.mark.parametrize("mb,on_original,waves", [(8, False, "4"), (32, False, "1"), (64, True, "1"), (128, True, "4")])
-def test_delta_other_macroblock_sizes_and_big_blocks(pkg, ctx, pair, mb, on_original, waves, monkeypatch):
+def test_delta_other_macroblock_sizes_and_big_blocks(pkg, ctx, pair, mb, on_original, waves, request):
     """Macroblock sizes other than 16; with 64-voxel blocks on the unsimplified cloud a block holds thousands of points
     (more targets than the ICP kernel stages in LDS: the HBM/L2 path)."""
-    monkeypatch.setenv("PCC_ICP_WAVES", waves)
+    ctx.set_option("icp_waves", int(waves))   # one ICP kernel shape for every macroblock (the context is shared: undone afterwards)
+    request.addfinalizer(lambda: ctx.set_option("icp_waves", 0))
     i_cloud, p_cloud = pair
     prm = _params(pkg, macroblock_size=mb)
     got = ctx.encode_delta(i_cloud, p_cloud, prm, icp_on_original=on_original)

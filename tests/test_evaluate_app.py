@@ -102,7 +102,7 @@ def test_app_group_loop_matches_the_oracle(pkg, oracle, tmp_path):
     ptrs = (C.c_void_p * 3)(*[w.ctypes.data for w in work])
     sizes = (C.c_size_t * 3)(*[len(w) for w in work])
     mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
-    assert lib.pcc_normalize_group(ptrs, sizes, 3, 0.2, mn.ctypes.data, mx.ctypes.data) == 0
+    assert lib.pcc_normalize_group_boxes(ptrs, sizes, 3, 0.2, mn.ctypes.data, mx.ctypes.data, None) == 0
     lines = open(tmp_path / "intra_frame_quality.csv").read().splitlines()
     assert lines[0] == CSV_HEADER
     assert len(lines) == 4

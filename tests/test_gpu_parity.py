@@ -409,16 +409,12 @@ def test_indexed_keys_match_bare_keys(pkg, oracle):
             c.close()
 
 
-def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypatch):
-    """Fused mode (PCC_FUSED_KEYS=1; off by default until it has been timed on the chip): the streaming workgroups of k_boxes_events keep their points in registers and write sort
-    keys and digit counts themselves once workgroup 0 has published the plan (the chunks that hold points of earlier
-    epochs take the epoch table from it as well); k_make_keys only visits chunks whose wait ran out.  Same bytes as the two-kernel form (PCC_FUSED_KEYS=0) and as a frame in which every workgroup's
-    wait for the plan runs out (PCC_PLAN_SPINS=1: everything falls back), for every key layout, with growth events
-    spread over the cloud (earlier epochs in later chunks), cell ranks, non-finite points, ragged sizes."""
-    import ctypes as C
+def test_every_key_layout_with_growth_events_all_over_the_cloud(pkg, oracle):
+    """Every key layout the sort plan of k_boxes_events can choose ([code | colour], [code | index] + colour payload, bare
+    codes, LINES colours), on clouds whose growth events are spread over the chunks (earlier epochs in later chunks: the
+    tiles of k_make_keys that look their epoch up), with a first chunk without a finite point, cell ranks, non-finite
+    points and ragged sizes around the 2048-point chunk: the oracle's bytes."""
     b = pkg.binding
-    lib = b.load_library()
-    lib.pcc_debug_fused_chunks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     rng = np.random.default_rng(77)
     clouds = []
     for n in (1, 2047, 2048, 2049, 6000, 70_001):
@@ -432,29 +428,19 @@ def test_fused_keys_read_the_cloud_once_and_change_nothing(pkg, oracle, monkeypa
     holes = s.copy(); holes["y"][::7] = np.nan; holes["x"][:3000] = np.inf   # chunk 0 without a finite point
     clouds.append((holes, dict(octree_bits=10)))
     clouds.append((pkg.synthetic.voxelised_body(120_000, 0xB0D), dict(octree_bits=10)))   # cell ranks
-    seen_fused = seen_fallback = 0
     c = b.Context(0)
     try:
         for pts, kw in clouds:
-            hot, want = assert_matches_oracle(pkg, oracle, c, pts, **kw)
-            out = (C.c_uint32 * 3)()
-            assert lib.pcc_debug_fused_chunks(c.h, out) == 0
-            seen_fused += out[0]; seen_fallback += out[1] - out[0]
+            assert_matches_oracle(pkg, oracle, c, pts, **kw)
     finally:
         c.close()
-    import os
-    if os.environ.get("PCC_FUSED_KEYS", "0") == "0" or os.environ.get("PCC_PLAN_SPINS") == "1":
-        assert seen_fused == 0
-    elif "PCC_PLAN_SPINS" not in os.environ:   # (a shortened wait leaves some chunks to k_make_keys: same bytes, checked above)
-        print("fused chunks", seen_fused, "left to k_make_keys", seen_fallback)
-        assert seen_fused > 100 and seen_fallback == 0   # every chunk, the ones that hold earlier epochs included (epoch table in the plan)
 
 
 def test_crowded_voxels_beside_a_surface(pkg, oracle, ctx):
-    """Thousands of points inside one 4 x 4 x 4-voxel cube next to an ordinary surface (more than one sort tile of them): the
-    group of equal high code bits is far longer than the local fix-up of PCC_SORT_LOCAL takes on (the frame is then sent
-    back and sorted by four global passes); in every mode the bytes are the oracle's."""
-    s = pkg.synthetic.sphere_shell(450_000, 0xC0DE)   # (more than 96 sort tiles: the narrow kernel shapes, the only ones the experiment has)
+    """Thousands of points inside one 4 x 4 x 4-voxel cube next to an ordinary surface (more than one sort tile of equal
+    leading digits: long runs of one digit in the onesweep passes, thousands of points per leaf in k_leaf_tile): the
+    oracle's bytes, and an ordinary frame behind it on the same context."""
+    s = pkg.synthetic.sphere_shell(450_000, 0xC0DE)   # (more than 96 sort tiles: the narrow kernel shapes)
     rng = np.random.default_rng(9)
     crowd = cloud(pkg, 0.5 + rng.uniform(0.0, 3.5 / 1024.0, (9_000, 3)), seed=4)
     pts = np.concatenate([s[:170_000], crowd, s[170_000:]])

@@ -13,28 +13,56 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+DEV_LIB = os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip_dev.so")   # `make dev`, built by __graft_entry__.build()
 
 
 def test_library_exports_every_declared_symbol(pkg):
+    """Both headers of the C ABI -- pcc_codec.h, the drop-in boundary, and pcc_codec_tools.h, what measurements, tests and
+    tools use on top of it -- declare exactly the binding's two lists, the library exports every one of them, and nothing
+    named pcc_* besides."""
+    import subprocess
     lib = pkg.binding.load_library()
-    header = open(os.path.join(ROOT, "include", "pcc_codec.h")).read()
-    declared = set(re.findall(r"\b(pcc_[a-z_0-9]+)\s*\(", header))
-    assert declared == set(pkg.binding.EXPORTS), declared ^ set(pkg.binding.EXPORTS)
-    for name in declared:
-        assert hasattr(lib, name), name
+    for header, names in (("pcc_codec.h", pkg.binding.BOUNDARY_EXPORTS), ("pcc_codec_tools.h", pkg.binding.TOOLS_EXPORTS)):
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        declared = set(re.findall(r"\b(pcc_[a-z_0-9]+)\s*\(", text))
+        assert declared == set(names), (header, declared ^ set(names))
+        for name in declared:
+            assert hasattr(lib, name), name
+    assert len(pkg.binding.BOUNDARY_EXPORTS) <= 40
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg.binding.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = {l.split()[-1] for l in nm.stdout.splitlines() if " T pcc_" in l}
+        assert exported == set(pkg.binding.EXPORTS), exported ^ set(pkg.binding.EXPORTS)
     assert b"gfx950" in lib.pcc_version()
 
 
-def test_known_good_round2_library_loads_beside_head(pkg):
-    """tools/known_good/build.sh: the library of the last commit whose parity suite ran green on an MI355X (round 2), built
-    from that commit's sources, with HEAD's whole C ABI (two later entry points come from a compat file) -- so that one GPU
-    session can time and digest-check it beside HEAD.  Here: it loads, exports every declared symbol, and its host-side
-    range coder and JPEG writer give HEAD's bytes.  bench.py / smoke() refuse it (it is not HEAD's product library)."""
+def test_the_shipped_library_reads_only_the_pipelines_deployment_variables():
+    """Developer switches go through dev_env() (csrc/pcc_dev.h: a constant nullptr unless -DPCC_DEV): what is left of getenv in
+    the sources is the pipeline's deployment configuration, the nine names include/pcc_codec.h lists under "Environment"."""
+    import glob
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "cwi-pcl-codec_amd", "csrc", "*.*")):
+        if f.endswith((".cpp", ".hip", ".h")) and not f.endswith("pcc_dev.h"):
+            names |= set(re.findall(r'(?<![_a-z:])getenv\("([A-Z_0-9]+)"\)', open(f).read()))
+    assert names == {"PCC_PIPELINE_ENTROPY", "PCC_PIPELINE_GPU_THREADS", "PCC_PIPELINE_UPLOAD_THREADS", "PCC_PIPELINE_BATCH", "PCC_PIPELINE_PIN",
+                     "PCC_PIPELINE_PIN_OFFSET", "PCC_PIPELINE_PIN_SPAN", "LOCAL_RANK", "LOCAL_WORLD_SIZE"}, names
+    header = open(os.path.join(ROOT, "include", "pcc_codec.h")).read()
+    for n in names:
+        assert n in header, n
+
+
+@pytest.mark.parametrize("tag", ["r02", "r04x"])
+def test_the_libraries_of_older_commits_load_beside_head(pkg, tag):
+    """tools/known_good/build.sh: r02 = the library of the last commit whose parity suite ran green on an MI355X (round 2),
+    r04x = round 4's HEAD with the opt-in forms that left the product in round 5 (branch experiments/r04-optin-forms), each
+    built from its commit's sources with HEAD's whole C ABI (later entry points come from a compat file) -- so that one GPU
+    session can time and digest-check them beside HEAD.  Here: they load, export every declared symbol, and their host-side
+    range coder and JPEG writer give HEAD's bytes.  bench.py / smoke() refuse them (not HEAD's product library)."""
     import subprocess
-    path = os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip_r02.so")
+    path = os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip_%s.so" % tag)
     if not os.path.exists(path):
         if not os.path.isdir(os.path.join(ROOT, ".git")):
-            pytest.skip("no git history here: the round-2 library cannot be rebuilt")
+            pytest.skip("no git history here: the older library cannot be rebuilt")
         assert subprocess.run(["bash", os.path.join(ROOT, "tools", "known_good", "build.sh")]).returncode == 0
     old, new = C.CDLL(path), pkg.binding.load_library()
     for name in pkg.binding.EXPORTS:
@@ -157,7 +185,9 @@ def test_five_to_sixteen_range_coders_in_one_call_match_the_oracle(pkg, oracle, 
                     checked += 1
         print("OK", checked)
     """ % ROOT)
-    env = dict(os.environ, PCC_RC_WIDE=wide)
+    if wide == "1" and not pkg.binding.load_library().pcc_debug_host_rc_wide():
+        pytest.skip("no AVX-512 on this host: the vector path of the host range coder cannot be compared here")
+    env = dict(os.environ, PCC_RC_WIDE=wide, PCC_LIB=DEV_LIB)   # (the switch exists in the developer build only: csrc/pcc_dev.h)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
@@ -248,7 +278,7 @@ def test_host_decoder_on_one_thread_gives_the_same_cloud(pkg, oracle, tmp_path):
             "pts, info = b.Context(None).decode_intra(open(%r, 'rb').read()); sys.stdout.buffer.write(pts.tobytes())"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "frame.bin")))
     for serial in ("", "1"):
-        env = dict(os.environ)
+        env = dict(os.environ, PCC_LIB=DEV_LIB)   # (the switch exists in the developer build only: csrc/pcc_dev.h)
         env.pop("PCC_DECODE_SERIAL", None)
         if serial:
             env["PCC_DECODE_SERIAL"] = serial
@@ -341,7 +371,7 @@ def test_normalize_group_matches_numpy(pkg):
     sizes = (C.c_size_t * 1)(len(a))
     mn = np.zeros(3, np.float32)
     mx = np.zeros(3, np.float32)
-    assert lib.pcc_normalize_group(ptrs, sizes, 1, 0.2, mn.ctypes.data, mx.ctypes.data) == 0
+    assert lib.pcc_normalize_group_boxes(ptrs, sizes, 1, 0.2, mn.ctypes.data, mx.ctypes.data, None) == 0
     assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2) and a.tobytes() == ref.tobytes()
     assert lib.pcc_restore_scaling(a.ctypes.data, len(a), mn.ctypes.data, mx.ctypes.data) == 0
     for ax in "xyz":

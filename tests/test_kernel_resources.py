@@ -33,12 +33,12 @@ def test_no_kernel_spills(resources):
 
 @pytest.mark.parametrize("kernel,vgprs,lds,scratch", [
     # two 512-thread workgroups per CU (four waves per SIMD): at most 128 registers, two tiles' LDS within 160 KB
-    ("k_sort_pass<512, 8, false, true>", 128, 64 * 1024, 0),
-    ("k_sort_pass<1024, 4, false, true>", 128, 88 * 1024, 0),
-    ("k_leaf_scan<512, 8, false, false>", 128, 4 * 1024, 0),
+    ("k_sort_pass<512, 8, false>", 128, 64 * 1024, 0),
+    ("k_sort_pass<1024, 4, false>", 128, 88 * 1024, 0),
+    ("k_leaf_scan<512, 8, false>", 128, 4 * 1024, 0),
     # three workgroups of 512 threads per CU (six waves per SIMD): at most 80 registers and 53 KB of LDS
     ("k_leaf_tile<false>", 80, 53 * 1024, 16),
-    # fused keys: 1024 resident 256-thread workgroups = four per CU = four waves per SIMD: at most 128 registers
+    # the streaming workgroups are 256 threads wide: four and more per CU
     ("k_boxes_events", 128, 32 * 1024, 16),
     # the one-workgroup-per-tile key maker streams the cloud: two 1024-thread workgroups per CU need at most 64 registers
     ("k_make_keys<1024, 4>", 64, 24 * 1024, 0),

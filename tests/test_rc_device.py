@@ -62,9 +62,9 @@ def entropy_batch_and_pipeline(pkg, oracle, lanes):
     b = pkg.binding
     lib = b.load_library()
     ctx = b.Context(0)
-    ctx.set_option("rc_device_lanes", lanes)
     batch = lib.pcc_entropy_batch_create(0, 64)
     assert batch
+    assert lib.pcc_entropy_batch_set_option(batch, b"rc_device_lanes", lanes) == 0   # the form of the coder this batch's flushes launch
     cases = [dict(octree_bits=8, color_coding_type=1, jpeg_quality=85), dict(octree_bits=8, color_coding_type=0, color_bits=6, keep_centroid=1),
              dict(octree_bits=7, color_coding_type=2, jpeg_quality=50), dict(octree_bits=7, color_coding_type=3, keep_centroid=1),
              dict(octree_bits=9, color_bits=0), dict(octree_bits=8, color_coding_type=1, jpeg_quality=30, keep_centroid=1)]
@@ -104,6 +104,8 @@ def entropy_batch_and_pipeline(pkg, oracle, lanes):
     pipe = b.Pipeline(0, workers=2)
     try:
         pipe.set_option("entropy_on_gpu", 1)
+        pipe.set_option("rc_device_lanes", lanes)
+        assert pipe.get("rc_device_lanes") == lanes
         pipe.set_option("entropy_gpu_batch", 4)   # several flushes per thread and a partial one at the end
         for rep in range(2):
             got = pipe.encode_host(frames, b.make_params(frame_id=2, **kw))
@@ -137,6 +139,3 @@ def entropy_batch_and_pipeline(pkg, oracle, lanes):
         assert all(len(got[k][0]) == len(got[k % 3][0]) for k in range(len(many)))
     finally:
         pipe.close()
-        c2 = b.Context(0)
-        c2.set_option("rc_device_lanes", 0)
-        c2.close()

@@ -1,12 +1,16 @@
-"""The forms of the kernels that are OFF by default until an MI355X has timed them, each still held against the oracle: this
-file sorts behind every other test file on purpose -- `pytest -x` on the GPU box reaches it last, so a form that has never run
-on the chip cannot stop the tests of the default forms from being run and counted.
+"""Forms that are OFF by default until an MI355X has timed them, each still held against the oracle: this file sorts behind
+every other test file on purpose -- `pytest -x` on the GPU box reaches it last, so a form that has never run on the chip cannot
+stop the tests of the default forms from being run and counted.
 
-  * the hot path's optional forms (fused front end and its fallback, XCD-aware sort tickets, the two sort experiments, round
-    2's probe layout): child processes, because the switches are read once per process
-  * the device range coder with one LANE per stream (option "rc_device_lanes"; the default is one wave per stream)
+  * round 2's layouts of k_leaf_tile (evenly spaced first probes of the parent search, block row = blockIdx) and a forced
+    workgroup shape of the sort: developer switches of csrc/pcc_dev.h, so the child processes load the developer build
+    (libpcc_hip_dev.so; the shipped library reads no such switch)
+  * the device range coder with one LANE per stream (option "rc_device_lanes" of a context, a batch, a pipeline; the default is
+    one wave per stream)
   * the pipeline's entropy threads coding sixteen frames per call instead of four (PCC_PIPELINE_BATCH=16: the host range coder's
     AVX-512 path)
+(The fused front end, the XCD-aware sort tickets and the two sort experiments of rounds 3-4 left the product in round 5:
+branch experiments/r04-optin-forms, built as libpcc_hip_r04x.so for the A/B of a GPU session.)
 """
 import os
 import subprocess
@@ -16,35 +20,41 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env", [{"PCC_FUSED_KEYS": "1"}, {"PCC_FUSED_KEYS": "1", "PCC_PLAN_SPINS": "1"}, {"PCC_LEAF_PROBES": "uniform"}, {"PCC_SORT_XCD": "16"},
-                                 {"PCC_SORT_XCD": "3"}, {"PCC_SORT_BARE": "1"}, {"PCC_SORT_LOCAL": "1"}, {"PCC_SORT_LOCAL": "1", "PCC_SORT_SHAPE": "wide"}])
-def test_optional_forms_of_the_hot_path_give_the_same_bytes(env):
-    """The clouds of test_gpu_parity.py with fused mode switched on (the default is the two-kernel form), with every wait for the plan running
-    out (all chunks fall back to k_make_keys), and with the parent search of k_leaf_tile on evenly spaced first probes (round
-    2's layout; the default spaces them geometrically back from the tile), and with the sort passes' tiles handed out in
-    XCD-aware chunks of sixteen or three tiles (the default is one ticket counter, round 2's form), and with the payload-free sort passes enqueued first (an
-    experiment: frames whose keys carry a payload are sent back once), and with the local fix-up of the low code bits in the
-    leaf scan (an experiment that saves a sort pass: three passes for the headline frame; a frame with a group of equal
-    high bits too long for it is sent back once; with the wide kernel shape forced, which the experiment does not exist in, it
-    must quietly stay off): child processes, because the switches are read once."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "fused_keys_read or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points or cfg3_capture or cfg2_1m_depth10_surface or crowded_voxels"],
-                       cwd=root, env=e, capture_output=True, text=True, timeout=1800)
-    # with the mode off / all chunks timing out the fused-chunk counters of the first test do not hold: it is told so
+def dev_library():
+    """the developer build of the library under test: libpcc_hip_dev.so beside libpcc_hip.so; the CPU executor's builds (tests/emu)
+    read the switches themselves"""
+    cur = os.environ.get("PCC_LIB")
+    if cur:
+        return cur
+    return os.path.join(ROOT, "cwi-pcl-codec_amd", "libpcc_hip_dev.so")
+
+
+@pytest.mark.parametrize("env", [{"PCC_LEAF_PROBES": "uniform"}, {"PCC_LEAF_ROWS": "linear"}, {"PCC_SORT_SHAPE": "wide"}, {"PCC_SORT_SHAPE": "narrow"}],
+                         ids=lambda e: "_".join("%s=%s" % kv for kv in e.items()))
+def test_developer_forms_of_the_hot_path_give_the_same_bytes(env):
+    """The clouds of test_gpu_parity.py with the parent search of k_leaf_tile on evenly spaced first probes (round 2's layout;
+    the default spaces them geometrically back from the tile), with its block rows in blockIdx order (round 2's; the default
+    gives every XCD one contiguous range), and with the sort passes and the leaf scan forced into ONE workgroup shape for every
+    frame size (the default picks 1024 x 4 up to 96 tiles, 512 x 8 beyond): child processes on the developer build, because the
+    switches are read once."""
+    lib = dev_library()
+    if not os.path.exists(lib):
+        pytest.skip("no developer build here (make -C cwi-pcl-codec_amd/csrc dev)")
+    e = dict(os.environ, PCC_LIB=lib, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        "-k", "every_key_layout or random_sweep or test_modes_bitstream or cfg1_100k or growth or nan_points or cfg3_capture or cfg2_1m_depth10_surface or crowded_voxels"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.fixture(scope="module")
 def lanes_ctx(pkg):
     c = pkg.binding.Context(0)
-    c.set_option("rc_device_lanes", 1)   # process-wide
+    c.set_option("rc_device_lanes", 1)   # (of this context: pcc_device_range_encode through it launches the lane form)
     yield c
-    c.set_option("rc_device_lanes", 0)
     c.close()
 
 
@@ -78,7 +88,7 @@ def test_pipeline_with_sixteen_frames_per_coder_call(pkg):
     dropped, on two entropy threads: the oracle's bitstreams, from host memory and from device memory.  A child process (the
     batch size is read when the pipeline is made)."""
     import textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = ROOT
     code = textwrap.dedent("""
         import sys
         sys.path.insert(0, %r)
@@ -96,7 +106,7 @@ def test_pipeline_with_sixteen_frames_per_coder_call(pkg):
             ref.append(b"" if r is None else r.bitstream); fid += 0 if r is None else 1
         pipe = b.Pipeline(0, workers=2)
         try:
-            assert pipe.n_contexts >= 2 * 16
+            assert pipe.n_contexts >= 2 * 16 and pipe.get("frames_per_coder_call") == 16
             for rep in range(2):
                 got = pipe.encode_host(frames, b.make_params(frame_id=3, **kw))
                 assert [g[0] for g in got] == ref

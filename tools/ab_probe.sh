@@ -1,22 +1,23 @@
 #!/bin/bash
-# A/B of one environment knob -- or of two builds of the library: VAR=PCC_LIB, values = paths -- : the parity subset with
-# EVERY setting (a rebuilt library is a different program), then lone-frame latency and the saturated GPU stage for both
-# settings, twice; both timing tools hold every frame they time against the oracle's golden digests.
-#   bash tools/ab_probe.sh <tag> <VAR> <value-A> <value-B> [workload]
-TAG=$1; VAR=$2; A=$3; B=$4; WL=${5:-cfg2}
+# A/B of two settings on one box -- each a list of KEY=value pairs for the environment, e.g. two builds of the library
+# ("PCC_LIB=.../libpcc_hip.so" against "PCC_LIB=.../libpcc_hip_r02.so") or one developer build with and without a switch --:
+# the parity subset with EVERY setting (another library is another program), then lone-frame latency and the saturated GPU
+# stage for both settings, alternating, twice; both timing tools hold every frame they time against the oracle's golden digests.
+#   bash tools/ab_probe.sh <tag> "<setting A>" "<setting B>" [workload]
+TAG=$1; A=$2; B=$3; WL=${4:-cfg2}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+name() { echo "$1" | sed 's|[^ ]*/||g; s/[ =]/_/g'; }
 for v in "$A" "$B"; do
-  if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
-  L=$OUT/pytest_$(basename "$v").log
-  python -m pytest tests/test_gpu_parity.py tests/test_codec_golden.py -m gpu -x -q > $L 2>&1; echo "$VAR=$v pytest rc=$?" | tee -a $L
+  L=$OUT/pytest_$(name "$v").log
+  env $v python -m pytest tests/test_gpu_parity.py tests/test_codec_golden.py -m gpu -q --timeout 900 > $L 2>&1; echo "[$v] pytest rc=$?" | tee -a $L
   tail -2 $L
 done
 for v in "$A" "$B" "$A" "$B"; do
-  if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
-  python tools/gpu_latency.py $WL 30 > $OUT/latency_${WL}_$(basename "$v").txt 2>&1
-  echo "== $VAR=$v"; grep -A9 "profiling=2" $OUT/latency_${WL}_$(basename "$v").txt | grep -v "^   (" | head -10
-  grep "profiling=0" $OUT/latency_${WL}_$(basename "$v").txt
-  python tools/gpu_throughput.py $WL 12 2>&1 | tee -a $OUT/thr_${WL}_$(basename "$v").txt | tail -3
+  N=$(name "$v")
+  env $v python tools/gpu_latency.py $WL 30 > $OUT/latency_${WL}_$N.txt 2>&1
+  echo "== [$v]"; grep -A9 "profiling=2" $OUT/latency_${WL}_$N.txt | grep -v "^   (" | head -10
+  grep "profiling=0" $OUT/latency_${WL}_$N.txt
+  env $v python tools/gpu_throughput.py $WL 12 2>&1 | tee -a $OUT/thr_${WL}_$N.txt | tail -3
 done

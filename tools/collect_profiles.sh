@@ -1,8 +1,8 @@
 #!/bin/bash
 # After a GPU session: copy the summaries of gpurun_out/<tag>/ (scratch, untracked) that are quoted as evidence into
 # profiles/ under the round's name, so that nothing judged depends on a scratch directory.  (CPU; no GPU needed.)
-#   bash tools/collect_profiles.sh <tag> [<round prefix, default r04>]
-TAG=${1:?usage: collect_profiles.sh <tag> [prefix]}; P=${2:-r04}
+#   bash tools/collect_profiles.sh <tag> [<round prefix, default r05>]
+TAG=${1:?usage: collect_profiles.sh <tag> [prefix]}; P=${2:-r05}
 S=gpurun_out/$TAG; D=profiles
 [ -d $S ] || { echo "no $S"; exit 1; }
 cpif() { [ -s "$1" ] && cp "$1" "$2" && echo "  $2"; }
@@ -18,7 +18,6 @@ for WL in cfg2 cfg4; do
   cpif $S/pmc_$WL/hbm_traffic_$WL.json          $D/${P}_hbm_traffic_$WL.json
 done
 cpif $S/pmc_cfg2_12frames/hbm_traffic_cfg2.json $D/${P}_hbm_traffic_cfg2_12_distinct_frames.json
-cpif $S/pmc_cfg2_fused/hbm_traffic_cfg2.json    $D/${P}_hbm_traffic_cfg2_fused_keys.json
 cpif $S/bench_kernel_stats.txt                  $D/${P}_bench_kernel_stats.txt
 cpif $S/rc_device_speed.txt                     $D/${P}_rc_device_speed.txt
 cpif $S/rc_many.txt                             $D/${P}_rc_many_host_coder.txt

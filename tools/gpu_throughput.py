@@ -33,15 +33,4 @@ for T in threads:
         list(ex.map(work, range(T)))            # warm-up
         t = time.perf_counter(); list(ex.map(work, range(T))); dt = time.perf_counter() - t
     print("%s: %2d streams: %.1f frames/s  (%.1f us per frame, %.0f Mpoints/s)" % (wl, T, K / dt, dt / K * 1e6, K * n / dt / 1e6))
-    # fused keys under load: how many chunks of each context's LAST frame were keyed by the streaming workgroups of
-    # k_boxes_events, how many were left to k_make_keys because their wait for the plan ran out (grid not resident as a whole)
-    import ctypes as C
-    lib = b.load_library()
-    lib.pcc_debug_fused_chunks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
-    fused = left = 0
-    for c in ctxs:
-        o = (C.c_uint32 * 3)()
-        if lib.pcc_debug_fused_chunks(c.h, o) == 0 and o[2]:
-            fused += o[0]; left += o[1] - o[0]
-    print("    fused keys, last frame of every stream: %d chunks keyed in k_boxes_events, %d left to k_make_keys" % (fused, left))
     for c in ctxs: c.close()
