@@ -1647,12 +1647,33 @@ struct Reader {
 }  // namespace
 
 
-// How many symbols `coded` bytes of a range-coded vector can hold at most: a symbol costs at least -log2((65535 - 255) / 65535)
-// = 0.0056 bits (the table total stays below 2^16 and every absent symbol still has count 1), i.e. fewer than 1424 symbols per
-// byte.  A count in a frame header beyond that is a corrupt or hostile stream -- refused before anything is allocated for it.
-// (Round 3's guard allowed 64 symbols per byte; a frame of coincident points -- 64 k voxels, every centroid byte the same:
-// 192 k symbols in 1.2 KB -- is valid and was refused.  Found by tools/fuzz_executor.py.)
-static inline bool plausible_symbol_count(uint64_t n, size_t coded) { return n <= (uint64_t)coded * 1424u + 4096u; }
+// How many symbols the range-coded vector at `in` (its 257-entry cumulative table, then the coded bytes) can hold at most --
+// asked BEFORE the output is allocated, because the count comes from a header a hostile stream controls.  The coder starts
+// with a range of 2^32, every symbol narrows it by at least the symbol's share of the table and every coded byte widens it
+// by 2^8: n symbols of at least b bits each need n * b <= 8 * coded bytes + 32.  b comes from the stream's OWN table (the
+// widest symbol over the total), which is read before anything else anyway; a table whose total is 0 or beyond 2^16 (the
+// encoder halves its table below that), that is not non-decreasing, or in which one symbol takes everything (every symbol
+// has width 1 at least: a symbol then costs 0.0056 bits or more, 1424 symbols per byte at most) is not the encoder's.
+// (Round 3's guard allowed 64 symbols per byte whatever the table: a frame of coincident points -- 64 k voxels, every
+// centroid byte the same: 192 k symbols in 1.2 KB -- is valid and was refused; round 4's allowed 1424 per byte whatever the
+// table.  With the table's own bound a stream has to BE that skewed to claim that many symbols.)
+static bool plausible_symbol_count(uint64_t n, const uint8_t* in, size_t in_len) {
+  if (n == 0) return true;
+  uint32_t freq[257];
+  if (in_len < sizeof(freq) + 4) return false;
+  memcpy(freq, in, sizeof(freq));
+  const uint32_t total = freq[256];
+  if (total == 0 || total > 65536u || freq[0] != 0) return false;
+  uint32_t widest = 0;
+  for (int k = 0; k < 256; ++k) {
+    if (freq[k + 1] < freq[k]) return false;
+    widest = std::max(widest, freq[k + 1] - freq[k]);
+  }
+  if (widest >= total) return false;
+  const double bits = -log2((double)widest / (double)total);
+  const double room = 8.0 * (double)(in_len - sizeof(freq)) + 64.0;
+  return (double)n <= room / bits + 1.0;
+}
 
 int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, FrameStreams& fs, bool colours_too,
                          const std::function<void()>& after_occupancy) {
@@ -1704,7 +1725,9 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   }
 
   uint64_t occ_n = 0;
-  if (!r.get(occ_n) || !plausible_symbol_count(occ_n, r.len - r.pos)) return PCC_ERR_STREAM;
+  // (a leaf opens at most one branch node per level: a count beyond that is not a voxel-grid frame's; 2^40 voxels: no overflow below)
+  if (count >= (1ull << 40)) return PCC_ERR_STREAM;
+  if (!r.get(occ_n) || occ_n > count * (uint64_t)std::max(info.depth, 1u) || !plausible_symbol_count(occ_n, r.p + r.pos, r.len - r.pos)) return PCC_ERR_STREAM;
   Bytes& occ = fs.occ;
   occ.resize((size_t)occ_n);
   size_t used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, occ.data(), occ.size());
@@ -1718,7 +1741,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   cen.clear();
   if (p.do_voxel_centroid) {
     uint32_t n = 0;
-    if (!r.get(n) || !plausible_symbol_count(n, r.len - r.pos)) return PCC_ERR_STREAM;
+    if (!r.get(n) || (uint64_t)n != 3u * count || !plausible_symbol_count(n, r.p + r.pos, r.len - r.pos)) return PCC_ERR_STREAM;   // (three bytes per voxel, impl.hpp:1706)
     cen.resize(n);
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, cen.data(), cen.size());
     if (!used) return PCC_ERR_STREAM;
@@ -1729,7 +1752,7 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   fs.payload.clear();
   if (with_color) {
     uint64_t n = 0;
-    if (!r.get(n) || !plausible_symbol_count(n, r.len - r.pos)) return PCC_ERR_STREAM;
+    if (!r.get(n) || !plausible_symbol_count(n, r.p + r.pos, r.len - r.pos)) return PCC_ERR_STREAM;
     Bytes& payload = fs.payload;
     payload.resize((size_t)n);
     used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, payload.data(), payload.size());

@@ -78,7 +78,7 @@ struct pcc_pipeline {
   // goes to the GPU.  Both constants are round-2 figures of one box; auto stays opt-in until they are calibrated where
   // the pipeline runs (option "entropy_on_gpu", PCC_PIPELINE_ENTROPY=host|gpu|auto)
   int entropy_mode = 0;
-  size_t pin_cores_taken = 0;  // of g_pin_cores_taken, given back when the pipeline is destroyed
+  size_t pin_start = 0, pin_cores_taken = 0;  // this pipeline's range in g_pin_ranges, given back when the pipeline is destroyed
   int gpu_batch = 256;
   bool rc_lanes = false;  // option "rc_device_lanes": the form of the device range coder the entropy threads' batches launch
   std::vector<pcc_entropy_batch*> batches;  // one per entropy thread, made on first use
@@ -439,7 +439,32 @@ struct pcc_pipeline {
 static thread_local int pin_offset_hint = 0, pin_span_hint = 0;
 // cores handed to the entropy threads of earlier pipelines of this process: a pipeline created without a range of its own
 // (no hint, no PCC_PIPELINE_PIN_OFFSET) starts behind them, so two plain pcc_pipeline_create calls do not pin to the same cores
-static std::atomic<size_t> g_pin_cores_taken{0};
+// Which positions of a process's core range the entropy threads of its live pipelines sit on: [start, start + len) each, in any
+// order of creation and destruction (a bump counter that pipelines decrement is only right when they die in LIFO order: create A
+// and B, destroy A, create C -- C landed on B's cores, the half-speed case the pinning exists to avoid, while A's sat idle).
+static std::mutex g_pin_mu;
+static std::vector<std::pair<size_t, size_t>> g_pin_ranges;
+// the lowest free stretch of `len` positions inside [0, span); if the span is full, behind everything taken so far, wrapping
+static size_t pin_take(size_t len, size_t span) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  std::vector<std::pair<size_t, size_t>> taken = g_pin_ranges;
+  std::sort(taken.begin(), taken.end());
+  size_t at = 0, total = 0;
+  bool found = false;
+  for (const auto& r : taken) {
+    if (!found && r.first >= at + len) found = true;
+    if (!found) at = std::max(at, r.first + r.second);
+    total += r.second;
+  }
+  if (!found && at + len > span) at = total % std::max<size_t>(span, 1);
+  g_pin_ranges.emplace_back(at, len);
+  return at;
+}
+static void pin_give_back(size_t start, size_t len) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  for (size_t i = 0; i < g_pin_ranges.size(); ++i)
+    if (g_pin_ranges[i].first == start && g_pin_ranges[i].second == len) { g_pin_ranges.erase(g_pin_ranges.begin() + (long)i); return; }
+}
 
 static std::vector<int> one_cpu_per_core() {
   std::vector<int> out;
@@ -547,7 +572,7 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) base = (size_t)std::max(atoi(o), 0);
     else if (pin_span_hint == 0 && mode) {
       p->pin_cores_taken = (size_t)p->n_entropy * per;
-      start = g_pin_cores_taken.fetch_add(p->pin_cores_taken) % span;
+      start = p->pin_start = pin_take(p->pin_cores_taken, span);
     }
     if (mode && !cores.empty()) {
       for (int w = 0; w < p->n_entropy; ++w) {
@@ -574,7 +599,7 @@ void pcc_pipeline_destroy(pcc_pipeline* p) {
   pcc_upload_lane_destroy(p->lane);
   for (pcc_stream* st : p->gpu_streams) pcc_stream_destroy(st);
   free(p->arena);
-  if (p->pin_cores_taken) g_pin_cores_taken.fetch_sub(p->pin_cores_taken);  // the next pipeline of this process may have them
+  if (p->pin_cores_taken) pin_give_back(p->pin_start, p->pin_cores_taken);  // the next pipeline of this process may have them
   delete p;
 }
 

@@ -68,10 +68,16 @@ class OctreePointCloudCodecV2 {
                           bool doVoxelGridCentroid_arg = true, bool createScalableStream_arg = true,
                           bool codeConnectivity_arg = false, int jpeg_quality_arg = 75, int num_threads = 0)
       : show_statistics_(showStatistics_arg), frame_id_(0) {
+    // What constructs is what the evaluation app passes (eval.hpp:377-395): MANUAL_CONFIGURATION, voxel-grid downsampling on,
+    // iFrameRate 0.  The reference's OWN default arguments (codec.h:108-112: a PCL profile, downsampling off) select PCL's
+    // profile table and the point-detail tail of the bitstream (impl.hpp:1728-1757), neither of which is built here: refused,
+    // before any device is touched, rather than coded differently from the reference.
     if (compressionProfile_arg != MANUAL_CONFIGURATION)
-      throw std::invalid_argument("OctreePointCloudCodecV2: only MANUAL_CONFIGURATION is supported (eval.hpp:379)");
+      throw std::invalid_argument("OctreePointCloudCodecV2 (libpcc_hip): only MANUAL_CONFIGURATION is supported -- PCL's compression "
+                                  "profiles, the reference's default first argument included, are not built (eval.hpp:379 passes MANUAL_CONFIGURATION)");
     if (!doVoxelGridDownDownSampling_arg || iFrameRate_arg != 0)
-      throw std::invalid_argument("OctreePointCloudCodecV2: voxel-grid intra coding only (eval.hpp:385-386)");
+      throw std::invalid_argument("OctreePointCloudCodecV2 (libpcc_hip): only doVoxelGridDownDownSampling = true with iFrameRate = 0 is "
+                                  "supported -- the point-detail stream (impl.hpp:1728-1757) is not built (eval.hpp:385-386 passes true, 0)");
     (void)num_threads;
     memset(&prm_, 0, sizeof(prm_));
     prm_.octree_resolution = octreeResolution_arg;

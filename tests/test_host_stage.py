@@ -410,6 +410,35 @@ def test_decoder_accepts_streams_that_compress_a_thousandfold(pkg, oracle):
     struct.pack_into("<Q", stream, hdr, 1 << 40)
     with pytest.raises(b.PccError):
         host.decode_intra(bytes(stream))
+    # ... and the bound is the stream's OWN table's (the widest symbol over the total gives the bits a symbol costs at least),
+    # not a constant: this frame's occupancy table is nowhere near one symbol taking everything, so a count a few times the
+    # true one is already more than its coded bytes can hold -- refused, although 1424 symbols per byte would allow it
+    freq = struct.unpack_from("<257I", stream, hdr + 8)
+    widest, total = max(freq[k + 1] - freq[k] for k in range(256)), freq[256]
+    bits = -np.log2(widest / total)
+    n_points, = struct.unpack_from("<Q", stream, at + 7)
+    depth = info["depth"]
+    bound = (8 * (r.perf[0] - 1028) + 64) / bits + 1          # symbols the coded occupancy bytes can hold by their own table
+    claim = int(bound) + 100
+    # more than the stream really holds, fewer than "one branch node per level and voxel", far fewer than 1424 per byte would allow
+    assert n_occ <= bound and n_occ < claim <= n_points * depth and claim < 1424 * (r.perf[0] - 1028)
+    struct.pack_into("<Q", stream, hdr, claim)
+    with pytest.raises(b.PccError):
+        host.decode_intra(bytes(stream))
+    # a table in which one symbol takes everything costs nothing per symbol and could claim any count: not the encoder's, refused
+    struct.pack_into("<Q", stream, hdr, n_occ)
+    struct.pack_into("<257I", stream, hdr + 8, *([0] * 200 + [1000] * 57))
+    with pytest.raises(b.PccError):
+        host.decode_intra(bytes(stream))
+    # the centroid stream holds three bytes per voxel, exactly
+    stream = bytearray(r.bitstream)
+    occ_coded = r.perf[0]
+    cen_at = hdr + 8 + occ_coded
+    n_cen, = struct.unpack_from("<I", stream, cen_at)
+    assert n_cen == 3 * n_points
+    struct.pack_into("<I", stream, cen_at, n_cen + 3)
+    with pytest.raises(b.PccError):
+        host.decode_intra(bytes(stream))
 
 
 def test_host_decoder_accepts_the_2048_wide_strip_a_reference_encoder_writes(pkg, oracle):

@@ -45,6 +45,55 @@ def test_header_keeps_the_reference_defaults():
     assert "throw std::logic_error" not in src
 
 
+def test_what_the_constructor_refuses_and_what_it_says(tmp_path):
+    """The boundary's one residual, pinned: the class constructs with what the evaluation app passes (eval.hpp:377-395:
+    MANUAL_CONFIGURATION, voxel-grid downsampling, iFrameRate 0) and with nothing else.  The reference's own default-argument
+    constructor (codec.h:108-121: MED_RES_ONLINE_COMPRESSION_WITH_COLOR, downsampling off) and a manual configuration without
+    downsampling -- legal against the reference, where they select PCL's profile table and the point-detail stream
+    (impl.hpp:1728-1757) -- throw std::invalid_argument with these texts, before any device is looked for (so: on the CPU too)."""
+    src = tmp_path / "ctor.cpp"
+    src.write_text(r'''
+        #include <pcl/cloud_codec_v2/point_cloud_codec_v2.h>
+        #include <cstdio>
+        typedef pcl::io::OctreePointCloudCodecV2<pcl::PointXYZRGB> Codec;
+        template <class F> static void attempt(const char* what, F make) {
+          try { make(); std::printf("%s: constructed\n", what); }
+          catch (const std::invalid_argument& e) { std::printf("%s: invalid_argument: %s\n", what, e.what()); }
+          catch (const std::runtime_error& e) { std::printf("%s: runtime_error: %s\n", what, e.what()); }
+        }
+        int main() {
+          attempt("default arguments", [] { Codec c; });
+          attempt("a PCL profile", [] { Codec c(pcl::io::LOW_RES_ONLINE_COMPRESSION_WITHOUT_COLOR); });
+          attempt("manual, no downsampling", [] { Codec c(pcl::io::MANUAL_CONFIGURATION, false, 0.001, 0.01, false); });
+          attempt("manual, an I-frame rate", [] { Codec c(pcl::io::MANUAL_CONFIGURATION, false, 0.001, 0.01, true, 30); });
+          attempt("what the app passes", [] { Codec c(pcl::io::MANUAL_CONFIGURATION, false, 1.0 / 4096, 1.0 / 1024, true, 0, true, 8, 1, false, false, false, 75, 0); });
+          return 0;
+        }
+    ''')
+    exe = str(tmp_path / "ctor")
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "cwi-pcl-codec_amd", "shim"), "-I", os.path.join(ROOT, "include"),
+           str(src), "-o", exe, "-L", os.path.dirname(LIB), "-lpcc_hip", "-Wl,-rpath," + os.path.dirname(LIB)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env).stdout.splitlines()
+    profile = ("invalid_argument: OctreePointCloudCodecV2 (libpcc_hip): only MANUAL_CONFIGURATION is supported -- PCL's compression profiles, the "
+               "reference's default first argument included, are not built (eval.hpp:379 passes MANUAL_CONFIGURATION)")
+    detail = ("invalid_argument: OctreePointCloudCodecV2 (libpcc_hip): only doVoxelGridDownDownSampling = true with iFrameRate = 0 is supported -- "
+              "the point-detail stream (impl.hpp:1728-1757) is not built (eval.hpp:385-386 passes true, 0)")
+    assert out[0] == "default arguments: " + profile
+    assert out[1] == "a PCL profile: " + profile
+    assert out[2] == "manual, no downsampling: " + detail
+    assert out[3] == "manual, an I-frame rate: " + detail
+    # the app's own arguments get past the checks: a codec object with a GPU, "no usable device" without one -- never an argument error
+    assert out[4] in ("what the app passes: constructed",
+                      "what the app passes: runtime_error: OctreePointCloudCodecV2: no usable MI355X/HIP device (there is no CPU fallback)")
+    # ... and INTEGRATION.md says so on its first screen
+    first_screen = open(os.path.join(ROOT, "INTEGRATION.md")).read()[:3000]
+    assert "MANUAL_CONFIGURATION" in first_screen and "throws" in first_screen and "codec.h:108-121" in first_screen
+
+
 @pytest.mark.gpu
 def test_reference_call_patterns_run(tmp_path):
     exe = _build(tmp_path, "c++11")
