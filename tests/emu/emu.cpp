@@ -333,83 +333,6 @@ void run_workgroup(Worker* w) {
   }
 }
 
-// ------------------------------------------------------------------ traffic model (PCC_EMU_TRAFFIC=1, libpcc_emu_traffic.so)
-// The .hip sources of that build are compiled with outline memory-access instrumentation (gcc -fsanitize=kernel-address
-// with a call threshold of 0: every load and store calls __asan_loadN_noabort / __asan_storeN_noabort), and the callbacks
-// below -- not a sanitizer: a counter -- book every access that falls into "device memory" (hipMalloc hands out pieces of
-// one arena in this mode) on the launch in flight:
-//   requested bytes           what the lanes asked for (what an ideal cache hierarchy would still have to deliver to them)
-//   first-touch line bytes    128-byte lines touched for the first time in this launch by workgroups of one XCD
-//                             (workgroup b runs on XCD b mod 8, each XCD has an L2 of its own): what must come in from
-//                             beyond the L2s at least -- a lower bound of what FETCH_SIZE / WRITE_SIZE count, with L2s of
-//                             unlimited size and nothing left in them from the launch before
-// It is a MODEL of the access pattern as written, for comparing two forms of a kernel without a GPU; it knows nothing of
-// capacity misses, the Infinity Cache, write combining or timing.
-struct Traffic {
-  bool on = false;
-  char* lo = nullptr;
-  char* hi = nullptr;
-  std::atomic<size_t> bump{0};
-  uint16_t* seen_load = nullptr;   // [8 XCDs][lines]: launch number (low 16 bits) that touched the line last
-  uint16_t* seen_store = nullptr;
-  size_t lines = 0;
-  uint16_t launch = 0;
-  struct Rec { std::string name; uint64_t launches = 0, req_load = 0, req_store = 0, line_load = 0, line_store = 0; };
-  std::mutex mu;
-  std::vector<Rec> recs;
-  std::atomic<uint64_t> cur[4];    // of the launch in flight: requested load / store bytes, first-touch load / store lines
-  static constexpr size_t kArena = (size_t)12 << 30;
-  void init() {
-    const char* e = getenv("PCC_EMU_TRAFFIC");
-    on = e && e[0] == '1';
-    if (!on) return;
-    lo = (char*)mmap(nullptr, kArena, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (lo == MAP_FAILED) { perror("traffic arena"); abort(); }
-    hi = lo + kArena;
-    lines = kArena / 128;
-    seen_load = (uint16_t*)mmap(nullptr, lines * 8 * 2, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    seen_store = (uint16_t*)mmap(nullptr, lines * 8 * 2, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    for (auto& c : cur) c.store(0);
-  }
-  void* alloc(size_t bytes) {
-    const size_t need = (bytes + 4095) & ~(size_t)4095;
-    const size_t at = bump.fetch_add(need);
-    if (at + need > kArena) { fprintf(stderr, "wave64 executor: traffic arena exhausted\n"); abort(); }
-    return lo + at;
-  }
-  void begin() {
-    if (++launch == 0) launch = 1;  // (a line last touched exactly 65 535 launches ago would be taken for touched: never in practice)
-    for (auto& c : cur) c.store(0);
-  }
-  void end(const char* name) {
-    std::string n(name);
-    const size_t lt = n.find('<');
-    if (lt != std::string::npos) n.resize(lt);
-    while (!n.empty() && (n[0] == '(' || n[0] == ' ')) n.erase(0, 1);
-    std::lock_guard<std::mutex> lk(mu);
-    Rec* r = nullptr;
-    for (auto& x : recs) if (x.name == n) r = &x;
-    if (!r) { recs.emplace_back(); r = &recs.back(); r->name = n; }
-    ++r->launches;
-    r->req_load += cur[0]; r->req_store += cur[1]; r->line_load += cur[2]; r->line_store += cur[3];
-  }
-};
-Traffic& traffic() {
-  static Traffic* t = [] { Traffic* x = new Traffic(); x->init(); return x; }();
-  return *t;
-}
-inline void traffic_access(uintptr_t a, size_t n, bool store) {
-  Traffic& t = traffic();
-  if (!t.on || a < (uintptr_t)t.lo || a >= (uintptr_t)t.hi) return;
-  Worker* w = tl_worker;
-  if (!w || w->cur < 0) return;  // host code touching device memory (memcpy): not a kernel's traffic
-  t.cur[store ? 1 : 0].fetch_add(n, std::memory_order_relaxed);
-  const size_t xcd = w->block_linear & 7u;
-  uint16_t* seen = (store ? t.seen_store : t.seen_load) + xcd * t.lines;
-  for (size_t line = (a - (uintptr_t)t.lo) >> 7, last = (a + n - 1 - (uintptr_t)t.lo) >> 7; line <= last; ++line)
-    if (__atomic_exchange_n(&seen[line], t.launch, __ATOMIC_RELAXED) != t.launch) t.cur[store ? 3 : 2].fetch_add(1, std::memory_order_relaxed);
-}
-
 // ------------------------------------------------------------------ pool
 // Workgroups are handed out in blockIdx order.  A workgroup that keeps sleeping (it polls for something another
 // workgroup has to produce) while workgroups of the launch are still waiting for a thread asks for one more thread:
@@ -529,7 +452,6 @@ struct Pool {
     if (nt == 0 || nt > (uint64_t)kMaxThreads) { fprintf(stderr, "wave64 executor: %s: %llu threads per workgroup\n", name, (unsigned long long)nt); abort(); }
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return busy == 0; });  // (a worker that woke up late for the launch before)
-    if (traffic().on) traffic().begin();
     if (race::on()) race::launch_begin(name, g.x * g.y * g.z);
     job = &l; kname = name; grid = g; block = b;
     total = g.x * g.y * g.z;
@@ -540,7 +462,6 @@ struct Pool {
     cv_done.wait(lk, [&] { return blocks_done == total && busy == 0; });
     job = nullptr;
     tokens = 0;
-    if (traffic().on) traffic().end(name);
     if (race::on()) race::launch_end();
   }
 };
@@ -555,25 +476,6 @@ Pool& pool() {
 void ask_for_a_thread() { pool().more_threads_please(); }
 
 }  // namespace
-
-// what the traffic model has booked since the last call: one line per kernel name
-extern "C" size_t pcc_emu_traffic_report(char* out, size_t cap) {
-  Traffic& t = traffic();
-  std::string s;
-  std::lock_guard<std::mutex> lk(t.mu);
-  for (auto& r : t.recs) {
-    char line[320];
-    snprintf(line, sizeof(line), "%s %llu %llu %llu %llu %llu\n", r.name.c_str(), (unsigned long long)r.launches, (unsigned long long)r.req_load,
-             (unsigned long long)r.req_store, (unsigned long long)(r.line_load * 128), (unsigned long long)(r.line_store * 128));
-    s += line;
-  }
-  t.recs.clear();
-  if (out && cap) { strncpy(out, s.c_str(), cap - 1); out[cap - 1] = 0; }
-  return s.size();
-}
-void* traffic_alloc(size_t bytes) { return traffic().on ? traffic().alloc(bytes) : nullptr; }
-bool traffic_owns(void* p) { return traffic().on && (char*)p >= traffic().lo && (char*)p < traffic().hi; }
-void traffic_touch(uintptr_t a, size_t n, bool store) { traffic_access(a, n, store); }
 
 uint64_t ballot(int pred, int site) { return yield_lane(site, kCollective, kBallot, (uint64_t)(pred != 0), 0); }
 int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, int site) {
@@ -649,25 +551,13 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
   if (a == hipDeviceAttributeMultiprocessorCount) { *v = 256; return hipSuccess; }
   return hipErrorInvalidValue;
 }
-namespace emu { void* traffic_alloc(size_t bytes); bool traffic_owns(void* p); void traffic_touch(uintptr_t a, size_t n, bool store); }
-// the access callbacks of the instrumented build (see "traffic model" above)
-// (the same callbacks feed the happens-before checker of race.cpp when PCC_EMU_RACE=1: the return address is the access)
+// The `race` build's access callbacks feed the happens-before checker of race.cpp when PCC_EMU_RACE=1 (the return address is the access)
 static inline void emu_touch(uintptr_t a, size_t n, bool store, void* pc) {
   if (emu::race::on()) emu::race::access(a, n, store, pc);
-  else emu::traffic_touch(a, n, store);
 }
-#define PCC_EMU_CB(N) \
-  extern "C" void __asan_load##N##_noabort(uintptr_t a) { emu_touch(a, N, false, __builtin_return_address(0)); } \
-  extern "C" void __asan_store##N##_noabort(uintptr_t a) { emu_touch(a, N, true, __builtin_return_address(0)); }
-PCC_EMU_CB(1) PCC_EMU_CB(2) PCC_EMU_CB(4) PCC_EMU_CB(8) PCC_EMU_CB(16)
-extern "C" void __asan_loadN_noabort(uintptr_t a, size_t n) { emu_touch(a, n, false, __builtin_return_address(0)); }
-extern "C" void __asan_storeN_noabort(uintptr_t a, size_t n) { emu_touch(a, n, true, __builtin_return_address(0)); }
-extern "C" void __asan_handle_no_return() {}
-extern "C" void __asan_before_dynamic_init(const char*) {}
-extern "C" void __asan_after_dynamic_init() {}
-// The `race` build is instrumented by gcc's -fsanitize=thread pass instead (the address sanitizer's pass leaves direct
-// accesses to thread-local variables alone -- every scalar __shared__ variable -- and this one does not): the same idea,
-// these are its callbacks.  libtsan is NOT linked: the checker is race.cpp.  The atomics below are the ones inside the
+// The `race` build is instrumented by gcc's -fsanitize=thread pass (the address sanitizer's outline pass leaves direct
+// accesses to thread-local variables alone -- every scalar __shared__ variable -- and this one does not): these are its
+// callbacks.  libtsan is NOT linked: the checker is race.cpp.  The atomics below are the ones inside the
 // hooks of hip_runtime.h (already booked by the hook; a bare one from a running lane is booked here as agent scope).
 #ifndef PCC_EMU_REAL_TSAN   // (the `tsan` build of the Makefile links the real ThreadSanitizer for the HOST sources: its symbols, not these)
 #define PCC_TSAN_CB(N) \
@@ -712,7 +602,6 @@ extern "C" void __tsan_atomic_signal_fence(int) {}
 
 hipError_t hipMalloc(void** p, size_t bytes) {
   if (void* t = emu::race::arena_alloc(bytes ? bytes : 256)) { memset(t, 0xA5, bytes); *p = t; return hipSuccess; }
-  if (void* t = emu::traffic_alloc(bytes ? bytes : 256)) { memset(t, 0xA5, bytes); *p = t; return hipSuccess; }
   void* q = nullptr;
   if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
   // fresh device memory holds whatever was there before: poison it so that a kernel that relies on zeroes is caught
@@ -720,7 +609,7 @@ hipError_t hipMalloc(void** p, size_t bytes) {
   *p = q;
   return hipSuccess;
 }
-hipError_t hipFree(void* p) { if (!emu::traffic_owns(p) && !emu::race::arena_owns(p)) free(p); return hipSuccess; }  // (the arenas are never reused)
+hipError_t hipFree(void* p) { if (!emu::race::arena_owns(p)) free(p); return hipSuccess; }  // (the checker's arena is never reused)
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
   if (void* t = emu::race::arena_alloc(bytes ? bytes : 256)) { *p = t; return hipSuccess; }  // pinned memory the kernels write has a shadow too
   void* q = nullptr;

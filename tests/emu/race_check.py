@@ -7,7 +7,7 @@ store, atomic and fence of the kernel sources) -- TEST INFRASTRUCTURE, not a mea
 
 Every frame is also held against the oracle (the instrumented build must still give its bytes).  Prints one block per
 distinct report -- kernel, memory space, the two accesses (kind, source line, workgroup, wave), how often -- and exits 1 if
-there is any.  PCC_FUSED_KEYS=1, PCC_PLAN_SPINS=1, PCC_SORT_XCD=16 ... select the forms of the kernels as everywhere else."""
+there is any.  The developer switches of csrc/pcc_dev.h (PCC_LEAF_PROBES=uniform ...) select the forms of the kernels as everywhere else."""
 import ctypes as C
 import os
 import subprocess
