@@ -332,13 +332,24 @@ def main():
         dom_bytes = kernel_algorithmic_bytes(dominant, n_points, L, B, with_color, image_bytes)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         sum_spans = float(sum(span_frame_ms.values()))
-        traffic = traffic_taken = None   # (PMC counters need their own rocprofv3 passes: the figure comes from a file, and says from when)
+        # PMC counters need their own rocprofv3 passes (tools/pmc_run.sh): the figure comes from a file.  It counts as THIS line's
+        # roofline.traffic only if it was taken on the kernel sources this library was built from (the file records their hash);
+        # a figure of other sources -- round 2's, while no GPU session has refreshed it -- is reported beside it, labelled, and
+        # traffic stays null: not a measurement of the run that prints it.
+        traffic = traffic_taken = traffic_of_other_sources = None
         try:
+            import hashlib
             with open(args.traffic_json or os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)) as fh:
                 tj = json.load(fh)
+            with open(os.path.join(ROOT, "cwi-pcl-codec_amd", "csrc", "pcc_kernels.hip"), "rb") as fh:
+                sha_now = hashlib.sha256(fh.read()).hexdigest()[:16]
             if tj.get("workload") == args.workload:
-                traffic = tj.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
-                traffic_taken = tj.get("taken", "a separate rocprofv3 --pmc run (tools/pmc_run.sh)") if traffic is not None else None
+                figure = tj.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
+                taken = tj.get("taken", "a separate rocprofv3 --pmc run (tools/pmc_run.sh)")
+                if figure is not None and tj.get("kernels_sha16") == sha_now:
+                    traffic, traffic_taken = figure, taken
+                elif figure is not None:
+                    traffic_of_other_sources = {"hbm_bytes_per_launch": figure, "taken": taken}
         except (OSError, ValueError):
             pass
         # inside the timed region several frames share the GPU: what the same kernel takes there (HIP events on ONE
@@ -348,6 +359,7 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_taken": traffic_taken,
+            "traffic_of_other_sources": traffic_of_other_sources,
             "kernel_avg_ms": round(dom_ms, 5), "kernel_bytes_per_launch": int(dom_bytes),
             "kernel_launches_per_frame": round(launches[dominant], 2),
             "kernel_span_ms": round(span_ms, 5),

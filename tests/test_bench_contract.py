@@ -80,3 +80,9 @@ def test_two_ranks_started_by_the_bench_itself():
              env={"PCC_BENCH_SHARE_GPU0": "1"})
     assert d["n_gpus"] == 2 and d["steps"] == 48 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["frames_per_gpu"] == 48
+    # every rank's view, so that a flat scaling curve explains itself
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    for r in d["ranks"]:
+        assert r["value"] > 0 and r["gpu_only_mpoints_per_s"] > 0 and r["host_cpus_for_this_rank"] >= 1
+        assert r["host_bound"] == (r["entropy_stage"]["host_frames_per_s_bound"] < r["entropy_stage"]["gpu_stage_frames_per_s"])
+    assert d["host_bound"] == any(r["host_bound"] for r in d["ranks"])

@@ -146,6 +146,10 @@ def test_bench_script_runs_end_to_end_on_the_executor(emu_libs):
                 "data", "config", "roofline", "cpu_baseline", "host_input", "entropy_stage", "host_bound", "ranks", "entropy_coder"):
         assert key in line, key
     assert line["roofline"]["kernel"] == "k_sort_pass" and line["roofline"]["bound"] == "hbm"
+    # the PMC figure in profiles/ was taken on other kernel sources (round 2's): it is not this line's traffic
+    assert line["roofline"]["traffic"] is None
+    other = line["roofline"]["traffic_of_other_sources"]
+    assert other is None or ("taken" in other and other["hbm_bytes_per_launch"] > 0)
     assert line["entropy_stage"]["ran_on"] in ("host", "gpu")
     # the line says what it was produced on: this one, the executor (bench.py refuses it unless it is started through bench_on_executor.py)
     assert line["library"]["file"] == "libpcc_emu.so" and line["library"]["version"].startswith("pcc_emu")

@@ -41,7 +41,13 @@ try:
     built = time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime(os.path.getmtime(lib)))
 except OSError:
     built = "?"
-res = {"workload": workload, "taken": "%s, on the library built %s" % (time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()), built), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/gpu_latency.py; "
+import hashlib  # noqa: E402
+try:   # which kernel sources the counters were taken on: bench.py quotes the figure as roofline.traffic only for the same sources
+    ksrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cwi-pcl-codec_amd", "csrc", "pcc_kernels.hip")
+    kernels_sha16 = hashlib.sha256(open(ksrc, "rb").read()).hexdigest()[:16]
+except OSError:
+    kernels_sha16 = None
+res = {"workload": workload, "kernels_sha16": kernels_sha16, "taken": "%s, on the library built %s" % (time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()), built), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/gpu_latency.py; "
        "bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 correction of MI355X_MICROARCH.md)", "kernels": kernels}
 json.dump(res, open(os.path.join(out_dir, "hbm_traffic_%s.json" % workload), "w"), indent=1)
 print(json.dumps(res, indent=1))
