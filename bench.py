@@ -243,7 +243,7 @@ def main():
                                        ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
     trace("timed region done: %.3f s" % elapsed)
     stats = pipe.stats()
-    entropy_mode_timed = pipe.last_entropy_mode()   # (option "entropy_on_gpu": 0 host, the default; 1 GPU; -1 decided per call from a cost estimate)
+    entropy_mode_timed = pipe.last_entropy_mode()   # (option "entropy_on_gpu": 0 host, the default; 1 GPU)
     ktimes, profiled = pipe.kernel_times()
     for c in prof_ctxs:
         c.set_profiling(False)

@@ -580,7 +580,7 @@ class Pipeline:
             pass
 
     def last_entropy_mode(self):
-        """Where the entropy stage of the last call ran: 0 host, 1 GPU (option "entropy_on_gpu" -1 decides per call)."""
+        """Where the entropy stage of the last call ran: 0 host, 1 GPU (option "entropy_on_gpu")."""
         return self.get("last_entropy_mode")
 
     def get(self, name):

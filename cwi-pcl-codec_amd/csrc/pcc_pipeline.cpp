@@ -72,11 +72,10 @@ struct pcc_pipeline {
   // Opt-in (pcc_pipeline_set_option "entropy_on_gpu"): the range coders run on the GPU, one wave per stream, in batches of
   // `gpu_batch` frames per entropy thread -- for hosts with fewer cores than the GPU stage can feed.
   bool entropy_on_gpu = false;   // what the job at hand uses (decided when the job starts)
-  // 0 (default): the host coders, whose cost on this path has been measured.  1: forced to the GPU.  -1 ("auto"): decided
-  // per call from a cost estimate -- the host coders need ~1.5 ns of one core per symbol, a flush of the device coder
-  // ~110 ns per symbol of its longest stream however many streams it holds: a long call on a host with few cores per GPU
-  // goes to the GPU.  Both constants are round-2 figures of one box; auto stays opt-in until they are calibrated where
-  // the pipeline runs (option "entropy_on_gpu", PCC_PIPELINE_ENTROPY=host|gpu|auto)
+  // 0 (default): the host coders, whose cost on this path has been measured.  1: the device coder -- a deployment choice for
+  // hosts with few cores per GPU (round 2: a flush costs ~110 ns per symbol of its longest stream however many streams it
+  // holds).  Option "entropy_on_gpu", PCC_PIPELINE_ENTROPY=host|gpu.  (Rounds 3-4 had a third setting that decided per call from
+  // a cost estimate with two constants nobody had calibrated; it went with the other unmeasured forms.)
   int entropy_mode = 0;
   size_t pin_start = 0, pin_cores_taken = 0;  // this pipeline's range in g_pin_ranges, given back when the pipeline is destroyed
   int gpu_batch = 256;
@@ -531,7 +530,7 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
   p->batches.assign((size_t)p->n_entropy, nullptr);
   if (const char* e = pcc::dev_env("PCC_RC_DEVICE")) p->rc_lanes = !strcmp(e, "lanes");
-  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_mode = !strcmp(e, "gpu") ? 1 : (!strcmp(e, "host") ? 0 : -1);
+  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_mode = !strcmp(e, "gpu") ? 1 : 0;
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p, w] { p->entropy_thread(w); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
   // threads of one core run at about half speed each, and the scheduler does put them there (20 frames on 16 threads:
@@ -618,7 +617,7 @@ int pcc_pipeline_reserve(pcc_pipeline* p, size_t n_frames, size_t bytes_per_fram
 int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
   if (!p || !name) return PCC_ERR_ARG;
   std::lock_guard<std::mutex> lk(p->mu);  // between jobs: the threads read these when a job starts
-  if (!strcmp(name, "entropy_on_gpu")) p->entropy_mode = value < 0 ? -1 : (value != 0 ? 1 : 0);  // -1: per call, from the cost estimate
+  if (!strcmp(name, "entropy_on_gpu")) p->entropy_mode = value != 0 ? 1 : 0;
   else if (!strcmp(name, "entropy_gpu_batch")) p->gpu_batch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
   else if (!strcmp(name, "rc_device_lanes")) p->rc_lanes = value != 0;
   else if (!strcmp(name, "pack_upload")) { for (pcc_ctx* c : p->ctxs) (void)pcc_set_option(c, "pack_upload", value); }  // host frames: 16 B per point over PCIe
@@ -667,17 +666,7 @@ static int run_job(pcc_pipeline* p, const void* const* dev_frames, const size_t*
     p->job.host_input = host_input;
     {
       // where the entropy stage of this call runs
-      bool on_gpu = p->entropy_mode == 1;
-      if (p->entropy_mode < 0 && mode == 0 && n_frames >= 64) {
-        double pts = 0;
-        for (size_t f = 0; f < n_frames; ++f) pts += (double)n_points[f];
-        const double sym = 1.15 * pts / (double)n_frames;          // occupancy bytes ~ points of a surface, + the colour payload
-        const double threads = (double)std::max(p->n_entropy, 1);
-        const double host_ms = (double)n_frames * sym * 1.5e-6 / threads;
-        const double per_thread = std::ceil((double)n_frames / threads);
-        const double gpu_ms = std::ceil(per_thread / (double)p->gpu_batch) * (sym * 110e-6 + 5.0);
-        on_gpu = host_ms > 2.0 * gpu_ms;
-      }
+      const bool on_gpu = p->entropy_mode == 1;
       p->entropy_on_gpu = on_gpu && mode == 0;
     }
     p->streams.assign(n_frames, std::vector<uint8_t>());

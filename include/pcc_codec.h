@@ -27,7 +27,7 @@
  * coder's harness, pcc_debug_*); a caller of the codec never needs it.
  *
  * Environment: the shipped library reads NINE variables, all of them deployment configuration of pcc_pipeline (none changes
- * an output byte): PCC_PIPELINE_ENTROPY = host | gpu | auto (where the entropy stage runs; default host),
+ * an output byte): PCC_PIPELINE_ENTROPY = host | gpu (where the entropy stage runs; default host),
  * PCC_PIPELINE_GPU_THREADS, PCC_PIPELINE_UPLOAD_THREADS (frames in flight on the GPU / uploads), PCC_PIPELINE_BATCH
  * (frames per coder loop, 1..16, default 4), PCC_PIPELINE_PIN = groups | cores | none with PCC_PIPELINE_PIN_OFFSET and
  * PCC_PIPELINE_PIN_SPAN (core pinning of the entropy threads), and torchrun's LOCAL_RANK / LOCAL_WORLD_SIZE (each rank pins
@@ -205,9 +205,7 @@ void pcc_pipeline_destroy(pcc_pipeline *p);
 /* pipeline knobs (no output byte changes), to be set between calls:
  *   "entropy_on_gpu" 1: the range coders of the entropy stage run on the GPU (pcc_entropy_batch), the entropy threads
  *                 only copy, stitch JPEG rows and assemble -- for hosts with fewer cores than the GPU stage can feed; a flush
- *                 takes ~0.1 s whatever its size.  0 (default): always on the host.  -1 (PCC_PIPELINE_ENTROPY=host|gpu|auto):
- *                 decided per call from a cost estimate (frames, symbols per frame, entropy threads): long calls on hosts
- *                 with few cores per GPU go to the GPU -- opt-in until its two cost constants are calibrated on the box.
+ *                 takes ~0.1 s whatever its size.  0 (default; PCC_PIPELINE_ENTROPY=host|gpu sets it): on the host.
  *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread.
  *   "rc_device_lanes" (default 0): with the entropy stage on the GPU, the device range coder codes one stream per LANE
  *                 instead of one per wave (same bytes; never timed on an MI355X).

@@ -119,23 +119,5 @@ def entropy_batch_and_pipeline(pkg, oracle, lanes):
         pipe.set_option("entropy_on_gpu", 0)
         assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         assert pipe.last_entropy_mode() == 0
-        # -1 (auto; the default is 0, the host): decided per call from a cost estimate; a short call of small frames stays on the host
-        pipe.set_option("entropy_on_gpu", -1)
-        assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
-        assert pipe.last_entropy_mode() == 0
-        # ... a long call on a host with two entropy threads goes to the GPU (1 024 frames announced as 1 M points each
-        # would, by the estimate; here 192 small frames with a batch of 8 per flush: the estimate counts flushes)
-        many = [frames[0], frames[1], frames[2]] * 64
-        want = []
-        fid = 2
-        for k in range(len(many)):
-            r = oracle.encode_intra(many[k], oracle.make_params(frame_id=fid, **kw), keep=False) if k < 3 else None
-            want.append(r)
-            fid += 1
-        got = pipe.encode_host(many, b.make_params(frame_id=2, **kw))
-        assert len(got) == len(many)
-        for k in range(3):   # (same clouds, consecutive frame ids: the first round against the oracle, the rest by length)
-            assert got[k][0] == want[k].bitstream
-        assert all(len(got[k][0]) == len(got[k % 3][0]) for k in range(len(many)))
     finally:
         pipe.close()

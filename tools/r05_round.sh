@@ -82,8 +82,8 @@ if want ab; then
     echo "frames per coder call $BATCH: $(python -c "import json,sys; d=json.load(open('$OUT/bench_batch_$BATCH.json')); print(d['value'], d['host_cpu_ms_per_frame'], d['entropy_stage'])" 2>&1)"
   done
   (cd tools/ubench && g++ -O3 -march=x86-64-v3 -I../../cwi-pcl-codec_amd/csrc -I../../include rc_many.cpp ../../cwi-pcl-codec_amd/csrc/dev_obj/pcc_host_codec.o -o rc_many && ./rc_many && PCC_RC_WIDE=0 ./rc_many | tail -4) > $OUT/rc_many.txt 2>&1; tail -24 $OUT/rc_many.txt
-  # where the entropy stage of a long call should run on this box: host (default), GPU, the cost estimate
-  for M in host gpu auto; do
+  # where the entropy stage of a long call should run on this box: host (default) or GPU
+  for M in host gpu; do
     PCC_PIPELINE_ENTROPY=$M python bench.py --steps 1024 --warmup 8 --no-cpu-baseline --no-host-input > $OUT/bench_entropy_$M.json 2> $OUT/bench_entropy_$M.err
     echo "entropy=$M: $(python -c "import json,sys; d=json.load(open('$OUT/bench_entropy_$M.json')); print(d['value'], d['entropy_stage'])" 2>&1)"
   done
