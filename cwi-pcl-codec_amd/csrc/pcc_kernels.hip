@@ -5,10 +5,14 @@
 //   P1/P2  addPointsFromInputCloud + adoptBoundingBoxToPoint   -> k_boxes_events (chunk boxes + growth replay in one launch)
 //   P3     genOctreeKeyforPoint                                -> k_make_keys
 //   P4     createLeafRecursive + addPointIndex                 -> LSD radix sort (k_make_keys histograms, k_digit_totals, k_sort_pass)
-//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_scan + k_leaf_finalize
-//   C2/P6  serializeTreeCallback / encodeAverageOfPoints       -> k_leaf_finalize
-//   C3b    SnakeGridMapping::doMapping                         -> k_leaf_finalize (closed-form position)
-//   C4     PointCodingV2::encodePoint                          -> k_leaf_finalize
+//   P5     serializeTree (depth-first occupancy bytes)         -> k_leaf_scan + k_leaf_tile
+//   C2/P6  serializeTreeCallback / encodeAverageOfPoints       -> k_leaf_tile
+//   C3b    SnakeGridMapping::doMapping                         -> k_leaf_tile (closed-form position)
+//   C4     PointCodingV2::encodePoint                          -> k_leaf_tile
+//   C3/C5  encodeJPEGSnake / encodeJPEGLines, JPEGWriter       -> k_leaf_tile (image rows), k_jpeg_rows, k_jpeg_lines
+//
+// These are the forms that have run on an MI355X (round 2) plus layout-only changes; forms that have not are not compiled
+// into this file (branch experiments/r04-optin-forms; DESIGN.md, status).
 //
 // All of it is integer / byte / fp64-scalar work bound by HBM bandwidth and launch latency:
 // no MFMA anywhere (there is no dense contraction in this path).
