@@ -30,11 +30,16 @@ workers = int(rng.choice([1, 2, 3, 5]))
 pipe = b.Pipeline(0, workers=workers)
 try:
     for rep in range(2):
-        if rng.integers(0, 3) == 0: pipe.set_option("entropy_on_gpu", 1); pipe.set_option("entropy_gpu_batch", int(rng.choice([1, 3, 8])))
+        if rng.integers(0, 3) == 0:
+            pipe.set_option("entropy_on_gpu", 1); pipe.set_option("entropy_gpu_batch", int(rng.choice([1, 3, 8])))
+            pipe.set_option("rc_device_lanes", int(rng.integers(0, 2)))   # (the form of the device coder the threads' batches launch)
         else: pipe.set_option("entropy_on_gpu", 0)
         got = pipe.encode_host(frames, b.make_params(frame_id=4, **kw))
         assert [g[0] for g in got] == ref, "bitstreams"
         pipe.stats()
+        assert pipe.get("workers") == workers and pipe.get("last_entropy_mode") in (0, 1)
+        if rep == 0 and rng.integers(0, 2):   # a second pipeline comes and goes while this one lives (the pin ranges: not in LIFO order)
+            other = b.Pipeline(0, workers=1); other.encode_host(frames[:3], b.make_params(frame_id=4, **kw)); other.close()
 finally:
     pipe.close()
 print("ok seed", seed, "frames", nf, "workers", workers, "batch", os.environ.get("PCC_PIPELINE_BATCH", "4"))
