@@ -29,8 +29,9 @@ def test_library_exports_every_declared_symbol(pkg):
         for name in declared:
             assert hasattr(lib, name), name
     assert len(pkg.binding.BOUNDARY_EXPORTS) <= 40
-    nm = subprocess.run(["nm", "-D", "--defined-only", pkg.binding.LIB_PATH], capture_output=True, text=True)
-    if nm.returncode == 0:
+    import shutil
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg.binding.LIB_PATH], capture_output=True, text=True) if shutil.which("nm") else None
+    if nm is not None and nm.returncode == 0:
         exported = {l.split()[-1] for l in nm.stdout.splitlines() if " T pcc_" in l}
         assert exported == set(pkg.binding.EXPORTS), exported ^ set(pkg.binding.EXPORTS)
     assert b"gfx950" in lib.pcc_version()
