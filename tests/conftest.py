@@ -25,3 +25,65 @@ def pkg():
     """The product package (cwi-pcl-codec_amd/), imported by path (hyphen in the name)."""
     import __graft_entry__ as G
     return G.load_package()
+
+
+# The order in which `pytest -m gpu -x` meets the tests (VERDICT round 5, weak 2): the hot path on the BASELINE configs first, then the
+# rest of SURVEY.md 8(a), the boundary (b), the rows of (f), the pipelines, and only then the tests that look at clocks or at forms the
+# product does not use -- so that with -x a timing assertion or an ICP tolerance cannot leave the hot-path rows untested.  A name is
+# placed by the first pattern that matches "file::function"; tests nobody lists keep their file order between the pipelines and the
+# bench contract.  CPU tests (-m "not gpu") are left where they are.
+_GPU_ORDER = [
+    # 8(a) on BASELINE.json's configs
+    r"test_gpu_parity\.py::test_cfg1_100k_depth8",
+    r"test_gpu_parity\.py::test_cfg2_1m_depth10_surface",
+    r"test_gpu_parity\.py::test_cfg2_1m_depth10_uniform",
+    r"test_gpu_parity\.py::test_cfg4_reduced_parity_and_full_size_properties",
+    r"test_gpu_parity\.py::test_cfg3_gop_of_8_frames",
+    r"test_gpu_parity\.py::test_cfg3_capture_like_voxelised_frames",
+    # 8(a): micro cases, golden vectors, colour modes, key layouts, the JPEG stage, the random sweep
+    r"test_gpu_parity\.py::test_(appendix_f|single_point|two_points|growth_every|empty_and|nan_points|duplicates_and|points_on_voxel)",
+    r"test_gpu_parity\.py::test_(non_power_of_two|sorted_input|large_coordinates|trees_of_22|a_large_frame|a_tree_of_32|unaligned_stride|bad_arguments)",
+    r"test_codec_golden\.py::",
+    r"test_gpu_parity\.py::test_(modes_bitstream|geometry_only|snake_image_heights|codec_class_round_trip)",
+    r"test_gpu_parity\.py::test_(pair_sort_mode|indexed_keys|every_key_layout|crowded_voxels|cell_ranks)",
+    r"test_gpu_parity\.py::test_jpeg_stage_on_gpu",
+    r"test_gpu_parity\.py::test_jpeg_huffman_rows",
+    r"test_gpu_parity\.py::test_random_sweep",
+    # 8(b): the boundary
+    r"test_gpu_parity\.py::test_cpp_shim_example_runs",
+    r"test_shim_boundary\.py::",
+    # 8(f) 1-4: the app, quality, outliers, the GPU decoder, LINES, the device range coder, then the P path (ICP last)
+    r"test_evaluate_app\.py::test_app_group_loop",
+    r"test_evaluate_app\.py::test_app_with_a_device_list",
+    r"test_quality\.py::",
+    r"test_outliers\.py::",
+    r"test_gpu_parity\.py::test_gpu_decode",
+    r"test_gpu_parity\.py::test_jpeg_lines_on_gpu",
+    r"test_rc_device\.py::",
+    r"test_delta_gpu\.py::test_delta_(encode_matches|decode_matches|round_trip|class_interface|disjoint|rejects_empty|other_macroblock|many_blocks|clouds_outside)",
+    r"test_delta_gpu\.py::test_cfg5",
+    r"test_evaluate_app\.py::test_app_delta_coding_branch",
+    r"test_delta_gpu\.py::test_delta_icp_close",
+    # the pipelines
+    r"test_gpu_parity\.py::test_(cpp_pipeline_bench|next_frame_may|short_calls|pipeline_gives|two_pipelines|pipelines_of_a_rank|host_frames_through|contexts_on_borrowed)",
+    None,                                   # <- anything not listed
+    r"test_bench_contract\.py::",
+    r"test_zz_",
+]
+
+
+def gpu_order_rank(nodeid):
+    import re
+    base = nodeid.split("[")[0]
+    for i, pat in enumerate(_GPU_ORDER):
+        if pat is not None and re.search(pat, base):
+            return i
+    return _GPU_ORDER.index(None)
+
+
+def pytest_collection_modifyitems(config, items):
+    gpu = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu:
+        return
+    ordered = iter(sorted(gpu, key=lambda it: gpu_order_rank(it.nodeid)))      # stable: file order inside one pattern
+    items[:] = [next(ordered) if it.get_closest_marker("gpu") else it for it in items]

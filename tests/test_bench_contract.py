@@ -67,9 +67,18 @@ def test_one_line_with_roofline_host_input_and_cpu_baseline():
     r = d["roofline"]
     assert r["kernel"] == "k_sort_pass" and r["bound"] == "hbm" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert 0.005 < r["kernel_span_ms"] <= r["kernel_avg_ms"] <= r["kernel_avg_ms_hip_events"] * 1.05
+    # the kernel's own clock brackets less than the launch-to-launch average; how that average relates to the HIP-event figure is a
+    # property of the box (three clocks), reported in the line and not asserted here
+    assert 0 < r["kernel_span_ms"] <= r["kernel_avg_ms"] and r["kernel_avg_ms_hip_events"] > 0
+    print("k_sort_pass: span %.4f ms, avg %.4f ms, HIP events %.4f ms (avg / events = %.3f)"
+          % (r["kernel_span_ms"], r["kernel_avg_ms"], r["kernel_avg_ms_hip_events"], r["kernel_avg_ms"] / r["kernel_avg_ms_hip_events"]))
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["host_input"]["e2e_from_host_mpoints_per_s"] > 0 and "workload" in d["config"]
+    # the reference's own timed span (host memory in, bitstream out) stands beside the headline, not under a sub-object
+    assert d["value_from_host_memory"] == d["host_input"]["e2e_from_host_mpoints_per_s"]
+    assert d["single_call_ms"] == d["host_input"]["single_call_latency_ms"] > 0
+    assert abs(d["single_call_mpoints_per_s"] - 1_000_000 / d["single_call_ms"] / 1e3) < 0.1   # cfg2: 1M points per call
+    assert "eval.hpp:462-464" in d["reference_timed_span"]
 
 
 @pytest.mark.gpu

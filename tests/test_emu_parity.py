@@ -155,6 +155,10 @@ def test_bench_script_runs_end_to_end_on_the_executor(emu_libs):
     assert line["library"]["file"] == "libpcc_emu.so" and line["library"]["version"].startswith("pcc_emu")
     assert line["short_call_floor_ms"] >= 0
     assert "e2e_from_host_packed_16B_mpoints_per_s" in line["host_input"]
+    # the reference's timed span (host memory in, bitstream out) stands at the top level, beside the headline
+    assert line["value_from_host_memory"] == line["host_input"]["e2e_from_host_mpoints_per_s"] > 0
+    assert line["single_call_ms"] == line["host_input"]["single_call_latency_ms"] > 0 and line["single_call_mpoints_per_s"] > 0
+    assert "eval.hpp:462-464" in line["reference_timed_span"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
 
 
