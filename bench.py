@@ -169,13 +169,9 @@ def main():
     workers = args.workers or default_workers(world)
 
     # ---- frames of this rank, resident in HBM before the clock starts ----
-    if world > 1 and "PCC_PIPELINE_PIN_SPAN" not in os.environ:
-        # the pipeline gives its entropy threads groups of physical cores of their own; the ranks of one host share the
-        # host's cores, so every rank takes its own range (a core has two hardware threads: half the allowed CPUs)
-        cores = max(1, len(os.sched_getaffinity(0)) // 2)
-        span = max(1, cores // world)
-        os.environ["PCC_PIPELINE_PIN_SPAN"] = str(span)
-        os.environ["PCC_PIPELINE_PIN_OFFSET"] = str(int(os.environ.get("LOCAL_RANK", "0")) * span)
+    # The ranks of one host share its cores: the library gives every rank's pipeline cores of its own from torchrun's LOCAL_RANK /
+    # LOCAL_WORLD_SIZE -- cores of the NUMA node its GPU hangs off where the host names one for every GPU (csrc/pcc_numa.h), an
+    # n-th of the allowed cores otherwise.  PCC_PIPELINE_PIN_SPAN / _OFFSET override it.  Which it was: "numa_node" per rank.
     pipe = b.Pipeline(local_rank, workers)
     ctx0 = pipe.context(0)
     for w in range(pipe.n_contexts):
@@ -194,6 +190,10 @@ def main():
     ctx0.hotpath_launch(dev_frames[0], n_points, params)
     hot0 = ctx0.hotpath_finish(copy=False)
     L, B, depth = hot0.n_leaves, hot0.n_branches, hot0.depth
+    lib0 = b.load_library()
+    placement = {"numa_node": pipe.get("numa_node"),                                            # whose cores this rank's host threads sit on (None: no placement by node)
+                 "gpu_numa_node": (lambda v: None if v < 0 else v)(lib0.pcc_debug_device_numa_node(local_rank, None)),
+                 "landing_buffer_numa_node": (lambda v: None if v < 0 else v)(lib0.pcc_debug_address_node(hot0.raw.occupancy))}  # where the runtime put the page-locked landing buffer
     image_bytes = hot0.image_w * hot0.image_h * 3
 
     trace("first frame done: L=%d B=%d D=%d" % (L, B, depth))
@@ -283,6 +283,7 @@ def main():
         # the host stage of this rank cannot keep up with what its GPU stage delivers: more GPUs on these CPUs add nothing
         "host_bound": bool(host_bound_fps is not None and host_bound_fps < gpu_only_fps),
     }
+    mine.update(placement)
     ranks = [mine]
     if dist is not None:
         ranks = [None] * world

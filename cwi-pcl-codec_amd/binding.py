@@ -22,6 +22,7 @@ POINT_DTYPE = np.dtype(
 )
 
 PCC_OK = 0
+PCC_NO_NUMA_NODE = -100   # pcc_pipeline_get(p, "numa_node"): the cores were not chosen by NUMA node
 ERR_NAMES = {-1: "PCC_ERR_ARG", -2: "PCC_ERR_HIP", -3: "PCC_ERR_EMPTY", -4: "PCC_ERR_UNSUPPORTED",
              -5: "PCC_ERR_STREAM", -6: "PCC_ERR_STATE"}
 
@@ -52,8 +53,15 @@ TOOLS_EXPORTS = [
     "pcc_host_range_encode", "pcc_host_range_encode_many", "pcc_host_range_decode", "pcc_host_jpeg_encode", "pcc_host_jpeg_decode",
     "pcc_host_snake_position",
     "pcc_debug_sort_plan", "pcc_debug_pipeline_cpus", "pcc_debug_host_rc_wide",
+    "pcc_debug_device_pci_bus_id", "pcc_debug_device_numa_node", "pcc_debug_numa_plan", "pcc_debug_address_node",
 ]
 EXPORTS = BOUNDARY_EXPORTS + TOOLS_EXPORTS
+
+
+# csrc/pcc_dev.h: read by `make dev` builds (libpcc_hip_dev.so) and the executor, a constant nullptr in the shipped library
+DEV_SWITCHES = ("PCC_LEAF_PROBES", "PCC_LEAF_ROWS", "PCC_SORT_SHAPE", "PCC_WAIT", "PCC_WAIT_STATS", "PCC_FINISH_TRACE", "PCC_TRACE_DELTA",
+                "PCC_DECODE_TRACE", "PCC_PIPELINE_TRACE", "PCC_DECODE_SERIAL", "PCC_PIPELINE_SPREAD", "PCC_PIPELINE_OWN_STREAMS", "PCC_RC_WIDE",
+                "PCC_RC_DEVICE", "PCC_PACK_UPLOAD", "PCC_SYSFS_ROOT")
 
 
 class PccError(RuntimeError):
@@ -222,6 +230,10 @@ def load_library():
     lib.pcc_entropy_batch_last_error.restype = C.c_char_p
     lib.pcc_entropy_batch_last_error.argtypes = [vp]
     lib.pcc_pipeline_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.pcc_debug_device_pci_bus_id.argtypes = [i32, C.c_char_p, i32]
+    lib.pcc_debug_device_numa_node.argtypes = [i32, C.c_char_p]
+    lib.pcc_debug_numa_plan.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32]
+    lib.pcc_debug_address_node.argtypes = [vp]
     lib.pcc_pipeline_create_multi.restype = vp
     lib.pcc_pipeline_create_multi.argtypes = [C.POINTER(i32), i32, i32]
     lib.pcc_multi_pipeline_destroy.argtypes = [vp]
@@ -264,6 +276,14 @@ def load_library():
     lib.pcc_host_snake_position.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.pcc_normalize_group_boxes.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.c_double, vp, vp, vp]
     lib.pcc_restore_scaling.argtypes = [vp, sz, vp, vp]
+    # the developer switches of csrc/pcc_dev.h are read by the developer build and the executor only: set for a library that
+    # ignores them, a tool would measure something else than it says
+    ignored = [k for k in DEV_SWITCHES if k in os.environ]
+    version = lib.pcc_version().decode()
+    if ignored and "dev build" not in version and not version.startswith("pcc_emu"):
+        import warnings
+        warnings.warn("%s set, but the library loaded (%s: %s) does not read developer switches: use PCC_LIB=%s"
+                      % (", ".join(ignored), os.path.basename(LIB_PATH), version, os.path.join(_HERE, "libpcc_hip_dev.so")), RuntimeWarning, stacklevel=2)
     _lib = lib
     return lib
 
@@ -587,6 +607,8 @@ class Pipeline:
         """What the pipeline runs with: "workers", "gpu_threads", "contexts", "frames_per_coder_call", "last_entropy_mode",
         "rc_device_lanes", "entropy_gpu_batch" (pcc_pipeline_get)."""
         v = int(self.lib.pcc_pipeline_get(self.h, name.encode()))
+        if name == "numa_node":
+            return None if v == PCC_NO_NUMA_NODE else v      # the node whose cores the threads were given; None: not placed by node
         if v < 0:
             raise PccError(v, "pipeline value " + name)
         return v
@@ -680,6 +702,14 @@ class MultiPipeline:
             self.close()
         except Exception:
             pass
+
+    def numa_nodes(self):
+        """The host NUMA node every member's threads were placed on (None: an even share of the cores instead)."""
+        out = []
+        for i in range(len(self.devices)):
+            v = int(self.lib.pcc_pipeline_get(self.lib.pcc_multi_pipeline_member(self.h, i), b"numa_node"))
+            out.append(None if v == PCC_NO_NUMA_NODE else v)
+        return out
 
     def encode_host(self, host_frames, params, stride=32, rgb_offset=16, copy=True):
         frames = [np.ascontiguousarray(f) for f in host_frames]

@@ -26,6 +26,7 @@
 #include "pcc_delta.h"
 #include "pcc_rc_device.h"
 #include "pcc_dev.h"
+#include "pcc_numa.h"
 
 using namespace pcc;
 
@@ -413,6 +414,41 @@ pcc_ctx* pcc_create(int device) {
   }
   return c;
 }
+
+// ---- where a GPU hangs off the host (pcc_numa.h): asked by the pipelines when they choose cores ----
+// "0000:c1:00.0"-style PCI address of a device, as the runtime prints it
+int pcc_debug_device_pci_bus_id(int device, char* out, int cap) {
+  int count = 0;
+  if (!out || cap < 13 || hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+    (void)hipGetLastError();
+    return PCC_ERR_ARG;
+  }
+  if (hipDeviceGetPCIBusId(out, cap, device) != hipSuccess) {
+    (void)hipGetLastError();
+    out[0] = 0;
+    return PCC_ERR_HIP;
+  }
+  return PCC_OK;
+}
+// The host's NUMA node nearest to a device, -1 if nobody says: sysfs through the PCI address
+// (/sys/bus/pci/devices/<address>/numa_node) first, the runtime's own answer (hipDeviceAttributeHostNumaId) where sysfs has
+// none.  `sysfs_root` NULL = "/sys".
+int pcc_debug_device_numa_node(int device, const char* sysfs_root) {
+  char bdf[64];
+  if (pcc_debug_device_pci_bus_id(device, bdf, (int)sizeof(bdf)) == PCC_OK) {
+    const int node = pcc::numa::pci_numa_node(sysfs_root && *sysfs_root ? sysfs_root : "/sys", bdf);
+    if (node >= 0) return node;
+    if (sysfs_root && *sysfs_root) return -1;  // a made-up tree (tests): what it does not say stays unknown
+  }
+  int node = -1;
+  if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return node >= 0 ? node : -1;
+}
+// the node the page behind `p` is on right now (-1: not touched yet, or the kernel does not say): where a landing buffer went
+int pcc_debug_address_node(const void* p) { return p ? pcc::numa::node_of_address(p) : -1; }
 
 pcc_ctx* pcc_create_host(void) {
   pcc_ctx* c = new pcc_ctx();

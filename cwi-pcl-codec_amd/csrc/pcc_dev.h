@@ -16,6 +16,7 @@
 //   PCC_RC_WIDE=0             host range coder: scalar loop although AVX-512 is there
 //   PCC_RC_DEVICE=lanes       device range coder: process default of the option "rc_device_lanes"
 //   PCC_PACK_UPLOAD=1         host input: default of the option "pack_upload"
+//   PCC_SYSFS_ROOT=<dir>      pipelines: the tree the NUMA placement reads instead of /sys (tests: a made-up two-socket host)
 #pragma once
 #include <stdlib.h>
 

@@ -1704,6 +1704,9 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   p.do_icp_color_offset = u8;
   const double res = p.octree_resolution;
   if (!(res > 0.0)) return PCC_ERR_STREAM;
+  // do_voxel_grid_enDecoding_ false: `count` counts points, not voxels, and a point-detail tail follows the streams
+  // (impl.hpp:1728-1757) -- a frame this decoder would misread as a voxel-grid one; the encoder never writes it
+  if (!vg) return PCC_ERR_UNSUPPORTED;
 
   // defineBoundingBox + getKeyBitSize
   {
@@ -1728,6 +1731,9 @@ int decode_frame_streams(const uint8_t* stream, size_t len, pcc_cloud& info, Fra
   // (a leaf opens at most one branch node per level: a count beyond that is not a voxel-grid frame's; 2^40 voxels: no overflow below)
   if (count >= (1ull << 40)) return PCC_ERR_STREAM;
   if (!r.get(occ_n) || occ_n > count * (uint64_t)std::max(info.depth, 1u) || !plausible_symbol_count(occ_n, r.p + r.pos, r.len - r.pos)) return PCC_ERR_STREAM;
+  // ... and a branch byte opens at most eight voxels: with occ_n tied to the coded bytes above, this ties `count` -- which sizes
+  // everything allocated from here on -- to the stream's size too
+  if (count > 8u * occ_n) return PCC_ERR_STREAM;
   Bytes& occ = fs.occ;
   occ.resize((size_t)occ_n);
   size_t used = StaticRangeCoder::decode(r.p + r.pos, r.len - r.pos, occ.data(), occ.size());

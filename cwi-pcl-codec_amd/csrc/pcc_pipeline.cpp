@@ -35,6 +35,7 @@
 
 #include "../../include/pcc_codec_tools.h"
 #include "pcc_dev.h"
+#include "pcc_numa.h"
 
 namespace {
 typedef std::chrono::steady_clock Clock;
@@ -77,6 +78,7 @@ struct pcc_pipeline {
   // holds).  Option "entropy_on_gpu", PCC_PIPELINE_ENTROPY=host|gpu.  (Rounds 3-4 had a third setting that decided per call from
   // a cost estimate with two constants nobody had calibrated; it went with the other unmeasured forms.)
   int entropy_mode = 0;
+  int numa_node = -1;                         // the node whose cores this pipeline's threads were given (-1: no placement by node)
   size_t pin_start = 0, pin_cores_taken = 0;  // this pipeline's range in g_pin_ranges, given back when the pipeline is destroyed
   int gpu_batch = 256;
   bool rc_lanes = false;  // option "rc_device_lanes": the form of the device range coder the entropy threads' batches launch
@@ -433,9 +435,9 @@ struct pcc_pipeline {
   }
 };
 
-// one logical CPU per physical core, out of the CPUs this process may run on
-// set by pcc_pipeline_create_multi around the creation of each of its pipelines: which range of the allowed cores is whose
-static thread_local int pin_offset_hint = 0, pin_span_hint = 0;
+// set by pcc_pipeline_create_multi around the creation of each of its pipelines: which of the allowed cores are whose (the
+// cores of the GPU's own NUMA node where the host says which that is: pcc_numa.h)
+static thread_local const pcc::numa::Share* pin_share_hint = nullptr;
 // cores handed to the entropy threads of earlier pipelines of this process: a pipeline created without a range of its own
 // (no hint, no PCC_PIPELINE_PIN_OFFSET) starts behind them, so two plain pcc_pipeline_create calls do not pin to the same cores
 // Which positions of a process's core range the entropy threads of its live pipelines sit on: [start, start + len) each, in any
@@ -465,24 +467,54 @@ static void pin_give_back(size_t start, size_t len) {
     if (g_pin_ranges[i].first == start && g_pin_ranges[i].second == len) { g_pin_ranges.erase(g_pin_ranges.begin() + (long)i); return; }
 }
 
-static std::vector<int> one_cpu_per_core() {
+// one logical CPU per physical core out of `allowed` (ascending): the lowest allowed hardware thread of each core
+static std::vector<int> one_cpu_per_core(const std::string& root, const std::vector<int>& allowed) {
+  std::vector<int> out;
+  for (int c : allowed) {
+    std::string text;
+    int first = c;
+    if (pcc::numa::read_text(root + "/devices/system/cpu/cpu" + std::to_string(c) + "/topology/thread_siblings_list", &text)) {
+      const std::vector<int> siblings = pcc::numa::parse_cpulist(text);
+      for (int sib : siblings)
+        if (std::binary_search(allowed.begin(), allowed.end(), sib)) { first = sib; break; }
+    }
+    if (first == c) out.push_back(c);
+  }
+  return out;
+}
+static std::vector<int> allowed_cpus() {
   std::vector<int> out;
   cpu_set_t allowed;
   CPU_ZERO(&allowed);
   if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
-  for (int c = 0; c < CPU_SETSIZE; ++c) {
-    if (!CPU_ISSET(c, &allowed)) continue;
-    char path[128];
-    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
-    FILE* f = fopen(path, "r");
-    int first = c;
-    if (f) {
-      if (fscanf(f, "%d", &first) != 1) first = c;
-      fclose(f);
-    }
-    if (first == c || !CPU_ISSET(first, &allowed)) out.push_back(c);  // the lowest sibling stands for the core
-  }
+  for (int c = 0; c < CPU_SETSIZE; ++c)
+    if (CPU_ISSET(c, &allowed)) out.push_back(c);
   return out;
+}
+static std::string sysfs_root();
+static std::vector<int> one_cpu_per_core() { return one_cpu_per_core(sysfs_root(), allowed_cpus()); }
+
+// developer builds and the executor can point the planning at a made-up sysfs tree (tests); the shipped library reads /sys
+static std::string sysfs_root() {
+  const char* e = pcc::dev_env("PCC_SYSFS_ROOT");
+  return e && *e ? e : "/sys";
+}
+// every allowed logical CPU of `node` (both hardware threads of a core): where a placed pipeline's GPU-stage threads may run
+static std::vector<int> allowed_cpus_of_node(int node) {
+  const std::vector<int> all = allowed_cpus();
+  const std::vector<int> nodes = pcc::numa::nodes_of_cpus(sysfs_root(), all);
+  std::vector<int> out;
+  for (size_t i = 0; i < all.size(); ++i)
+    if (nodes[i] == node) out.push_back(all[i]);
+  return out;
+}
+// the shares of `n` pipelines on GPUs devices[0..n): cores of each GPU's own node where the host names it for all of them
+static std::vector<pcc::numa::Share> plan_shares(const int* devices, int n) {
+  const std::vector<int> cores = one_cpu_per_core();
+  const std::string root = sysfs_root();
+  std::vector<int> device_node((size_t)n, -1);
+  for (int d = 0; d < n; ++d) device_node[(size_t)d] = pcc_debug_device_numa_node(devices[d], root == "/sys" ? nullptr : root.c_str());
+  return pcc::numa::plan(cores, pcc::numa::nodes_of_cpus(root, cores), device_node);
 }
 
 extern "C" {
@@ -530,7 +562,13 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   for (int w = 0; w < p->n_gpu; ++w) p->threads.emplace_back([p, w] { p->gpu_thread(w); });
   p->batches.assign((size_t)p->n_entropy, nullptr);
   if (const char* e = pcc::dev_env("PCC_RC_DEVICE")) p->rc_lanes = !strcmp(e, "lanes");
-  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) p->entropy_mode = !strcmp(e, "gpu") ? 1 : 0;
+  if (const char* e = getenv("PCC_PIPELINE_ENTROPY")) {
+    p->entropy_mode = !strcmp(e, "gpu") ? 1 : 0;
+    if (strcmp(e, "gpu") && strcmp(e, "host")) {  // (rounds 3-4 knew "auto"; it is gone) -- said once per process, the host stage it is
+      static std::atomic<bool> said{false};
+      if (!said.exchange(true)) fprintf(stderr, "pcc_pipeline: PCC_PIPELINE_ENTROPY=%s is neither host nor gpu: the entropy stage runs on the host\n", e);
+    }
+  }
   for (int w = 0; w < p->n_entropy; ++w) p->threads.emplace_back([p, w] { p->entropy_thread(w); });
   // The entropy stage is a chain of dependent integer operations per symbol: two such threads on the two hardware
   // threads of one core run at about half speed each, and the scheduler does put them there (20 frames on 16 threads:
@@ -543,33 +581,52 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
   //   core per thread) | none;  PCC_PIPELINE_PIN_OFFSET = first core (in the list of allowed cores) of this pipeline,
   //   PCC_PIPELINE_PIN_SPAN = how many cores it may use: several pipelines / ranks on one host take different ranges.
   {
-    const std::vector<int> cores = one_cpu_per_core();
+    std::vector<int> cores = one_cpu_per_core();
     const char* e = getenv("PCC_PIPELINE_PIN");
-    size_t span = cores.size();
-    if (const char* o = getenv("PCC_PIPELINE_PIN_SPAN")) span = std::min<size_t>(cores.size(), (size_t)std::max(atoi(o), 1));
-    if (pin_span_hint > 0) span = std::min<size_t>(span, (size_t)pin_span_hint);
-    // one process per GPU on one host (torchrun: LOCAL_RANK of LOCAL_WORLD_SIZE): every rank takes its share of the
-    // allowed cores unless the caller gave a range
-    size_t rank_base = 0;
-    const bool ranged = pin_span_hint > 0 || getenv("PCC_PIPELINE_PIN_SPAN") || getenv("PCC_PIPELINE_PIN_OFFSET");
-    if (!ranged) {
+    // Whose cores: (1) the share pcc_pipeline_create_multi planned for this pipeline; (2) the caller's range
+    // (PCC_PIPELINE_PIN_OFFSET / _SPAN, positions in the list of allowed cores); (3) one process per GPU on one host (torchrun:
+    // LOCAL_RANK r of LOCAL_WORLD_SIZE n, rank i on GPU i): the share of pipeline r in the plan for GPUs 0..n-1 -- the cores of
+    // this GPU's own NUMA node, split among the ranks whose GPUs hang off the same node, where the host says which node that is,
+    // else an n-th of all cores; (4) all allowed cores.
+    const bool env_range = getenv("PCC_PIPELINE_PIN_SPAN") || getenv("PCC_PIPELINE_PIN_OFFSET");
+    size_t rank_base = 0, span = cores.size();
+    if (pin_share_hint) {
+      cores = pin_share_hint->cores;
+      p->numa_node = pin_share_hint->node;
+      span = cores.size();
+    } else if (env_range) {
+      if (const char* o = getenv("PCC_PIPELINE_PIN_SPAN")) span = std::min<size_t>(cores.size(), (size_t)std::max(atoi(o), 1));
+    } else {
       const char* lr = getenv("LOCAL_RANK");
       const char* lw = getenv("LOCAL_WORLD_SIZE");
       const int nr = lw ? atoi(lw) : 1, r = lr ? atoi(lr) : 0;
       if (nr > 1 && r >= 0 && r < nr) {
-        span = std::max<size_t>(cores.size() / (size_t)nr, 1);
-        rank_base = (size_t)r * span;
+        std::vector<pcc::numa::Share> shares;
+        char last[64];
+        if (device == r && pcc_debug_device_pci_bus_id(nr - 1, last, (int)sizeof(last)) == PCC_OK) {  // (GPU n-1 is there: rank i <-> GPU i holds)
+          std::vector<int> devs((size_t)nr);
+          for (int i = 0; i < nr; ++i) devs[(size_t)i] = i;
+          shares = plan_shares(devs.data(), nr);
+        }
+        if (!shares.empty() && shares[(size_t)r].node >= 0) {
+          cores = shares[(size_t)r].cores;
+          p->numa_node = shares[(size_t)r].node;
+          span = cores.size();
+        } else {
+          span = std::max<size_t>(cores.size() / (size_t)nr, 1);
+          rank_base = (size_t)r * span;
+        }
       }
     }
     int mode = (span >= 2 * (size_t)p->n_entropy) ? 2 : 0;  // 0 none, 1 cores, 2 groups
     if (e) mode = !strcmp(e, "cores") ? 1 : (!strcmp(e, "groups") ? 2 : 0);
     const size_t per = mode == 2 ? std::min<size_t>(8, std::max<size_t>(1, span / (size_t)std::max(p->n_entropy, 1))) : 1;
-    // the range [base, base + span) of the allowed cores is this pipeline's (the caller's, or this rank's share); `start`
-    // is where inside it the first entropy thread goes -- behind the cores of earlier pipelines of this process, wrapping
-    // INSIDE the range (a second pipeline of one rank must not land on the next rank's cores)
-    size_t base = pin_offset_hint > 0 ? (size_t)pin_offset_hint : rank_base, start = 0;
+    // the range [base, base + span) of `cores` is this pipeline's (the caller's, or this rank's share); `start` is where
+    // inside it the first entropy thread goes -- behind the cores of earlier pipelines of this process, wrapping INSIDE
+    // the range (a second pipeline of one rank must not land on the next rank's cores)
+    size_t base = rank_base, start = 0;
     if (const char* o = getenv("PCC_PIPELINE_PIN_OFFSET")) base = (size_t)std::max(atoi(o), 0);
-    else if (pin_span_hint == 0 && mode) {
+    else if (!pin_share_hint && mode) {
       p->pin_cores_taken = (size_t)p->n_entropy * per;
       start = p->pin_start = pin_take(p->pin_cores_taken, span);
     }
@@ -579,6 +636,17 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
         CPU_ZERO(&set);
         for (size_t k = 0; k < per; ++k) CPU_SET(cores[(base + (start + (size_t)w * per + k) % span) % cores.size()], &set);
         (void)pthread_setaffinity_np(p->threads[(size_t)p->n_gpu + w].native_handle(), sizeof(set), &set);
+      }
+    }
+    // a placed pipeline's GPU-stage threads (launch calls, waits for the landings, the packing of host frames) stay on the
+    // GPU's node too -- any of its allowed CPUs, they are not pinned to cores
+    if (mode && p->numa_node >= 0) {
+      const std::vector<int> of_node = allowed_cpus_of_node(p->numa_node);
+      if (!of_node.empty()) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        for (int c : of_node) CPU_SET(c, &set);
+        for (int w = 0; w < p->n_gpu; ++w) (void)pthread_setaffinity_np(p->threads[(size_t)w].native_handle(), sizeof(set), &set);
       }
     }
   }
@@ -617,7 +685,10 @@ int pcc_pipeline_reserve(pcc_pipeline* p, size_t n_frames, size_t bytes_per_fram
 int pcc_pipeline_set_option(pcc_pipeline* p, const char* name, int value) {
   if (!p || !name) return PCC_ERR_ARG;
   std::lock_guard<std::mutex> lk(p->mu);  // between jobs: the threads read these when a job starts
-  if (!strcmp(name, "entropy_on_gpu")) p->entropy_mode = value != 0 ? 1 : 0;
+  if (!strcmp(name, "entropy_on_gpu")) {
+    if (value != 0 && value != 1) return PCC_ERR_ARG;  // (-1 meant "decide per call" in rounds 3-4: refused, not silently taken for the GPU)
+    p->entropy_mode = value;
+  }
   else if (!strcmp(name, "entropy_gpu_batch")) p->gpu_batch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
   else if (!strcmp(name, "rc_device_lanes")) p->rc_lanes = value != 0;
   else if (!strcmp(name, "pack_upload")) { for (pcc_ctx* c : p->ctxs) (void)pcc_set_option(c, "pack_upload", value); }  // host frames: 16 B per point over PCIe
@@ -635,6 +706,7 @@ int pcc_pipeline_get(pcc_pipeline* p, const char* name) {
   if (!strcmp(name, "last_entropy_mode")) return p->entropy_on_gpu ? 1 : 0;
   if (!strcmp(name, "rc_device_lanes")) return p->rc_lanes ? 1 : 0;
   if (!strcmp(name, "entropy_gpu_batch")) return p->gpu_batch;
+  if (!strcmp(name, "numa_node")) return p->numa_node >= 0 ? p->numa_node : PCC_NO_NUMA_NODE;
   return PCC_ERR_ARG;
 }
 // developer aid (include/pcc_codec_tools.h, the pcc_debug_* block): the CPUs entropy thread `worker` may run on, lowest first; returns how many
@@ -648,6 +720,25 @@ int pcc_debug_pipeline_cpus(pcc_pipeline* p, int worker, int* out, int cap) {
   for (int c = 0; c < CPU_SETSIZE; ++c)
     if (CPU_ISSET(c, &set)) { if (n < cap) out[n] = c; ++n; }
   return n;
+}
+// developer aid (include/pcc_codec_tools.h): the planning of pcc_pipeline_create_multi / of the ranks of one host without a GPU,
+// on a sysfs tree and a CPU list the caller names
+int pcc_debug_numa_plan(const char* root, const char* const* pci, int n_devices, const int* cpus, int n_cpus, int* node_out, int* cores_out,
+                        int* n_cores_out, int cap) {
+  if (!root || !pci || n_devices < 1 || !cpus || n_cpus < 1 || !node_out || !cores_out || !n_cores_out || cap < 1) return PCC_ERR_ARG;
+  std::vector<int> allowed(cpus, cpus + n_cpus);
+  std::sort(allowed.begin(), allowed.end());
+  const std::vector<int> cores = one_cpu_per_core(root, allowed);
+  std::vector<int> device_node((size_t)n_devices);
+  for (int d = 0; d < n_devices; ++d) device_node[(size_t)d] = pcc::numa::pci_numa_node(root, pci[d]);
+  const std::vector<pcc::numa::Share> shares = pcc::numa::plan(cores, pcc::numa::nodes_of_cpus(root, cores), device_node);
+  for (int d = 0; d < n_devices; ++d) {
+    const pcc::numa::Share& sh = shares[(size_t)d];
+    node_out[d] = sh.node;
+    n_cores_out[d] = (int)sh.cores.size();
+    for (size_t k = 0; k < sh.cores.size() && (int)k < cap; ++k) cores_out[(size_t)d * (size_t)cap + k] = sh.cores[k];
+  }
+  return PCC_OK;
 }
 int pcc_pipeline_contexts(pcc_pipeline* p) { return p ? (int)p->ctxs.size() : 0; }
 
@@ -792,12 +883,13 @@ struct pcc_multi_pipeline {
 pcc_multi_pipeline* pcc_pipeline_create_multi(const int* devices, int n_devices, int n_workers_per_device) {
   if (!devices || n_devices < 1) return nullptr;
   pcc_multi_pipeline* m = new pcc_multi_pipeline();
-  const int n_cores = (int)one_cpu_per_core().size();
+  // every pipeline's entropy threads on cores of its own: of its GPU's NUMA node where the host names one for every GPU
+  // (pcc_numa.h), else an n-th of the allowed cores each
+  const std::vector<pcc::numa::Share> shares = plan_shares(devices, n_devices);
   for (int d = 0; d < n_devices; ++d) {
-    pin_span_hint = std::max(n_cores / n_devices, 1);  // every pipeline's entropy threads on a range of cores of its own
-    pin_offset_hint = d * pin_span_hint;
+    pin_share_hint = shares[(size_t)d].cores.empty() ? nullptr : &shares[(size_t)d];
     pcc_pipeline* p = pcc_pipeline_create(devices[d], n_workers_per_device);
-    pin_span_hint = pin_offset_hint = 0;
+    pin_share_hint = nullptr;
     if (!p) {  // a device that does not exist: nothing is silently left out
       for (pcc_pipeline* q : m->pipes) pcc_pipeline_destroy(q);
       delete m;

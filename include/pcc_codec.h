@@ -31,7 +31,7 @@
  * PCC_PIPELINE_GPU_THREADS, PCC_PIPELINE_UPLOAD_THREADS (frames in flight on the GPU / uploads), PCC_PIPELINE_BATCH
  * (frames per coder loop, 1..16, default 4), PCC_PIPELINE_PIN = groups | cores | none with PCC_PIPELINE_PIN_OFFSET and
  * PCC_PIPELINE_PIN_SPAN (core pinning of the entropy threads), and torchrun's LOCAL_RANK / LOCAL_WORLD_SIZE (each rank pins
- * inside its own share of the cores).  Developer switches (traces, bisecting forms) exist only in the `make dev` build:
+ * inside its own share of the cores: cores of its GPU's own NUMA node where /sys names one for every GPU, rank i on GPU i).  Developer switches (traces, bisecting forms) exist only in the `make dev` build:
  * csrc/pcc_dev.h.
  */
 #ifndef PCC_CODEC_H
@@ -48,9 +48,10 @@ extern "C" {
 #define PCC_ERR_ARG (-1)        /* bad argument */
 #define PCC_ERR_HIP (-2)        /* a HIP runtime call failed (no GPU, OOM, ...) */
 #define PCC_ERR_EMPTY (-3)      /* no finite input point: the reference drops the frame (impl.hpp:206-212) */
-#define PCC_ERR_UNSUPPORTED (-4) /* depth > 21 or key+index bits > 64 */
+#define PCC_ERR_UNSUPPORTED (-4) /* a tree of more than 31 levels, 2^30 points or more, a stream of 2 GB or more */
 #define PCC_ERR_STREAM (-5)     /* decode: header not found / truncated / corrupt */
 #define PCC_ERR_STATE (-6)      /* call order (finish without launch, ...) */
+#define PCC_NO_NUMA_NODE (-100) /* pcc_pipeline_get(p, "numa_node"): the cores were not chosen by NUMA node */
 
 typedef struct pcc_ctx pcc_ctx;
 
@@ -205,7 +206,8 @@ void pcc_pipeline_destroy(pcc_pipeline *p);
 /* pipeline knobs (no output byte changes), to be set between calls:
  *   "entropy_on_gpu" 1: the range coders of the entropy stage run on the GPU (pcc_entropy_batch), the entropy threads
  *                 only copy, stitch JPEG rows and assemble -- for hosts with fewer cores than the GPU stage can feed; a flush
- *                 takes ~0.1 s whatever its size.  0 (default; PCC_PIPELINE_ENTROPY=host|gpu sets it): on the host.
+ *                 takes ~0.1 s whatever its size.  0 (default; PCC_PIPELINE_ENTROPY=host|gpu sets it): on the host.  Any other
+ *                 value is PCC_ERR_ARG; any other word in the variable means host, and says so on stderr once.
  *   "entropy_gpu_batch" (default 256): frames per flush and entropy thread.
  *   "rc_device_lanes" (default 0): with the entropy stage on the GPU, the device range coder codes one stream per LANE
  *                 instead of one per wave (same bytes; never timed on an MI355X).
@@ -213,7 +215,8 @@ void pcc_pipeline_destroy(pcc_pipeline *p);
 int pcc_pipeline_set_option(pcc_pipeline *p, const char *name, int value);
 /* what the pipeline runs with: "workers" (entropy threads), "gpu_threads", "contexts", "frames_per_coder_call" (the batch
  * size in force: PCC_PIPELINE_BATCH after its range check), "last_entropy_mode" (where the entropy stage of the last call
- * ran: 0 host, 1 GPU), "rc_device_lanes", "entropy_gpu_batch"; PCC_ERR_ARG for an unknown name */
+ * ran: 0 host, 1 GPU), "rc_device_lanes", "entropy_gpu_batch", "numa_node" (the host's NUMA node whose cores the pipeline's
+ * threads were given -- the node its GPU hangs off -- or PCC_NO_NUMA_NODE); PCC_ERR_ARG for an unknown name */
 int pcc_pipeline_get(pcc_pipeline *p, const char *name);
 int pcc_pipeline_contexts(pcc_pipeline *p);
 pcc_ctx *pcc_pipeline_context(pcc_pipeline *p, int index); /* for pcc_set_option on the contexts of the ring */
@@ -234,7 +237,9 @@ const char *pcc_pipeline_last_error(pcc_pipeline *p);
 /* ---- the same frame loop over several GPUs of one node (frames shard one per GPU, no collective) ----
  * One pipeline per entry of `devices` (a GPU may be named more than once); frame f goes to devices[f mod n_devices];
  * the bitstreams come back in sequence order with the frame ids of the reference's serial loop (dropped frames do not
- * consume one).  pcc_pipeline_create_multi returns NULL if any of the devices is missing.  With device-resident
+ * consume one).  pcc_pipeline_create_multi returns NULL if any of the devices is missing.  Every pipeline's host threads get
+ * cores of their own: cores of the NUMA node the pipeline's GPU hangs off (/sys/bus/pci/devices/<address>/numa_node), split
+ * among the pipelines whose GPUs share that node, if the host names a node for every GPU; an n-th of the allowed cores otherwise.  With device-resident
  * frames, frame f has to live on devices[f mod n_devices]. */
 typedef struct pcc_multi_pipeline pcc_multi_pipeline;
 pcc_multi_pipeline *pcc_pipeline_create_multi(const int *devices, int n_devices, int n_workers_per_device);

@@ -180,6 +180,20 @@ int pcc_debug_sort_plan(pcc_ctx *ctx, int32_t out[5]);
 int pcc_debug_pipeline_cpus(pcc_pipeline *p, int worker, int *out, int cap);
 /* 1 if the host range coder's AVX-512 path is in use on this machine (tests skip its cases where it is not) */
 int pcc_debug_host_rc_wide(void);
+/* where a GPU hangs off the host (csrc/pcc_numa.h; what the pipelines choose their cores by): the device's PCI address as the
+ * runtime prints it ("0000:c1:00.0"; cap >= 13), and the host's NUMA node nearest to it, -1 if nobody says --
+ * <sysfs_root>/bus/pci/devices/<address>/numa_node first (sysfs_root NULL = "/sys"), the runtime's HostNumaId attribute otherwise */
+int pcc_debug_device_pci_bus_id(int device, char *out, int cap);
+int pcc_debug_device_numa_node(int device, const char *sysfs_root);
+/* the planning alone, no GPU needed: `n_devices` pipelines whose GPUs sit at the PCI addresses `pci[d]`, a process that may
+ * run on `cpus[0..n_cpus)` (ascending), the topology read from `sysfs_root`.  Writes the node of pipeline d's share to
+ * node_out[d] (-1: shares are plain n-ths of the cores) and its cores to cores_out[d * cap .. ), their number to n_cores_out[d]
+ * (at most `cap` are written).  PCC_OK or PCC_ERR_ARG. */
+int pcc_debug_numa_plan(const char *sysfs_root, const char *const *pci, int n_devices, const int *cpus, int n_cpus,
+                        int *node_out, int *cores_out, int *n_cores_out, int cap);
+/* the NUMA node the page behind `p` lives on right now, -1 if the kernel does not say (not touched yet, no NUMA): where a
+ * page-locked landing buffer went */
+int pcc_debug_address_node(const void *p);
 
 #ifdef __cplusplus
 }

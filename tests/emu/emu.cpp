@@ -551,6 +551,13 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
   if (a == hipDeviceAttributeMultiprocessorCount) { *v = 256; return hipSuccess; }
   return hipErrorInvalidValue;
 }
+hipError_t hipDeviceGetPCIBusId(char* out, int len, int d) {
+  int n = 0;
+  hipGetDeviceCount(&n);
+  if (!out || len < 13 || d < 0 || d >= n) return hipErrorInvalidValue;
+  snprintf(out, (size_t)len, "0000:%02X:00.0", d + 1);   // (upper-case, as the runtime prints it)
+  return hipSuccess;
+}
 // The `race` build's access callbacks feed the happens-before checker of race.cpp when PCC_EMU_RACE=1 (the return address is the access)
 static inline void emu_touch(uintptr_t a, size_t n, bool store, void* pc) {
   if (emu::race::on()) emu::race::access(a, n, store, pc);

@@ -324,7 +324,7 @@ enum : unsigned { hipEventDefault = 0, hipEventBlockingSync = 1, hipEventDisable
 enum : unsigned { hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
 enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
 struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
-enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1, hipDeviceAttributeMultiprocessorCount = 2 };
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1, hipDeviceAttributeMultiprocessorCount = 2, hipDeviceAttributeHostNumaId = 3 };
 struct hipDeviceProp_t {
   char name[256];
   char gcnArchName[256];
@@ -343,6 +343,7 @@ hipError_t hipSetDevice(int d);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int d);
+hipError_t hipDeviceGetPCIBusId(char* out, int len, int d);   // "0000:<d + 1, two hex digits>:00.0": a name for made-up sysfs trees
 hipError_t hipMalloc(void** p, size_t bytes);
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }
 hipError_t hipFree(void* p);

@@ -94,4 +94,7 @@ def test_two_ranks_started_by_the_bench_itself():
     for r in d["ranks"]:
         assert r["value"] > 0 and r["gpu_only_mpoints_per_s"] > 0 and r["host_cpus_for_this_rank"] >= 1
         assert r["host_bound"] == (r["entropy_stage"]["host_frames_per_s_bound"] < r["entropy_stage"]["gpu_stage_frames_per_s"])
+        # which NUMA node the rank's host threads sit on (None: an n-th of the cores, e.g. both ranks on GPU 0 as here), the GPU's own
+        # node and the node the runtime put the page-locked landing buffer on
+        assert "numa_node" in r and "gpu_numa_node" in r and "landing_buffer_numa_node" in r
     assert d["host_bound"] == any(r["host_bound"] for r in d["ranks"])

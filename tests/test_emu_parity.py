@@ -185,11 +185,53 @@ def test_bench_script_with_two_ranks_on_the_executor(emu_libs):
         e = r["entropy_stage"]
         assert e["ran_on"] == "host" and e["host_frames_per_s_bound"] > 0 and e["gpu_stage_frames_per_s"] > 0 and e["host_cpu_ms_per_frame"] > 0
         assert r["host_bound"] == (e["host_frames_per_s_bound"] < e["gpu_stage_frames_per_s"])
+        # where the rank's host threads were placed: this container names no node for the executor's device
+        assert "numa_node" in r and "gpu_numa_node" in r and "landing_buffer_numa_node" in r and r["numa_node"] is None
     assert line["host_bound"] == any(r["host_bound"] for r in line["ranks"])
     # the whole-job value is no more than the sum of the ranks' own rates (maximum over ranks of the time)
     assert line["value"] <= sum(r["value"] for r in line["ranks"]) * 1.001
     assert abs(line["gpu_only_mpoints_per_s"] - sum(r["gpu_only_mpoints_per_s"] for r in line["ranks"])) < 0.2
     assert line["config"]["frames_per_coder_call"] == 4 and line["entropy_coder"]["device_form"] == "waves"
+
+
+def test_multi_gpu_placement_on_a_made_up_two_socket_host(emu_libs, tmp_path):
+    """pcc_pipeline_create_multi and the one-process-per-GPU ranks choose their cores by the GPU's NUMA node (csrc/pcc_numa.h).  This
+    container has one node and no GPU: the executor shows two devices (PCC_EMU_DEVICES=2) and the planning reads a made-up sysfs tree
+    (PCC_SYSFS_ROOT, read by developer builds and the executor only) in which the allowed CPUs are two nodes and GPU 0 hangs off
+    node 1, GPU 1 off node 0.  The live test of tests/test_numa_plan.py then checks the affinity masks of the real threads."""
+    from test_numa_plan import make_tree
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("too few CPUs to make two nodes of")
+    half = len(allowed) // 2
+    make_tree(str(tmp_path), {0: allowed[:half], 1: allowed[half:]}, [1, 0])
+    env = dict(os.environ, PCC_LIB=emu_libs[0], PCC_EMU_DEVICES="2", PCC_SYSFS_ROOT=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-s", "-p", "no:cacheprovider", "--timeout", "900", "tests/test_numa_plan.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("OK nodes")][-1]
+    assert "OK nodes [1, 0] devices [0, 1]" in line, line
+    # one process per GPU (torchrun's LOCAL_RANK r of LOCAL_WORLD_SIZE 2, rank i on GPU i): rank 0's pipeline on node 1's cores, rank
+    # 1's on node 0's; a rank on another GPU than its number (the bench's share-one-GPU hook) falls back to its n-th of all cores
+    code = """
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+import __graft_entry__ as G
+b = G.load_package().binding
+lib = b.load_library()
+lib.pcc_debug_pipeline_cpus.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+p = b.Pipeline(int(sys.argv[1]), 1)
+buf = (C.c_int * 1024)()
+n = lib.pcc_debug_pipeline_cpus(p.h, 0, buf, 1024)
+print("RANK", p.get("numa_node"), sorted(buf[:n]))
+p.close()
+""" % ROOT
+    for rank, device, node, cpus in ((0, 0, 1, allowed[half:]), (1, 1, 0, allowed[:half]), (1, 0, None, allowed[half:2 * half])):
+        e = dict(env, LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="2")
+        r = subprocess.run([sys.executable, "-c", code, str(device)], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        got = [l for l in r.stdout.splitlines() if l.startswith("RANK")][-1]
+        assert got == "RANK %s %s" % (node, cpus), (rank, device, got)
 
 
 def test_product_library_has_no_cpu_fallback(pkg):

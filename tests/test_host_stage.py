@@ -440,6 +440,35 @@ def test_decoder_accepts_streams_that_compress_a_thousandfold(pkg, oracle):
     struct.pack_into("<I", stream, cen_at, n_cen + 3)
     with pytest.raises(b.PccError):
         host.decode_intra(bytes(stream))
+    # a voxel count that the occupancy bytes cannot open (eight voxels per branch byte at most) is refused before anything is
+    # sized by it (centroids off in this copy of the header, so that the three-bytes-per-voxel check is not what catches it)
+    stream = bytearray(r.bitstream)
+    assert struct.unpack_from("<Q", stream, at + 7)[0] == n_points and stream[at + 4 + 1 + 1 + 1 + 8 + 8 + 1 + 8 + 48] == 1
+    stream[at + 4 + 1 + 1 + 1 + 8 + 8 + 1 + 8 + 48] = 0          # do_voxel_centroid
+    struct.pack_into("<Q", stream, at + 7, 8 * n_occ + 1)
+    with pytest.raises(b.PccError, match="PCC_ERR_STREAM"):
+        host.decode_intra(bytes(stream))
+    # do_voxel_grid false (the reference's point-detail tail, impl.hpp:1728-1757: the count is points, not voxels): said, not misread
+    stream = bytearray(r.bitstream)
+    assert stream[at + 5] == 1
+    stream[at + 5] = 0
+    with pytest.raises(b.PccError, match="PCC_ERR_UNSUPPORTED"):
+        host.decode_intra(bytes(stream))
+
+
+def test_the_binding_warns_when_a_developer_switch_is_set_for_a_library_that_ignores_it():
+    """csrc/pcc_dev.h: the shipped library reads no developer switch.  A tool that sets one without pointing PCC_LIB at the developer
+    build would measure the default and report it under the switch's name: load_library() says so."""
+    import subprocess
+    code = ("import __graft_entry__ as G, warnings\nwarnings.simplefilter('error')\n"
+            "G.load_package().binding.load_library()\nprint('loaded')")
+    for extra, loads in ((dict(PCC_DECODE_TRACE="1"), False), (dict(PCC_DECODE_TRACE="1", PCC_LIB=DEV_LIB), True), ({}, True)):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PCC_")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+        assert ("loaded" in r.stdout) == loads, (extra, r.stdout, r.stderr[-600:])
+        if not loads:
+            assert "does not read developer switches" in r.stderr and "libpcc_hip_dev.so" in r.stderr
 
 
 def test_host_decoder_accepts_the_2048_wide_strip_a_reference_encoder_writes(pkg, oracle):

@@ -119,5 +119,10 @@ def entropy_batch_and_pipeline(pkg, oracle, lanes):
         pipe.set_option("entropy_on_gpu", 0)
         assert [g[0] for g in pipe.encode_host(frames, b.make_params(frame_id=2, **kw))] == ref
         assert pipe.last_entropy_mode() == 0
+        # 0 or 1: the -1 that meant "decide per call" in rounds 3-4 is refused, not silently taken for the GPU coder
+        for bad in (-1, 2):
+            with pytest.raises(b.PccError, match="PCC_ERR_ARG"):
+                pipe.set_option("entropy_on_gpu", bad)
+        assert [g[0] for g in pipe.encode_host(frames[:2], b.make_params(frame_id=2, **kw))] == ref[:2] and pipe.last_entropy_mode() == 0
     finally:
         pipe.close()

@@ -25,9 +25,15 @@ PCC_COMPAT int pcc_pipeline_get(pcc_pipeline* p, const char* name) {
   if (!strcmp(name, "contexts")) return pcc_pipeline_contexts(p);
   if (!strcmp(name, "last_entropy_mode")) return pcc_pipeline_last_entropy_mode(p);
   if (!strcmp(name, "frames_per_coder_call")) return 0;   // (not known from outside those builds)
+  if (!strcmp(name, "numa_node")) return -100;            // PCC_NO_NUMA_NODE: those builds split the allowed cores evenly
   if (!strcmp(name, "gpu_threads") || !strcmp(name, "rc_device_lanes") || !strcmp(name, "entropy_gpu_batch")) return 0;
   return -1;
 }
 PCC_COMPAT int pcc_entropy_batch_set_option(pcc_entropy_batch*, const char*, int) { return 0; }   // (the form was a process-wide option there)
 PCC_COMPAT int pcc_debug_host_rc_wide(void) { return 0; }
 PCC_COMPAT int pcc_debug_pipeline_cpus(pcc_pipeline*, int, int*, int) { return -1; }
+// (round 6: placement by NUMA node; the older builds split the allowed cores evenly and say so)
+PCC_COMPAT int pcc_debug_device_pci_bus_id(int, char* out, int cap) { if (out && cap > 0) out[0] = 0; return -2; }
+PCC_COMPAT int pcc_debug_device_numa_node(int, const char*) { return -1; }
+PCC_COMPAT int pcc_debug_numa_plan(const char*, const char* const*, int, const int*, int, int*, int*, int*, int) { return -1; }
+PCC_COMPAT int pcc_debug_address_node(const void*) { return -1; }

@@ -1,7 +1,9 @@
 #!/bin/bash
 # short calls of the pipeline: entropy threads unpinned / one core each / a group of cores each, and how the frames of a
 # short call are spread over the threads (PCC_PIPELINE_SPREAD); medians over interleaved repetitions
+# PCC_PIPELINE_SPREAD is a developer switch: only the developer build reads it (the shipped library would silently run its default)
 OUT=gpurun_out/${1:-r02_pin}; mkdir -p $OUT; rm -f $OUT/calls.txt
+export PCC_LIB=${PCC_LIB:-$PWD/cwi-pcl-codec_amd/libpcc_hip_dev.so} PCC_ALLOW_NON_PRODUCT_LIB=1
 for round in 1 2 3; do
 for v in none default; do
   unset PCC_PIPELINE_PIN PCC_PIPELINE_SPREAD
