@@ -85,5 +85,13 @@ def pytest_collection_modifyitems(config, items):
     gpu = [it for it in items if it.get_closest_marker("gpu")]
     if not gpu:
         return
+    # A GPU test that hangs (a wedged queue, a kernel that never ends) sits inside a C call, where pytest-timeout's signal method
+    # cannot reach it: the thread method ends the whole run with the stacks on stderr instead -- with -x nothing is lost, and the box
+    # gets its GPU back instead of being held until the driver's own limit.  Every in-kernel wait of the product is bounded
+    # (kSpinLimit), so this is for faults, not for the expected path.  Tests that set their own timeout keep it.
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in gpu:
+            if not it.get_closest_marker("timeout"):
+                it.add_marker(pytest.mark.timeout(1800, method="thread"))
     ordered = iter(sorted(gpu, key=lambda it: gpu_order_rank(it.nodeid)))      # stable: file order inside one pattern
     items[:] = [next(ordered) if it.get_closest_marker("gpu") else it for it in items]
