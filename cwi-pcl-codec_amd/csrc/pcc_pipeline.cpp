@@ -620,6 +620,7 @@ pcc_pipeline* pcc_pipeline_create(int device, int n_workers) {
     }
     int mode = (span >= 2 * (size_t)p->n_entropy) ? 2 : 0;  // 0 none, 1 cores, 2 groups
     if (e) mode = !strcmp(e, "cores") ? 1 : (!strcmp(e, "groups") ? 2 : 0);
+    if (!mode) p->numa_node = -1;  // nobody is pinned (too few cores for this many threads, or PCC_PIPELINE_PIN=none): "numa_node" must not claim a placement
     const size_t per = mode == 2 ? std::min<size_t>(8, std::max<size_t>(1, span / (size_t)std::max(p->n_entropy, 1))) : 1;
     // the range [base, base + span) of `cores` is this pipeline's (the caller's, or this rank's share); `start` is where
     // inside it the first entropy thread goes -- behind the cores of earlier pipelines of this process, wrapping INSIDE

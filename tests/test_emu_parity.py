@@ -226,6 +226,12 @@ n = lib.pcc_debug_pipeline_cpus(p.h, 0, buf, 1024)
 print("RANK", p.get("numa_node"), sorted(buf[:n]))
 p.close()
 """ % ROOT
+    # a pipeline whose share is too small to pin on (fewer than two cores per entropy thread) pins nobody -- and does not claim a node
+    many = half // 2 + 1
+    code2 = ("import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as G\nb = G.load_package().binding\n"
+             "m = b.MultiPipeline([0, 1], %d)\nprint('NODES', m.numa_nodes())\nm.close()\n" % (ROOT, many))
+    r = subprocess.run([sys.executable, "-c", code2], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NODES [None, None]" in r.stdout, (r.stdout + r.stderr)[-2000:]
     for rank, device, node, cpus in ((0, 0, 1, allowed[half:]), (1, 1, 0, allowed[:half]), (1, 0, None, allowed[half:2 * half])):
         e = dict(env, LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="2")
         r = subprocess.run([sys.executable, "-c", code, str(device)], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
